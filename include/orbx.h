@@ -1,0 +1,154 @@
+/* orbx.h — C ABI of the MI355X-native ORB extract + initialization-match hot path.
+ *
+ * Drop-in boundary for zeal-up/ORB_SLAM_Tracking's
+ *   ORBextractor::ORBextractor / operator()            (Features/ORBextractor.hpp:68-85, .cpp:492-595, 1531-1653)
+ *   ORBextractor getters + mvImagePyramid              (Features/ORBextractor.hpp:87-111)
+ *   ORBmatcher::SearchForInitialization                (Features/ORBmatcher.hpp:36, .cpp:11-150)
+ *   Frame grid rules the matcher depends on            (SlamTypes/Frame.cpp:70-99, 163-206)
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary.  The C++ classes with the
+ * reference's own signatures live in include/orbx_shim.hpp and call only the functions below.
+ *
+ * All compute runs in hand-written HIP kernels for gfx950 (liborbx.so).  There is no CPU fallback:
+ * every entry point that computes returns ORBX_E_HIP when no usable device / kernel image exists.
+ *
+ * Threading: one orbx_ctx is bound to one device; calls on one ctx must be
+ * serialised by the caller; different ctxs are independent (multi-GPU = one ctx per device/process).
+ */
+#ifndef ORBX_H_
+#define ORBX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes (negative).  ORBX_E_EMPTY == -1 keeps `operator()`'s "return -1 on empty image"
+ * (Features/ORBextractor.cpp:1536). */
+#define ORBX_OK 0
+#define ORBX_E_EMPTY (-1)
+#define ORBX_E_BADARG (-2)
+#define ORBX_E_TOOSMALL (-3) /* a pyramid level is narrower than one FAST cell: UB upstream (cpp:1071-1074) */
+#define ORBX_E_HIP (-4)
+#define ORBX_E_CAPACITY (-5)
+
+/* mirrors cv::KeyPoint (28 bytes): pt.x pt.y size angle response octave class_id */
+typedef struct orbx_keypoint {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} orbx_keypoint;
+
+/* ORBextractor ctor arguments (Features/ORBextractor.hpp:68-69) */
+typedef struct orbx_params {
+  int32_t nfeatures;
+  float scale_factor;
+  int32_t nlevels;
+  int32_t ini_th_fast;
+  int32_t min_th_fast;
+} orbx_params;
+
+/* Frame::mnMinX/mnMaxX/mnMinY/mnMaxY (SlamTypes/Frame.hpp, static ints) */
+typedef struct orbx_bounds {
+  int32_t min_x, max_x, min_y, max_y;
+} orbx_bounds;
+
+/* the three counters SearchForInitialization prints (Features/ORBmatcher.cpp:144-147) */
+typedef struct orbx_match_stats {
+  int32_t invalid_by_distance, invalid_by_ratio, invalid_by_orientation;
+} orbx_match_stats;
+
+typedef struct orbx_ctx orbx_ctx;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+/* Creates a context on `device_id` able to process batches of up to `max_batch` frames of up to
+ * max_width x max_height pixels.  `stream` is an optional hipStream_t (as void*) the caller wants
+ * the work issued on (e.g. torch's current stream); NULL = the ctx creates its own.
+ * Replaces ORBextractor::ORBextractor (cpp:492-595); scaleFactor==1 with nlevels>1 returns
+ * ORBX_E_BADARG instead of exit(1) (cpp:502-505). */
+int orbx_create(const orbx_params* params, int device_id, int max_width, int max_height, int max_batch,
+                void* stream, orbx_ctx** out);
+void orbx_destroy(orbx_ctx* ctx);
+const char* orbx_last_error(const orbx_ctx* ctx);
+
+/* ---- getters (Features/ORBextractor.hpp:87-108) ------------------------------------------- */
+int orbx_get_levels(const orbx_ctx* ctx);
+float orbx_get_scale_factor(const orbx_ctx* ctx);
+/* each out array has nlevels entries; any pointer may be NULL */
+int orbx_get_tables(const orbx_ctx* ctx, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                    int32_t* features_per_level);
+int orbx_get_umax(const orbx_ctx* ctx, int32_t* umax16);
+
+/* ---- extraction: ORBextractor::operator() (cpp:1531-1653) --------------------------------- */
+/* One frame from host memory.  Returns monoIndex (>= 0; == *n_out when lap0 == lap1 == 0, as in
+ * Frame.cpp:58-60) or a negative error.  `kps`/`desc32` must hold `capacity` >= nfeatures entries
+ * (keypoints 28 B, descriptors 32 B each). */
+int orbx_extract(orbx_ctx* ctx, const uint8_t* img, int width, int height, int stride, int lap0, int lap1,
+                 orbx_keypoint* kps, uint8_t* desc32, int capacity, int* n_out);
+
+/* `n_frames` same-sized frames from host memory (frame f at imgs + f*frame_stride_bytes).
+ * Outputs: frame f's keypoints at kps + f*capacity, descriptors at desc32 + f*capacity*32,
+ * counts n_out[f], return values (monoIndex) mono_out[f] (may be NULL). */
+int orbx_extract_batch(orbx_ctx* ctx, int n_frames, const uint8_t* imgs, int width, int height, int stride,
+                       size_t frame_stride_bytes, int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc32,
+                       int capacity, int* n_out, int* mono_out);
+
+/* Same, but the frames are already resident in device memory (HBM) and results stay there:
+ * d_kps / d_desc32 / d_n_out are device pointers (d_n_out: int32[n_frames]).  Nothing is copied
+ * to the host except what the host-side selection stage needs.  The call returns after the work
+ * has been issued and completed on the ctx stream (it synchronises internally between stages). */
+int orbx_extract_batch_device(orbx_ctx* ctx, int n_frames, const uint8_t* d_imgs, int width, int height,
+                              int stride, size_t frame_stride_bytes, orbx_keypoint* d_kps, uint8_t* d_desc32,
+                              int capacity, int32_t* d_n_out);
+
+/* mvImagePyramid (hpp:111): copies level `level` of frame `frame` of the last extract call to host.
+ * `border` = 0 copies the w x h level; border = 19 reproduces the reference's REFLECT_101 ring
+ * (cpp:1689,1708), dst then is (w+38) x (h+38).  dst_stride in bytes. */
+int orbx_level_size(const orbx_ctx* ctx, int level, int* width, int* height);
+int orbx_download_pyramid(orbx_ctx* ctx, int frame, int level, int border, uint8_t* dst, int dst_stride);
+
+/* ---- matching: ORBmatcher::SearchForInitialization (ORBmatcher.cpp:11-150) ----------------- */
+/* k1/d1 = F1.mvKeysUn / F1.mDescriptors (n1 entries), k2/d2 = F2's; `bounds` = Frame::mnMin/Max*;
+ * the 64x48 grid of F2 is rebuilt inside with Frame::PosInGrid's rule (Frame.cpp:89-99), so callers
+ * do not pass mGrid.  matches12 has n1 entries (-1 = none).  Returns nmatches exactly as the
+ * reference computes it (including its double-decrement quirk), or a negative error. */
+int orbx_match_init(orbx_ctx* ctx, const orbx_keypoint* k1, const uint8_t* d1, int n1, const orbx_keypoint* k2,
+                    const uint8_t* d2, int n2, const orbx_bounds* bounds, int window_size, float nnratio,
+                    int check_orientation, int32_t* matches12, orbx_match_stats* stats);
+
+/* Batched, device-resident: pair p matches frame first[p] against frame second[p] of the arrays a
+ * previous orbx_extract_batch_device call filled (same capacity / layout).  d_matches12 is
+ * int32[n_pairs*capacity], d_nmatches int32[n_pairs], d_stats (nullable) int32[n_pairs*3];
+ * h_first/h_second are host arrays. */
+int orbx_match_init_batch_device(orbx_ctx* ctx, int n_pairs, const int32_t* h_first, const int32_t* h_second,
+                                 const orbx_keypoint* d_kps, const uint8_t* d_desc32, const int32_t* d_n,
+                                 int capacity, const orbx_bounds* bounds, int window_size, float nnratio,
+                                 int check_orientation, int32_t* d_matches12, int32_t* d_nmatches,
+                                 int32_t* d_stats);
+
+/* ---- measurement hooks (bench.py; HIP events on the ctx stream) ---------------------------- */
+#define ORBX_STAGE_PYRAMID 0
+#define ORBX_STAGE_FAST 1
+#define ORBX_STAGE_SELECT 2 /* quadtree selection incl. its transfers */
+#define ORBX_STAGE_DESCRIBE 3
+#define ORBX_STAGE_MATCH 4
+#define ORBX_STAGE_COUNT 5
+/* enable: record hipEvents around every stage; accumulated device ms and launch counts since the
+ * last reset are returned by orbx_profile_get (arrays of ORBX_STAGE_COUNT). */
+int orbx_profile_enable(orbx_ctx* ctx, int on);
+int orbx_profile_reset(orbx_ctx* ctx);
+int orbx_profile_get(orbx_ctx* ctx, double* ms, int64_t* launches);
+
+/* ---- test hooks (used by tests/ only; stable but not part of the reference surface) -------- */
+/* candidates of (frame, level) of the last extract call, as produced by the FAST kernel, sorted
+ * into the reference's order (cell row, cell col, y, x): xyr = (x, y, response) triples relative to
+ * (minBorderX, minBorderY) like vToDistributeKeys (cpp:1134-1137).  Returns the count. */
+int orbx_debug_candidates(orbx_ctx* ctx, int frame, int level, float* xyr, int cap);
+/* quadtree selection alone: DistributeOctTree (cpp:698-1011) on caller-supplied candidates. */
+int orbx_debug_distribute(const float* xyr, int n, int min_x, int max_x, int min_y, int max_y, int n_features,
+                          float* out_xyr, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H_ */
