@@ -110,11 +110,12 @@ int orbx_download_pyramid(orbx_ctx* ctx, int frame, int level, int border, uint8
 /* ---- matching: ORBmatcher::SearchForInitialization (ORBmatcher.cpp:11-150) ----------------- */
 /* k1/d1 = F1.mvKeysUn / F1.mDescriptors (n1 entries), k2/d2 = F2's; `bounds` = Frame::mnMin/Max*;
  * the 64x48 grid of F2 is rebuilt inside with Frame::PosInGrid's rule (Frame.cpp:89-99), so callers
- * do not pass mGrid.  matches12 has n1 entries (-1 = none).  Returns nmatches exactly as the
- * reference computes it (including its double-decrement quirk), or a negative error. */
+ * do not pass mGrid.  matches12 has n1 entries (-1 = none).  *nmatches receives the reference's return value
+ * exactly as it computes it (its double-decrement quirk can make it differ from the number of non-negative
+ * entries, even negative), which is why it is an out-parameter; the function returns ORBX_OK or an error. */
 int orbx_match_init(orbx_ctx* ctx, const orbx_keypoint* k1, const uint8_t* d1, int n1, const orbx_keypoint* k2,
                     const uint8_t* d2, int n2, const orbx_bounds* bounds, int window_size, float nnratio,
-                    int check_orientation, int32_t* matches12, orbx_match_stats* stats);
+                    int check_orientation, int32_t* matches12, int32_t* nmatches, orbx_match_stats* stats);
 
 /* Batched, device-resident: pair p matches frame first[p] against frame second[p] of the arrays a
  * previous orbx_extract_batch_device call filled (same capacity / layout).  d_matches12 is

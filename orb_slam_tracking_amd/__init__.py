@@ -1,0 +1,333 @@
+"""orb_slam_tracking_amd — MI355X-native ORB extraction + initialization matching.
+
+Thin ctypes mirror of the C ABI in ``include/orbx.h`` (``liborbx.so``: hand-written HIP kernels for gfx950 plus the
+C++ host pipeline).  The classes keep the names and argument meaning of the reference's C++ interface for this path:
+
+* ``ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)`` / ``__call__``  -- Features/ORBextractor.hpp:68-85
+* ``ORBmatcher(nnratio=0.6, checkOri=True).SearchForInitialization(F1, F2, windowSize=100)`` -- Features/ORBmatcher.hpp:15,36
+* ``Frame`` -- the part of SlamTypes/Frame.{hpp,cpp} the matcher reads (mvKeys, mvKeysUn, mDescriptors, N, image bounds)
+
+There is NO CPU fallback: importing works anywhere, but every compute call raises ``OrbxError`` unless liborbx.so is
+built and a HIP device is usable.  (The C++ drop-in classes live in include/orbx_shim.hpp.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+__all__ = ["KEYPOINT_DTYPE", "OrbxError", "ORBextractor", "ORBmatcher", "Frame", "lib", "lib_path",
+           "STAGES", "E_EMPTY", "E_BADARG", "E_TOOSMALL", "E_HIP", "E_CAPACITY"]
+
+# mirrors cv::KeyPoint / orbx_keypoint (28 bytes)
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                           ("octave", "<i4"), ("class_id", "<i4")])
+assert KEYPOINT_DTYPE.itemsize == 28
+
+E_EMPTY, E_BADARG, E_TOOSMALL, E_HIP, E_CAPACITY = -1, -2, -3, -4, -5
+_ERRNAMES = {-1: "ORBX_E_EMPTY", -2: "ORBX_E_BADARG", -3: "ORBX_E_TOOSMALL", -4: "ORBX_E_HIP", -5: "ORBX_E_CAPACITY"}
+STAGES = ("pyramid", "fast", "select", "describe", "match")
+
+
+class OrbxError(RuntimeError):
+    def __init__(self, code: int, what: str = ""):
+        self.code = code
+        super().__init__("%s (%d)%s" % (_ERRNAMES.get(code, "ORBX_E_?"), code, (": " + what) if what else ""))
+
+
+class _Params(ctypes.Structure):
+    _fields_ = [("nfeatures", ctypes.c_int32), ("scale_factor", ctypes.c_float), ("nlevels", ctypes.c_int32),
+                ("ini_th_fast", ctypes.c_int32), ("min_th_fast", ctypes.c_int32)]
+
+
+class _Bounds(ctypes.Structure):
+    _fields_ = [("min_x", ctypes.c_int32), ("max_x", ctypes.c_int32), ("min_y", ctypes.c_int32), ("max_y", ctypes.c_int32)]
+
+
+class _Stats(ctypes.Structure):
+    _fields_ = [("invalid_by_distance", ctypes.c_int32), ("invalid_by_ratio", ctypes.c_int32),
+                ("invalid_by_orientation", ctypes.c_int32)]
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "liborbx.so")
+
+
+_LIB = None
+
+
+def lib() -> ctypes.CDLL:
+    """Loads liborbx.so (built in-tree by ``__graft_entry__.build()`` / ``make -C orb_slam_tracking_amd/csrc``)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise OrbxError(E_HIP, "liborbx.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+    L = ctypes.CDLL(path)
+    vp, i32, f32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+    L.orbx_create.argtypes = [ctypes.POINTER(_Params), i32, i32, i32, i32, vp, ctypes.POINTER(vp)]
+    L.orbx_destroy.argtypes = [vp]
+    L.orbx_destroy.restype = None
+    L.orbx_last_error.argtypes = [vp]
+    L.orbx_last_error.restype = ctypes.c_char_p
+    L.orbx_get_levels.argtypes = [vp]
+    L.orbx_get_scale_factor.argtypes = [vp]
+    L.orbx_get_scale_factor.restype = f32
+    L.orbx_get_tables.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.orbx_get_umax.argtypes = [vp, vp]
+    L.orbx_extract.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]
+    L.orbx_extract_batch.argtypes = [vp, i32, vp, i32, i32, i32, sz, i32, i32, vp, vp, i32, vp, vp]
+    L.orbx_extract_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, sz, vp, vp, i32, vp]
+    L.orbx_level_size.argtypes = [vp, i32, vp, vp]
+    L.orbx_download_pyramid.argtypes = [vp, i32, i32, i32, vp, i32]
+    L.orbx_match_init.argtypes = [vp, vp, vp, i32, vp, vp, i32, ctypes.POINTER(_Bounds), i32, f32, i32, vp,
+                                  ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_Stats)]
+    L.orbx_match_init_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, ctypes.POINTER(_Bounds), i32, f32, i32,
+                                               vp, vp, vp]
+    L.orbx_profile_enable.argtypes = [vp, i32]
+    L.orbx_profile_reset.argtypes = [vp]
+    L.orbx_profile_get.argtypes = [vp, vp, vp]
+    L.orbx_debug_candidates.argtypes = [vp, i32, i32, vp, i32]
+    L.orbx_debug_distribute.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32]
+    _LIB = L
+    return L
+
+
+def _ptr(a) -> ctypes.c_void_p:
+    if a is None:
+        return ctypes.c_void_p(0)
+    if isinstance(a, np.ndarray):
+        return ctypes.c_void_p(a.ctypes.data)
+    if hasattr(a, "data_ptr"):  # torch tensor
+        return ctypes.c_void_p(a.data_ptr())
+    return ctypes.c_void_p(int(a))
+
+
+class ORBextractor:
+    """Features/ORBextractor.hpp:55-158.  One instance == one orbx_ctx bound to one device; calls are serialised by
+    the caller (the reference's operator() is not re-entrant either, cpp:1669)."""
+
+    HARRIS_SCORE, FAST_SCORE = 0, 1
+
+    def __init__(self, nfeatures: int, scaleFactor: float, nlevels: int, iniThFAST: int, minThFAST: int, *,
+                 max_width: int = 1920, max_height: int = 1080, max_batch: int = 1, device: int = 0,
+                 stream: Optional[int] = None):
+        self._L = lib()
+        self._h = ctypes.c_void_p(0)
+        p = _Params(int(nfeatures), float(scaleFactor), int(nlevels), int(iniThFAST), int(minThFAST))
+        r = self._L.orbx_create(ctypes.byref(p), int(device), int(max_width), int(max_height), int(max_batch),
+                                ctypes.c_void_p(stream or 0), ctypes.byref(self._h))
+        if r != 0:
+            self._h = ctypes.c_void_p(0)
+            raise OrbxError(r, "orbx_create failed (no usable HIP device / kernel image?)" if r == E_HIP else "orbx_create")
+        self.nfeatures, self.nlevels, self.device, self.max_batch = int(nfeatures), int(nlevels), int(device), int(max_batch)
+        q = np.zeros(self.nlevels, np.int32)
+        self._L.orbx_get_tables(self._h, None, None, None, None, _ptr(q))
+        self.capacity = max(int(q.sum()), 1)
+
+    # -- lifetime ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.orbx_destroy(self._h)
+            self._h = ctypes.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, r: int, what: str = "") -> int:
+        if r < 0:
+            raise OrbxError(r, (self._L.orbx_last_error(self._h) or b"").decode() or what)
+        return r
+
+    # -- getters (hpp:87-108) --------------------------------------------------------------------
+    def GetLevels(self) -> int:
+        return self._L.orbx_get_levels(self._h)
+
+    def GetScaleFactor(self) -> float:
+        return float(self._L.orbx_get_scale_factor(self._h))
+
+    def _table(self, idx: int, dtype=np.float32) -> np.ndarray:
+        out = np.zeros(self.nlevels, dtype)
+        args = [None] * 5
+        args[idx] = _ptr(out)
+        self._L.orbx_get_tables(self._h, *args)
+        return out
+
+    def GetScaleFactors(self):
+        return self._table(0)
+
+    def GetInverseScaleFactors(self):
+        return self._table(1)
+
+    def GetScaleSigmaSquares(self):
+        return self._table(2)
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._table(3)
+
+    def GetNumFeaturesPerLevel(self):
+        return self._table(4, np.int32)
+
+    def umax(self) -> np.ndarray:
+        out = np.zeros(16, np.int32)
+        self._L.orbx_get_umax(self._h, _ptr(out))
+        return out
+
+    # -- operator() (cpp:1531-1653) ----------------------------------------------------------------
+    def __call__(self, image: np.ndarray, mask=None, vLappingArea: Sequence[int] = (0, 0)) -> Tuple[int, np.ndarray, np.ndarray]:
+        """Returns (monoIndex, keypoints[KEYPOINT_DTYPE], descriptors[N,32] uint8); -1 for an empty image (cpp:1536)."""
+        if image is None or image.size == 0:
+            return -1, np.zeros(0, KEYPOINT_DTYPE), np.zeros((0, 32), np.uint8)
+        if image.dtype != np.uint8 or image.ndim != 2:
+            raise OrbxError(E_BADARG, "image must be a 2-D uint8 array (CV_8UC1, cpp:1541)")
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        h, w = image.shape
+        kps = np.zeros(self.capacity, KEYPOINT_DTYPE)
+        desc = np.zeros((self.capacity, 32), np.uint8)
+        n = ctypes.c_int(0)
+        r = self._L.orbx_extract(self._h, _ptr(image), w, h, image.strides[0], int(vLappingArea[0]), int(vLappingArea[1]),
+                                 _ptr(kps), _ptr(desc), self.capacity, ctypes.byref(n))
+        self._check(r, "orbx_extract")
+        return r, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch(self, images: np.ndarray, vLappingArea: Sequence[int] = (0, 0)):
+        """images: [B, H, W] uint8 (host).  Returns a list of (monoIndex, keypoints, descriptors) per frame."""
+        images = np.ascontiguousarray(images)
+        if images.dtype != np.uint8 or images.ndim != 3:
+            raise OrbxError(E_BADARG, "images must be [B,H,W] uint8")
+        B, h, w = images.shape
+        kps = np.zeros((B, self.capacity), KEYPOINT_DTYPE)
+        desc = np.zeros((B, self.capacity, 32), np.uint8)
+        n = np.zeros(B, np.int32)
+        mono = np.zeros(B, np.int32)
+        r = self._L.orbx_extract_batch(self._h, B, _ptr(images), w, h, w, w * h, int(vLappingArea[0]), int(vLappingArea[1]),
+                                       _ptr(kps), _ptr(desc), self.capacity, _ptr(n), _ptr(mono))
+        self._check(r, "orbx_extract_batch")
+        return [(int(mono[f]), kps[f, :n[f]].copy(), desc[f, :n[f]].copy()) for f in range(B)]
+
+    def extract_batch_device(self, d_imgs, n_frames: int, width: int, height: int, stride: int, frame_stride: int,
+                             d_kps, d_desc, d_n, capacity: Optional[int] = None) -> None:
+        """Frames resident in HBM in, keypoints/descriptors/counts resident in HBM out (device pointers or torch tensors)."""
+        r = self._L.orbx_extract_batch_device(self._h, int(n_frames), _ptr(d_imgs), int(width), int(height), int(stride),
+                                              int(frame_stride), _ptr(d_kps), _ptr(d_desc), int(capacity or self.capacity),
+                                              _ptr(d_n))
+        self._check(r, "orbx_extract_batch_device")
+
+    def match_pairs_device(self, first: np.ndarray, second: np.ndarray, d_kps, d_desc, d_n, bounds: Tuple[int, int, int, int],
+                           d_matches12, d_nmatches, d_stats=None, windowSize: int = 100, nnratio: float = 0.9,
+                           checkOri: bool = True, capacity: Optional[int] = None) -> None:
+        first = np.ascontiguousarray(first, np.int32)
+        second = np.ascontiguousarray(second, np.int32)
+        b = _Bounds(*[int(v) for v in bounds])
+        r = self._L.orbx_match_init_batch_device(self._h, len(first), _ptr(first), _ptr(second), _ptr(d_kps), _ptr(d_desc),
+                                                 _ptr(d_n), int(capacity or self.capacity), ctypes.byref(b), int(windowSize),
+                                                 float(nnratio), int(bool(checkOri)), _ptr(d_matches12), _ptr(d_nmatches),
+                                                 _ptr(d_stats))
+        self._check(r, "orbx_match_init_batch_device")
+
+    # -- mvImagePyramid (hpp:111) ----------------------------------------------------------------
+    def level_size(self, level: int) -> Tuple[int, int]:
+        w, h = ctypes.c_int(0), ctypes.c_int(0)
+        self._check(self._L.orbx_level_size(self._h, level, ctypes.byref(w), ctypes.byref(h)), "orbx_level_size")
+        return w.value, h.value
+
+    def image_pyramid(self, level: int, frame: int = 0, border: int = 0) -> np.ndarray:
+        w, h = self.level_size(level)
+        out = np.zeros((h + 2 * border, w + 2 * border), np.uint8)
+        self._check(self._L.orbx_download_pyramid(self._h, frame, level, border, _ptr(out), out.strides[0]), "orbx_download_pyramid")
+        return out
+
+    # -- measurement / test hooks ------------------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        self._L.orbx_profile_enable(self._h, int(on))
+
+    def profile_reset(self):
+        self._L.orbx_profile_reset(self._h)
+
+    def profile_get(self):
+        ms = np.zeros(len(STAGES), np.float64)
+        cnt = np.zeros(len(STAGES), np.int64)
+        self._L.orbx_profile_get(self._h, _ptr(ms), _ptr(cnt))
+        return {s: (float(ms[i]), int(cnt[i])) for i, s in enumerate(STAGES)}
+
+    def debug_candidates(self, frame: int, level: int) -> np.ndarray:
+        n = self._check(self._L.orbx_debug_candidates(self._h, frame, level, None, 0))
+        out = np.zeros((max(n, 1), 3), np.float32)
+        self._check(self._L.orbx_debug_candidates(self._h, frame, level, _ptr(out), n))
+        return out[:n]
+
+
+def debug_distribute(xyr: np.ndarray, min_x: int, max_x: int, min_y: int, max_y: int, n_features: int) -> np.ndarray:
+    """DistributeOctTree alone (host stage of liborbx; test hook)."""
+    xyr = np.ascontiguousarray(xyr, np.float32).reshape(-1, 3)
+    out = np.zeros((len(xyr) + 8, 3), np.float32)
+    r = lib().orbx_debug_distribute(_ptr(xyr), len(xyr), min_x, max_x, min_y, max_y, n_features, _ptr(out), len(out))
+    if r < 0:
+        raise OrbxError(r, "orbx_debug_distribute")
+    return out[:r]
+
+
+class Frame:
+    """The slice of SlamTypes/Frame.{hpp,cpp} on this path: runs the extractor (Frame.cpp:58-60), keeps mvKeys /
+    mvKeysUn / mDescriptors / N and the image bounds (Frame.cpp:101-134; identity when there is no distortion).
+    Keypoint undistortion is SURVEY 8(f) rank 1 and not built yet: only distCoef[0] == 0 is accepted."""
+
+    def __init__(self, im: np.ndarray, timestamp: float, extractor: ORBextractor, dist_k1: float = 0.0):
+        if dist_k1 != 0.0:
+            raise NotImplementedError("keypoint undistortion (SURVEY 8(f) rank 1) is not part of this round")
+        self.mTimestamp = timestamp
+        self.mpORBextractor = extractor
+        h, w = im.shape
+        self.bounds = (0, w, 0, h)  # mnMinX, mnMaxX, mnMinY, mnMaxY (Frame.cpp:127-131)
+        _, self.mvKeys, self.mDescriptors = extractor(im, None, (0, 0))
+        self.mvKeysUn = self.mvKeys  # Frame.cpp:137-140
+        self.N = len(self.mvKeysUn)
+
+    @classmethod
+    def from_arrays(cls, keys: np.ndarray, descriptors: np.ndarray, bounds: Tuple[int, int, int, int]) -> "Frame":
+        f = cls.__new__(cls)
+        f.mTimestamp, f.mpORBextractor = 0.0, None
+        f.mvKeys = f.mvKeysUn = np.ascontiguousarray(keys, KEYPOINT_DTYPE)
+        f.mDescriptors = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        f.N = len(f.mvKeysUn)
+        f.bounds = tuple(int(v) for v in bounds)
+        return f
+
+
+class ORBmatcher:
+    """Features/ORBmatcher.hpp:13-61."""
+
+    TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30
+
+    def __init__(self, nnratio: float = 0.6, checkOri: bool = True, extractor: Optional[ORBextractor] = None):
+        self.mfNNratio = float(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+        self._ext = extractor
+        self.last_stats = None
+
+    def SearchForInitialization(self, F1: Frame, F2: Frame, windowSize: int = 100):
+        """Returns (nmatches, vnMatches12).  nmatches keeps the reference's double-decrement quirk (cpp:95-98,130-138)."""
+        ext = self._ext or F1.mpORBextractor or F2.mpORBextractor
+        if ext is None:
+            raise OrbxError(E_BADARG, "ORBmatcher needs an ORBextractor (device context); pass extractor=")
+        k1 = np.ascontiguousarray(F1.mvKeysUn, KEYPOINT_DTYPE)
+        k2 = np.ascontiguousarray(F2.mvKeysUn, KEYPOINT_DTYPE)
+        d1 = np.ascontiguousarray(F1.mDescriptors, np.uint8)
+        d2 = np.ascontiguousarray(F2.mDescriptors, np.uint8)
+        m12 = np.full(max(len(k1), 1), -1, np.int32)
+        st = _Stats()
+        b = _Bounds(*[int(v) for v in F2.bounds])
+        nm = ctypes.c_int32(0)
+        r = ext._L.orbx_match_init(ext._h, _ptr(k1), _ptr(d1), len(k1), _ptr(k2), _ptr(d2), len(k2), ctypes.byref(b),
+                                   int(windowSize), self.mfNNratio, int(self.mbCheckOrientation), _ptr(m12), ctypes.byref(nm),
+                                   ctypes.byref(st))
+        ext._check(r, "orbx_match_init")
+        self.last_stats = (st.invalid_by_distance, st.invalid_by_ratio, st.invalid_by_orientation)
+        return int(nm.value), m12[:len(k1)].copy()

@@ -1,0 +1,895 @@
+// orbx_api.cpp — host side of liborbx: context, per-batch pipeline and the C ABI of include/orbx.h.
+//
+// Pipeline of one batch (B frames, all on one HIP stream):
+//   k_resize x (nlevels-1)  ->  k_fast (all cells of all levels of all frames)  ->  candidate counts D2H
+//   -> candidates D2H -> quadtree selection on host threads (orbx_octree.cpp) -> selected keypoints H2D
+//   -> k_describe (orientation + blur + descriptors) -> results stay in HBM (device API) or D2H (host API)
+// and, for matching, k_match with one workgroup per frame pair.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "orbx_device.h"
+#include "orbx_internal.h"
+
+namespace orbx {
+
+hipError_t launch_resize(hipStream_t st, int nFrames, const uint8_t* src, long long srcFrameStride, int sw, int sh, int sstride,
+                         uint8_t* dst, long long dstFrameStride, int dw, int dh, int dstride, const ResizeTab* xtab,
+                         const ResizeTab* ytab);
+hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, int img0Aligned,
+                       const uint8_t* pyr, const Geom& g, uint32_t* cand, int* candCount, int* overflow);
+hipError_t launch_describe(hipStream_t st, int nFrames, int maxSel, const uint8_t* img0, long long img0FrameStride,
+                           const uint8_t* pyr, const Geom& g, const SelKp* sel, const int* nsel, orbx_keypoint* kps,
+                           uint8_t* desc, int capacity);
+hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int* dSecond, const orbx_keypoint* kps,
+                        const uint8_t* desc, const int* nkp, int capacity, orbx_bounds b, int window, float nnratio, int checkOri,
+                        int* matches12, int* nmatches, int* stats, int* scratch);
+
+namespace {
+
+inline int cvRoundF(float v) { return (int)lrintf(v); }  // round half to even
+inline int cvRoundD(double v) { return (int)lrint(v); }
+inline int alignUp(int v, int a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------
+// small persistent thread pool for the host-side selection stage
+// ---------------------------------------------------------------------------------------------
+class ThreadPool {
+ public:
+  explicit ThreadPool(int n) {
+    for (int i = 0; i < n; i++) workers_.emplace_back([this] { loop(); });
+  }
+  ~ThreadPool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  void parallelFor(int n, const std::function<void(int)>& fn) {
+    if (n <= 0) return;
+    if (workers_.empty() || n == 1) {
+      for (int i = 0; i < n; i++) fn(i);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn;
+      total_ = n;
+      next_ = 0;
+      done_ = 0;
+      gen_++;
+    }
+    cv_.notify_all();
+    work();  // the caller helps
+    std::unique_lock<std::mutex> lk(m_);
+    doneCv_.wait(lk, [this] { return done_ == total_; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      int i;
+      const std::function<void(int)>* fn;
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (!fn_ || next_ >= total_) return;
+        i = next_++;
+        fn = fn_;
+      }
+      (*fn)(i);
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (++done_ == total_) doneCv_.notify_all();
+      }
+    }
+  }
+  void loop() {
+    unsigned long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+      }
+      work();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_, doneCv_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int total_ = 0, next_ = 0, done_ = 0;
+  unsigned long gen_ = 0;
+  bool stop_ = false;
+};
+
+}  // namespace
+}  // namespace orbx
+
+using namespace orbx;
+
+struct orbx_ctx {
+  orbx_params p{};
+  int device = 0;
+  hipStream_t st = nullptr;
+  bool ownStream = false;
+  int maxW = 0, maxH = 0, maxB = 0;
+  std::vector<float> scale, invScale, sigma2, invSigma2;
+  std::vector<int> quota;
+  int umax[16]{};
+  int selCap = 0;  // sum of the per-level quotas
+
+  // geometry of the current frame size
+  int curW = 0, curH = 0, curStride0 = 0;
+  Geom g{};
+  std::vector<ResizeTab> hTab;
+
+  // device buffers
+  uint8_t* dPyr = nullptr;
+  size_t pyrBytes = 0;
+  uint32_t* dCand = nullptr;
+  size_t candEntries = 0;
+  int* dCandCount = nullptr;
+  int* dOverflow = nullptr;
+  ResizeTab* dTab = nullptr;
+  size_t tabEntries = 0;
+  SelKp* dSel = nullptr;
+  int* dNsel = nullptr;
+  uint8_t* dIn = nullptr;
+  size_t inBytes = 0;
+  orbx_keypoint* dKps = nullptr;
+  uint8_t* dDesc = nullptr;
+  // pinned host mirrors
+  int* hCandCount = nullptr;
+  uint32_t* hCand = nullptr;
+  SelKp* hSel = nullptr;
+  int* hNsel = nullptr;
+  int* hOverflow = nullptr;
+  // matcher
+  int* dMatchScratch = nullptr;
+  size_t matchScratchInts = 0;
+  int* dPairs = nullptr;
+  size_t pairsCap = 0;
+  orbx_keypoint* dMk = nullptr;
+  uint8_t* dMd = nullptr;
+  int* dMi = nullptr;  // n[2] + matches12[cap] + nmatches + stats[3]
+  size_t mCap = 0;
+
+  // last extract call (for orbx_download_pyramid / debug hooks)
+  const uint8_t* lastImg0 = nullptr;
+  long long lastFrameStride0 = 0;
+  int lastB = 0;
+  std::vector<int> lastCandCount;
+
+  // profiling
+  bool prof = false;
+  hipEvent_t ev[ORBX_STAGE_COUNT][2]{};
+  double ms[ORBX_STAGE_COUNT]{};
+  int64_t launches[ORBX_STAGE_COUNT]{};
+
+  std::string err;
+  ThreadPool* pool = nullptr;
+};
+
+namespace {
+
+#define HIPCHK(expr)                                                                                     \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess) {                                                                              \
+      char buf_[512];                                                                                    \
+      snprintf(buf_, sizeof buf_, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+      ctx->err = buf_;                                                                                   \
+      return ORBX_E_HIP;                                                                                 \
+    }                                                                                                    \
+  } while (0)
+
+// ORBextractor ctor arithmetic, Features/ORBextractor.cpp:508-594
+void computeTables(orbx_ctx* c) {
+  const int nl = c->p.nlevels;
+  const double scaleFactor = (double)c->p.scale_factor;  // the member is a double (hpp:142)
+  c->scale.assign(nl, 1.f);
+  c->sigma2.assign(nl, 1.f);
+  c->invScale.assign(nl, 1.f);
+  c->invSigma2.assign(nl, 1.f);
+  for (int i = 1; i < nl; i++) {
+    c->scale[i] = (float)(c->scale[i - 1] * scaleFactor);
+    c->sigma2[i] = c->scale[i] * c->scale[i];
+  }
+  for (int i = 0; i < nl; i++) {
+    c->invScale[i] = 1.0f / c->scale[i];
+    c->invSigma2[i] = 1.0f / c->sigma2[i];
+  }
+  c->quota.assign(nl, 0);
+  const float factor = (float)(1.0f / scaleFactor);
+  float desired = c->p.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)(float)nl));
+  int sum = 0;
+  for (int l = 0; l < nl - 1; l++) {
+    c->quota[l] = cvRoundF(desired);
+    sum += c->quota[l];
+    desired *= factor;
+  }
+  c->quota[nl - 1] = std::max(c->p.nfeatures - sum, 0);
+  c->selCap = 0;
+  for (int q : c->quota) c->selCap += q;
+  const int HALF = 15;
+  const int vmax = (int)std::floor(HALF * std::sqrt(2.f) / 2 + 1);
+  const int vmin = (int)std::ceil(HALF * std::sqrt(2.f) / 2);
+  const double hp2 = HALF * HALF;
+  for (int v = 0; v <= HALF; v++) c->umax[v] = 0;
+  for (int v = 0; v <= vmax; ++v) c->umax[v] = cvRoundD(std::sqrt(hp2 - v * v));
+  for (int v = HALF, v0 = 0; v >= vmin; --v) {
+    while (c->umax[v0] == c->umax[v0 + 1]) ++v0;
+    c->umax[v] = v0;
+    ++v0;
+  }
+}
+
+void levelSize(const orbx_ctx* c, int w, int h, int l, int* lw, int* lh) {  // cpp:1662-1663
+  *lw = cvRoundF(w * c->invScale[l]);
+  *lh = cvRoundF(h * c->invScale[l]);
+}
+
+// fills c->g for a w x h frame whose level 0 has row stride `stride0`; returns 0 or an error code
+int buildGeometry(orbx_ctx* c, int w, int h, int stride0, Geom* out, std::vector<ResizeTab>* tab) {
+  Geom g{};
+  g.nlevels = c->p.nlevels;
+  g.iniTh = std::min(std::max(c->p.ini_th_fast, 0), 255);
+  g.minTh = std::min(std::max(c->p.min_th_fast, 0), 255);
+  g.selCap = c->selCap;
+  int cellBase = 0;
+  int64_t pyrOff = 0, candOff = 0;
+  int tabOff = 0;
+  if (tab) tab->clear();
+  int pw = 0, ph = 0;
+  for (int l = 0; l < g.nlevels; l++) {
+    LevelGeom& L = g.L[l];
+    levelSize(c, w, h, l, &L.w, &L.h);
+    if (L.w > 4096 || L.h > 4096) return ORBX_E_BADARG;
+    L.maxBX = L.w - ORBX_EDGE + 3;
+    L.maxBY = L.h - ORBX_EDGE + 3;
+    const float width = (float)(L.maxBX - ORBX_MIN_BORDER), height = (float)(L.maxBY - ORBX_MIN_BORDER);
+    if (width < 35.f || height < 35.f) return ORBX_E_TOOSMALL;
+    if ((int)std::round(width / height) < 1) return ORBX_E_TOOSMALL;  // nIni == 0 is UB upstream (cpp:706-709)
+    L.nCols = (int)(width / 35.f);
+    L.nRows = (int)(height / 35.f);
+    L.wCell = (int)std::ceil(width / L.nCols);
+    L.hCell = (int)std::ceil(height / L.nRows);
+    L.cellBase = cellBase;
+    cellBase += L.nCols * L.nRows;
+    // worst-case number of NMS survivors (no two are 8-neighbours)
+    int cap = 0;
+    for (int i = 0; i < L.nRows; i++) {
+      const int iniY = ORBX_MIN_BORDER + i * L.hCell;
+      if (iniY >= L.maxBY - 3) continue;
+      const int ch = std::min(iniY + L.hCell + 6, L.maxBY) - iniY;
+      for (int j = 0; j < L.nCols; j++) {
+        const int iniX = ORBX_MIN_BORDER + j * L.wCell;
+        if (iniX >= L.maxBX - 6) continue;
+        const int cw = std::min(iniX + L.wCell + 6, L.maxBX) - iniX;
+        if (cw < 7 || ch < 7) continue;
+        cap += ((cw - 6 + 1) / 2) * ((ch - 6 + 1) / 2);
+      }
+    }
+    L.candCap = std::max(cap, 1);
+    L.candOff = candOff;
+    candOff += (int64_t)L.candCap * c->maxB;
+    L.quota = c->quota[l];
+    L.scale = c->scale[l];
+    L.patchSize = (int)(31 * c->scale[l]);  // cpp:1165
+    if (l == 0) {
+      L.stride = stride0;
+      L.imgOff = 0;
+      L.frameStride = 0;
+      L.xtabOff = L.ytabOff = 0;
+    } else {
+      L.stride = alignUp(L.w, 64);
+      L.imgOff = pyrOff;
+      L.frameStride = (int64_t)L.stride * L.h;
+      pyrOff += L.frameStride * c->maxB;
+      if (tab) {
+        // cv::resize INTER_LINEAR coefficient tables
+        const int sw = pw, sh = ph, dw = L.w, dh = L.h;
+        const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);
+        L.xtabOff = tabOff;
+        const int dwPad = alignUp(dw, 4);
+        for (int dx = 0; dx < dwPad; dx++) {
+          const int d = std::min(dx, dw - 1);
+          float fx = (float)((d + 0.5) * scale_x - 0.5);
+          int sx = (int)std::floor(fx);
+          fx -= sx;
+          if (sx < 0) { fx = 0; sx = 0; }
+          if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+          const int c0 = cvRoundF((1.f - fx) * 2048), c1 = cvRoundF(fx * 2048);
+          tab->push_back(ResizeTab{sx, (c0 & 0xffff) | (c1 << 16)});
+        }
+        tabOff += dwPad;
+        L.ytabOff = tabOff;
+        for (int dy = 0; dy < dh; dy++) {
+          float fy = (float)((dy + 0.5) * scale_y - 0.5);
+          int sy = (int)std::floor(fy);
+          fy -= sy;
+          const int c0 = cvRoundF((1.f - fy) * 2048), c1 = cvRoundF(fy * 2048);
+          tab->push_back(ResizeTab{sy, (c0 & 0xffff) | (c1 << 16)});
+        }
+        tabOff += dh;
+      }
+    }
+    pw = L.w;
+    ph = L.h;
+  }
+  g.nCellsTotal = cellBase;
+  *out = g;
+  return ORBX_OK;
+}
+
+struct Sizes {
+  size_t pyrBytes, candEntries, tabEntries;
+};
+Sizes sizesOf(const orbx_ctx* c, const Geom& g, size_t tabEntries) {
+  Sizes s{};
+  const LevelGeom& last = g.L[g.nlevels - 1];
+  s.pyrBytes = g.nlevels > 1 ? (size_t)(last.imgOff + last.frameStride * c->maxB) : 0;
+  s.candEntries = (size_t)(last.candOff + (int64_t)last.candCap * c->maxB);
+  s.tabEntries = tabEntries;
+  return s;
+}
+
+int ensureGeometry(orbx_ctx* ctx, int w, int h, int stride0) {
+  if (w == ctx->curW && h == ctx->curH && stride0 == ctx->curStride0) return ORBX_OK;
+  if (w <= 0 || h <= 0) return ORBX_E_EMPTY;
+  if (w > ctx->maxW || h > ctx->maxH) { ctx->err = "frame larger than the context's max_width/max_height"; return ORBX_E_BADARG; }
+  Geom g;
+  std::vector<ResizeTab> tab;
+  int r = buildGeometry(ctx, w, h, stride0, &g, &tab);
+  if (r != ORBX_OK) return r;
+  Sizes s = sizesOf(ctx, g, tab.size());
+  if (s.pyrBytes > ctx->pyrBytes || s.candEntries > ctx->candEntries || s.tabEntries > ctx->tabEntries) {
+    ctx->err = "internal: geometry exceeds the buffers sized at orbx_create";
+    return ORBX_E_BADARG;
+  }
+  ctx->g = g;
+  ctx->hTab = tab;
+  if (!tab.empty()) HIPCHK(hipMemcpyAsync(ctx->dTab, ctx->hTab.data(), tab.size() * sizeof(ResizeTab), hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  ctx->curW = w;
+  ctx->curH = h;
+  ctx->curStride0 = stride0;
+  return ORBX_OK;
+}
+
+struct StageTimer {
+  orbx_ctx* c;
+  int stage;
+  StageTimer(orbx_ctx* c_, int s) : c(c_), stage(s) {
+    if (c->prof) (void)hipEventRecord(c->ev[s][0], c->st);
+  }
+  void stop(int nLaunches) {
+    if (c->prof) {
+      (void)hipEventRecord(c->ev[stage][1], c->st);
+      c->launches[stage] += nLaunches;
+    }
+  }
+};
+void collectProfile(orbx_ctx* c, const bool used[ORBX_STAGE_COUNT]) {
+  if (!c->prof) return;
+  for (int s = 0; s < ORBX_STAGE_COUNT; s++) {
+    if (!used[s]) continue;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev[s][0], c->ev[s][1]) == hipSuccess) c->ms[s] += ms;
+  }
+}
+
+// candidate order of the reference: cell row, cell col, y, x (cpp:1078-1137; cv::FAST emits row-major)
+inline uint64_t candOrderKey(const LevelGeom& L, uint32_t e) {
+  const int x = e & 0xfff, y = (e >> 12) & 0xfff;
+  const int cr = (y - 3) / L.hCell, cc = (x - 3) / L.wCell;
+  return ((uint64_t)(cr * L.nCols + cc) << 24) | ((uint64_t)y << 12) | (uint64_t)x;
+}
+
+// The whole extraction of one batch.  d_img0: device pointer of frame 0 / level 0.
+int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int stride0, long long frameStride0,
+                orbx_keypoint* dKps, uint8_t* dDesc, int capacity, int* dNout) {
+  if (B <= 0) return ORBX_E_BADARG;
+  if (B > ctx->maxB) { ctx->err = "batch larger than max_batch"; return ORBX_E_BADARG; }
+  if (capacity < ctx->selCap) return ORBX_E_CAPACITY;
+  int r = ensureGeometry(ctx, w, h, stride0);
+  if (r != ORBX_OK) return r;
+  const Geom& g = ctx->g;
+  const int nl = g.nlevels;
+  hipStream_t st = ctx->st;
+  const int aligned0 = (((uintptr_t)dImg0 | (uintptr_t)stride0 | (uintptr_t)frameStride0) & 3) == 0;
+  bool used[ORBX_STAGE_COUNT] = {false, false, false, false, false};
+
+  HIPCHK(hipMemsetAsync(ctx->dCandCount, 0, sizeof(int) * (size_t)B * nl + sizeof(int), st));  // counts + overflow flag
+  {
+    StageTimer tm(ctx, ORBX_STAGE_PYRAMID);
+    for (int l = 1; l < nl; l++) {
+      const LevelGeom& S = g.L[l - 1];
+      const LevelGeom& D = g.L[l];
+      const uint8_t* src = l == 1 ? dImg0 : ctx->dPyr + S.imgOff;
+      const long long sfs = l == 1 ? frameStride0 : S.frameStride;
+      HIPCHK(launch_resize(st, B, src, sfs, S.w, S.h, S.stride, ctx->dPyr + D.imgOff, D.frameStride, D.w, D.h, D.stride,
+                           ctx->dTab + D.xtabOff, ctx->dTab + D.ytabOff));
+    }
+    tm.stop(nl - 1);
+    used[ORBX_STAGE_PYRAMID] = nl > 1;
+  }
+  {
+    StageTimer tm(ctx, ORBX_STAGE_FAST);
+    HIPCHK(launch_fast(st, B, dImg0, frameStride0, aligned0, ctx->dPyr, g, ctx->dCand, ctx->dCandCount, ctx->dOverflow));
+    tm.stop(1);
+    used[ORBX_STAGE_FAST] = true;
+  }
+  // ---- selection stage: candidates to the host, quadtree on host threads, selection back ----
+  auto tSel0 = std::chrono::steady_clock::now();
+  HIPCHK(hipMemcpyAsync(ctx->hCandCount, ctx->dCandCount, sizeof(int) * (size_t)B * nl + sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (ctx->hCandCount[(size_t)B * nl]) { ctx->err = "internal: candidate buffer overflow"; return ORBX_E_CAPACITY; }
+  std::vector<int> maxCount(nl, 0);
+  std::vector<size_t> hostOff(nl, 0);
+  size_t hostTotal = 0;
+  for (int l = 0; l < nl; l++) {
+    for (int f = 0; f < B; f++) maxCount[l] = std::max(maxCount[l], ctx->hCandCount[f * nl + l]);
+    hostOff[l] = hostTotal;
+    hostTotal += (size_t)maxCount[l] * B;
+    if (maxCount[l] > 0)
+      HIPCHK(hipMemcpy2DAsync(ctx->hCand + hostOff[l], (size_t)maxCount[l] * 4, ctx->dCand + g.L[l].candOff,
+                              (size_t)g.L[l].candCap * 4, (size_t)maxCount[l] * 4, B, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  std::atomic<int> selErr{0};
+  ctx->pool->parallelFor(B, [&](int f) {
+    std::vector<uint64_t> keyed;
+    std::vector<OctCand> oc;
+    std::vector<int> chosen;
+    SelKp* out = ctx->hSel + (size_t)f * g.selCap;
+    int n = 0;
+    for (int l = 0; l < nl; l++) {
+      const LevelGeom& L = g.L[l];
+      const int cnt = ctx->hCandCount[f * nl + l];
+      const uint32_t* src = ctx->hCand + hostOff[l] + (size_t)f * maxCount[l];
+      keyed.resize(cnt);
+      for (int i = 0; i < cnt; i++) keyed[i] = (candOrderKey(L, src[i]) << 8) | (src[i] >> 24);
+      std::sort(keyed.begin(), keyed.end());
+      oc.resize(cnt);
+      for (int i = 0; i < cnt; i++) {
+        oc[i].x = (float)((keyed[i] >> 8) & 0xfff);
+        oc[i].y = (float)((keyed[i] >> 20) & 0xfff);
+        oc[i].response = (float)(keyed[i] & 0xff);
+      }
+      int rs = octree_select(oc.data(), cnt, ORBX_MIN_BORDER, L.maxBX, ORBX_MIN_BORDER, L.maxBY, L.quota, chosen);
+      if (rs < 0) { selErr = rs; return; }
+      const int keep = std::min((int)chosen.size(), L.quota);  // cpp:1159-1161
+      for (int i = 0; i < keep; i++) {
+        const OctCand& c = oc[chosen[i]];
+        SelKp k;
+        k.x = (uint16_t)((int)c.x + ORBX_MIN_BORDER);  // cpp:1171-1172
+        k.y = (uint16_t)((int)c.y + ORBX_MIN_BORDER);
+        k.level = (uint8_t)l;
+        k.response = (uint8_t)c.response;
+        k.pad = 0;
+        out[n++] = k;
+      }
+    }
+    ctx->hNsel[f] = n;
+  });
+  if (selErr.load() < 0) return selErr.load();
+  int maxSel = 0;
+  for (int f = 0; f < B; f++) maxSel = std::max(maxSel, ctx->hNsel[f]);
+  HIPCHK(hipMemcpyAsync(ctx->dNsel, ctx->hNsel, sizeof(int) * B, hipMemcpyHostToDevice, st));
+  if (maxSel > 0)
+    HIPCHK(hipMemcpy2DAsync(ctx->dSel, (size_t)g.selCap * sizeof(SelKp), ctx->hSel, (size_t)g.selCap * sizeof(SelKp),
+                            (size_t)maxSel * sizeof(SelKp), B, hipMemcpyHostToDevice, st));
+  if (ctx->prof) {
+    HIPCHK(hipStreamSynchronize(st));
+    ctx->ms[ORBX_STAGE_SELECT] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tSel0).count();
+    ctx->launches[ORBX_STAGE_SELECT] += 1;
+  }
+  {
+    StageTimer tm(ctx, ORBX_STAGE_DESCRIBE);
+    HIPCHK(launch_describe(st, B, maxSel, dImg0, frameStride0, ctx->dPyr, g, ctx->dSel, ctx->dNsel, dKps, dDesc, capacity));
+    tm.stop(maxSel > 0 ? 1 : 0);
+    used[ORBX_STAGE_DESCRIBE] = true;
+  }
+  if (dNout) HIPCHK(hipMemcpyAsync(dNout, ctx->dNsel, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  collectProfile(ctx, used);
+  ctx->lastImg0 = dImg0;
+  ctx->lastFrameStride0 = frameStride0;
+  ctx->lastB = B;
+  ctx->lastCandCount.assign(ctx->hCandCount, ctx->hCandCount + (size_t)B * nl);
+  return ORBX_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int orbx_create(const orbx_params* params, int device_id, int max_width, int max_height, int max_batch, void* stream,
+                orbx_ctx** out) {
+  if (!params || !out) return ORBX_E_BADARG;
+  *out = nullptr;
+  if (params->nlevels < 1 || params->nlevels > ORBX_MAX_LEVELS || params->nfeatures < 1 || !(params->scale_factor >= 1.0f) ||
+      (params->scale_factor == 1.0f && params->nlevels > 1) || max_width < 1 || max_height < 1 || max_batch < 1)
+    return ORBX_E_BADARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return ORBX_E_HIP;
+  if (hipSetDevice(device_id) != hipSuccess) return ORBX_E_HIP;
+  orbx_ctx* ctx = new orbx_ctx();
+  ctx->p = *params;
+  ctx->device = device_id;
+  ctx->maxW = max_width;
+  ctx->maxH = max_height;
+  ctx->maxB = max_batch;
+  computeTables(ctx);
+  auto fail = [&](int code) {
+    orbx_destroy(ctx);
+    return code;
+  };
+  if (stream) {
+    ctx->st = (hipStream_t)stream;
+  } else {
+    if (hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess) return fail(ORBX_E_HIP);
+    ctx->ownStream = true;
+  }
+  Geom g;
+  std::vector<ResizeTab> tab;
+  int r = buildGeometry(ctx, max_width, max_height, alignUp(max_width, 64), &g, &tab);
+  if (r != ORBX_OK) return fail(r);
+  Sizes s = sizesOf(ctx, g, tab.size());
+  // row strides grow by at most 63 bytes and tables by a few entries for smaller frames: keep headroom
+  ctx->pyrBytes = s.pyrBytes + (size_t)64 * max_height * ctx->p.nlevels * max_batch + 4096;
+  ctx->candEntries = s.candEntries + 1024;
+  ctx->tabEntries = s.tabEntries + 64 * ctx->p.nlevels;
+  const size_t B = (size_t)max_batch, nl = (size_t)ctx->p.nlevels;
+  const size_t cap = (size_t)std::max(ctx->selCap, 1);
+  ctx->inBytes = (size_t)alignUp(max_width, 64) * max_height * B;
+#define ALLOC(ptr, bytes)                                                      \
+  if (hipMalloc((void**)&(ptr), std::max<size_t>((bytes), 16)) != hipSuccess) return fail(ORBX_E_HIP)
+#define ALLOCH(ptr, bytes)                                                     \
+  if (hipHostMalloc((void**)&(ptr), std::max<size_t>((bytes), 16), hipHostMallocDefault) != hipSuccess) return fail(ORBX_E_HIP)
+  ALLOC(ctx->dPyr, ctx->pyrBytes);
+  ALLOC(ctx->dCand, ctx->candEntries * 4);
+  ALLOC(ctx->dCandCount, (B * nl + 1) * sizeof(int));
+  ctx->dOverflow = ctx->dCandCount + B * nl;
+  ALLOC(ctx->dTab, ctx->tabEntries * sizeof(ResizeTab));
+  ALLOC(ctx->dSel, B * cap * sizeof(SelKp));
+  ALLOC(ctx->dNsel, B * sizeof(int));
+  ALLOC(ctx->dIn, ctx->inBytes);
+  ALLOC(ctx->dKps, B * cap * sizeof(orbx_keypoint));
+  ALLOC(ctx->dDesc, B * cap * 32);
+  ALLOCH(ctx->hCandCount, (B * nl + 1) * sizeof(int));
+  ALLOCH(ctx->hCand, ctx->candEntries * 4);
+  ALLOCH(ctx->hSel, B * cap * sizeof(SelKp));
+  ALLOCH(ctx->hNsel, B * sizeof(int));
+#undef ALLOC
+#undef ALLOCH
+  for (int s2 = 0; s2 < ORBX_STAGE_COUNT; s2++)
+    for (int k = 0; k < 2; k++)
+      if (hipEventCreate(&ctx->ev[s2][k]) != hipSuccess) return fail(ORBX_E_HIP);
+  int nthreads = (int)std::thread::hardware_concurrency();
+  if (const char* e = getenv("ORBX_HOST_THREADS")) nthreads = atoi(e);
+  nthreads = std::min(std::max(nthreads, 1), 64);
+  ctx->pool = new ThreadPool(std::min(nthreads, max_batch) - 1);
+  *out = ctx;
+  return ORBX_OK;
+}
+
+void orbx_destroy(orbx_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->st) (void)hipStreamSynchronize(ctx->st);
+  delete ctx->pool;
+  void* dev[] = {ctx->dPyr, ctx->dCand, ctx->dCandCount, ctx->dTab, ctx->dSel, ctx->dNsel, ctx->dIn, ctx->dKps, ctx->dDesc,
+                 ctx->dMatchScratch, ctx->dPairs, ctx->dMk, ctx->dMd, ctx->dMi};
+  for (void* p : dev)
+    if (p) (void)hipFree(p);
+  void* host[] = {ctx->hCandCount, ctx->hCand, ctx->hSel, ctx->hNsel};
+  for (void* p : host)
+    if (p) (void)hipHostFree(p);
+  for (int s = 0; s < ORBX_STAGE_COUNT; s++)
+    for (int k = 0; k < 2; k++)
+      if (ctx->ev[s][k]) (void)hipEventDestroy(ctx->ev[s][k]);
+  if (ctx->ownStream && ctx->st) (void)hipStreamDestroy(ctx->st);
+  delete ctx;
+}
+
+const char* orbx_last_error(const orbx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int orbx_get_levels(const orbx_ctx* ctx) { return ctx ? ctx->p.nlevels : ORBX_E_BADARG; }
+float orbx_get_scale_factor(const orbx_ctx* ctx) { return ctx ? (float)(double)ctx->p.scale_factor : 0.f; }
+int orbx_get_tables(const orbx_ctx* ctx, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                    int32_t* features_per_level) {
+  if (!ctx) return ORBX_E_BADARG;
+  for (int i = 0; i < ctx->p.nlevels; i++) {
+    if (scale) scale[i] = ctx->scale[i];
+    if (inv_scale) inv_scale[i] = ctx->invScale[i];
+    if (sigma2) sigma2[i] = ctx->sigma2[i];
+    if (inv_sigma2) inv_sigma2[i] = ctx->invSigma2[i];
+    if (features_per_level) features_per_level[i] = ctx->quota[i];
+  }
+  return ORBX_OK;
+}
+int orbx_get_umax(const orbx_ctx* ctx, int32_t* umax16) {
+  if (!ctx || !umax16) return ORBX_E_BADARG;
+  for (int i = 0; i < 16; i++) umax16[i] = ctx->umax[i];
+  return ORBX_OK;
+}
+
+int orbx_extract_batch_device(orbx_ctx* ctx, int n_frames, const uint8_t* d_imgs, int width, int height, int stride,
+                              size_t frame_stride_bytes, orbx_keypoint* d_kps, uint8_t* d_desc32, int capacity,
+                              int32_t* d_n_out) {
+  if (!ctx) return ORBX_E_BADARG;
+  if (!d_imgs || width <= 0 || height <= 0) return ORBX_E_EMPTY;
+  if (!d_kps || !d_desc32 || stride < width) return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  return extractCore(ctx, n_frames, d_imgs, width, height, stride, (long long)frame_stride_bytes, d_kps, d_desc32, capacity,
+                     d_n_out);
+}
+
+int orbx_extract_batch(orbx_ctx* ctx, int n_frames, const uint8_t* imgs, int width, int height, int stride,
+                       size_t frame_stride_bytes, int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc32, int capacity,
+                       int* n_out, int* mono_out) {
+  if (!ctx) return ORBX_E_BADARG;
+  if (!imgs || width <= 0 || height <= 0) return ORBX_E_EMPTY;
+  if (!kps || !desc32 || !n_out || stride < width || n_frames < 1) return ORBX_E_BADARG;
+  if (capacity < ctx->selCap) return ORBX_E_CAPACITY;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  if (width > ctx->maxW || height > ctx->maxH) { ctx->err = "frame larger than the context's max_width/max_height"; return ORBX_E_BADARG; }
+  const int dstride = alignUp(width, 64);
+  const size_t dfs = (size_t)dstride * height;
+  const int cap = std::max(ctx->selCap, 1);
+  for (int f0 = 0; f0 < n_frames; f0 += ctx->maxB) {
+    const int B = std::min(ctx->maxB, n_frames - f0);
+    for (int f = 0; f < B; f++)
+      HIPCHK(hipMemcpy2DAsync(ctx->dIn + f * dfs, dstride, imgs + (size_t)(f0 + f) * frame_stride_bytes, stride, width, height,
+                              hipMemcpyHostToDevice, ctx->st));
+    int r = extractCore(ctx, B, ctx->dIn, width, height, dstride, (long long)dfs, ctx->dKps, ctx->dDesc, cap, nullptr);
+    if (r != ORBX_OK) return r;
+    for (int f = 0; f < B; f++) {
+      const int n = ctx->hNsel[f];
+      n_out[f0 + f] = n;
+      orbx_keypoint* ko = kps + (size_t)(f0 + f) * capacity;
+      uint8_t* dout = desc32 + (size_t)(f0 + f) * capacity * 32;
+      if (n > 0) {
+        HIPCHK(hipMemcpyAsync(ko, ctx->dKps + (size_t)f * cap, sizeof(orbx_keypoint) * n, hipMemcpyDeviceToHost, ctx->st));
+        HIPCHK(hipMemcpyAsync(dout, ctx->dDesc + (size_t)f * cap * 32, (size_t)32 * n, hipMemcpyDeviceToHost, ctx->st));
+      }
+    }
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    for (int f = 0; f < B; f++) {
+      const int n = n_out[f0 + f];
+      int mono = n;
+      if (!(lap0 == 0 && lap1 == 0) && n > 0) {
+        // stereo keypoints (x in [lap0, lap1]) go back-to-front, the rest front-to-back (cpp:1637-1646)
+        orbx_keypoint* ko = kps + (size_t)(f0 + f) * capacity;
+        uint8_t* dout = desc32 + (size_t)(f0 + f) * capacity * 32;
+        std::vector<orbx_keypoint> k2(ko, ko + n);
+        std::vector<uint8_t> d2(dout, dout + (size_t)n * 32);
+        int mi = 0, si = n - 1;
+        for (int i = 0; i < n; i++) {
+          const int dst = (k2[i].x >= lap0 && k2[i].x <= lap1) ? si-- : mi++;
+          ko[dst] = k2[i];
+          memcpy(dout + (size_t)dst * 32, &d2[(size_t)i * 32], 32);
+        }
+        mono = mi;
+      }
+      if (mono_out) mono_out[f0 + f] = mono;
+    }
+  }
+  return ORBX_OK;
+}
+
+int orbx_extract(orbx_ctx* ctx, const uint8_t* img, int width, int height, int stride, int lap0, int lap1, orbx_keypoint* kps,
+                 uint8_t* desc32, int capacity, int* n_out) {
+  int n = 0, mono = 0;
+  int r = orbx_extract_batch(ctx, 1, img, width, height, stride, 0, lap0, lap1, kps, desc32, capacity, &n, &mono);
+  if (n_out) *n_out = r == ORBX_OK ? n : 0;
+  return r == ORBX_OK ? mono : r;
+}
+
+int orbx_level_size(const orbx_ctx* ctx, int level, int* width, int* height) {
+  if (!ctx || level < 0 || level >= ctx->p.nlevels || ctx->curW == 0) return ORBX_E_BADARG;
+  if (width) *width = ctx->g.L[level].w;
+  if (height) *height = ctx->g.L[level].h;
+  return ORBX_OK;
+}
+
+int orbx_download_pyramid(orbx_ctx* ctx, int frame, int level, int border, uint8_t* dst, int dst_stride) {
+  if (!ctx || !dst || level < 0 || level >= ctx->p.nlevels || frame < 0 || frame >= ctx->lastB || border < 0) return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  const LevelGeom& L = ctx->g.L[level];
+  if (dst_stride < L.w + 2 * border) return ORBX_E_BADARG;
+  const uint8_t* src = level == 0 ? ctx->lastImg0 + (long long)frame * ctx->lastFrameStride0
+                                  : ctx->dPyr + L.imgOff + (long long)frame * L.frameStride;
+  HIPCHK(hipMemcpy2DAsync(dst + (size_t)border * dst_stride + border, dst_stride, src, L.stride, L.w, L.h, hipMemcpyDeviceToHost,
+                          ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  if (border > 0) {  // cv::copyMakeBorder BORDER_REFLECT_101 (cpp:1689,1708)
+    auto refl = [](int p, int n) {
+      if (n == 1) return 0;
+      while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+      return p;
+    };
+    const int W = L.w + 2 * border, H = L.h + 2 * border;
+    for (int y = 0; y < H; y++) {
+      const int sy = refl(y - border, L.h);
+      uint8_t* row = dst + (size_t)y * dst_stride;
+      const uint8_t* srow = dst + (size_t)(sy + border) * dst_stride + border;
+      for (int x = 0; x < W; x++) {
+        const int sx = refl(x - border, L.w);
+        if (y - border != sy || x - border != sx) row[x] = srow[sx];
+      }
+    }
+  }
+  return ORBX_OK;
+}
+
+// ---- matching ------------------------------------------------------------------------------------
+static int ensureMatchScratch(orbx_ctx* ctx, int nPairs, int capacity) {
+  const size_t need = (size_t)nPairs * capacity * 4;
+  if (need > ctx->matchScratchInts) {
+    if (ctx->dMatchScratch) (void)hipFree(ctx->dMatchScratch);
+    ctx->dMatchScratch = nullptr;
+    ctx->matchScratchInts = 0;
+    HIPCHK(hipMalloc((void**)&ctx->dMatchScratch, need * sizeof(int)));
+    ctx->matchScratchInts = need;
+  }
+  if ((size_t)nPairs > ctx->pairsCap) {
+    if (ctx->dPairs) (void)hipFree(ctx->dPairs);
+    ctx->dPairs = nullptr;
+    ctx->pairsCap = 0;
+    HIPCHK(hipMalloc((void**)&ctx->dPairs, (size_t)nPairs * 2 * sizeof(int)));
+    ctx->pairsCap = nPairs;
+  }
+  return ORBX_OK;
+}
+
+int orbx_match_init_batch_device(orbx_ctx* ctx, int n_pairs, const int32_t* h_first, const int32_t* h_second,
+                                 const orbx_keypoint* d_kps, const uint8_t* d_desc32, const int32_t* d_n, int capacity,
+                                 const orbx_bounds* bounds, int window_size, float nnratio, int check_orientation,
+                                 int32_t* d_matches12, int32_t* d_nmatches, int32_t* d_stats) {
+  if (!ctx || n_pairs < 0 || !h_first || !h_second || !d_kps || !d_desc32 || !d_n || !bounds || !d_matches12 || !d_nmatches ||
+      capacity < 1 || capacity >= (1 << 20))
+    return ORBX_E_BADARG;
+  if (bounds->max_x <= bounds->min_x || bounds->max_y <= bounds->min_y) return ORBX_E_BADARG;
+  if (n_pairs == 0) return ORBX_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  int r = ensureMatchScratch(ctx, n_pairs, capacity);
+  if (r != ORBX_OK) return r;
+  bool used[ORBX_STAGE_COUNT] = {false, false, false, false, true};
+  HIPCHK(hipMemcpyAsync(ctx->dPairs, h_first, sizeof(int) * n_pairs, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(ctx->dPairs + n_pairs, h_second, sizeof(int) * n_pairs, hipMemcpyHostToDevice, ctx->st));
+  {
+    StageTimer tm(ctx, ORBX_STAGE_MATCH);
+    HIPCHK(launch_match(ctx->st, n_pairs, ctx->dPairs, ctx->dPairs + n_pairs, d_kps, d_desc32, d_n, capacity, *bounds, window_size,
+                        nnratio, check_orientation, d_matches12, d_nmatches, d_stats, ctx->dMatchScratch));
+    tm.stop(1);
+  }
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  collectProfile(ctx, used);
+  return ORBX_OK;
+}
+
+int orbx_match_init(orbx_ctx* ctx, const orbx_keypoint* k1, const uint8_t* d1, int n1, const orbx_keypoint* k2, const uint8_t* d2,
+                    int n2, const orbx_bounds* bounds, int window_size, float nnratio, int check_orientation, int32_t* matches12,
+                    int32_t* nmatches, orbx_match_stats* stats) {
+  if (!ctx || n1 < 0 || n2 < 0 || !bounds || !nmatches || (n1 > 0 && (!k1 || !d1 || !matches12)) || (n2 > 0 && (!k2 || !d2))) return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  const size_t cap = (size_t)std::max(std::max(n1, n2), 1);
+  if (cap >= (1u << 20)) return ORBX_E_BADARG;
+  if (cap > ctx->mCap) {
+    if (ctx->dMk) (void)hipFree(ctx->dMk);
+    if (ctx->dMd) (void)hipFree(ctx->dMd);
+    if (ctx->dMi) (void)hipFree(ctx->dMi);
+    ctx->dMk = nullptr; ctx->dMd = nullptr; ctx->dMi = nullptr; ctx->mCap = 0;
+    HIPCHK(hipMalloc((void**)&ctx->dMk, 2 * cap * sizeof(orbx_keypoint)));
+    HIPCHK(hipMalloc((void**)&ctx->dMd, 2 * cap * 32));
+    HIPCHK(hipMalloc((void**)&ctx->dMi, (cap + 8) * sizeof(int)));
+    ctx->mCap = cap;
+  }
+  const size_t c = ctx->mCap;
+  hipStream_t st = ctx->st;
+  if (n1) {
+    HIPCHK(hipMemcpyAsync(ctx->dMk, k1, sizeof(orbx_keypoint) * n1, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->dMd, d1, (size_t)32 * n1, hipMemcpyHostToDevice, st));
+  }
+  if (n2) {
+    HIPCHK(hipMemcpyAsync(ctx->dMk + c, k2, sizeof(orbx_keypoint) * n2, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->dMd + c * 32, d2, (size_t)32 * n2, hipMemcpyHostToDevice, st));
+  }
+  int hn[2] = {n1, n2};
+  int* dN = ctx->dMi;            // [2]
+  int* dNm = ctx->dMi + 2;       // [1]
+  int* dSt = ctx->dMi + 3;       // [3]
+  int* dM12 = ctx->dMi + 8;      // [cap]
+  HIPCHK(hipMemcpyAsync(dN, hn, sizeof hn, hipMemcpyHostToDevice, st));
+  const int32_t first = 0, second = 1;
+  int r = orbx_match_init_batch_device(ctx, 1, &first, &second, ctx->dMk, ctx->dMd, dN, (int)c, bounds, window_size, nnratio,
+                                       check_orientation, dM12, dNm, dSt);
+  if (r != ORBX_OK) return r;
+  int res[4];
+  HIPCHK(hipMemcpyAsync(res, dNm, sizeof res, hipMemcpyDeviceToHost, st));
+  if (n1) HIPCHK(hipMemcpyAsync(matches12, dM12, sizeof(int) * n1, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (stats) { stats->invalid_by_distance = res[1]; stats->invalid_by_ratio = res[2]; stats->invalid_by_orientation = res[3]; }
+  *nmatches = res[0];
+  return ORBX_OK;
+}
+
+// ---- measurement hooks ------------------------------------------------------------------------
+int orbx_profile_enable(orbx_ctx* ctx, int on) {
+  if (!ctx) return ORBX_E_BADARG;
+  ctx->prof = on != 0;
+  return ORBX_OK;
+}
+int orbx_profile_reset(orbx_ctx* ctx) {
+  if (!ctx) return ORBX_E_BADARG;
+  for (int s = 0; s < ORBX_STAGE_COUNT; s++) { ctx->ms[s] = 0; ctx->launches[s] = 0; }
+  return ORBX_OK;
+}
+int orbx_profile_get(orbx_ctx* ctx, double* ms, int64_t* launches) {
+  if (!ctx) return ORBX_E_BADARG;
+  for (int s = 0; s < ORBX_STAGE_COUNT; s++) {
+    if (ms) ms[s] = ctx->ms[s];
+    if (launches) launches[s] = ctx->launches[s];
+  }
+  return ORBX_OK;
+}
+
+// ---- test hooks ---------------------------------------------------------------------------------
+int orbx_debug_candidates(orbx_ctx* ctx, int frame, int level, float* xyr, int cap) {
+  if (!ctx || frame < 0 || frame >= ctx->lastB || level < 0 || level >= ctx->p.nlevels) return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  const LevelGeom& L = ctx->g.L[level];
+  const int cnt = ctx->lastCandCount[(size_t)frame * ctx->p.nlevels + level];
+  std::vector<uint32_t> e(std::max(cnt, 1));
+  if (cnt > 0) HIPCHK(hipMemcpy(e.data(), ctx->dCand + L.candOff + (int64_t)frame * L.candCap, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+  std::vector<uint64_t> keyed(cnt);
+  for (int i = 0; i < cnt; i++) keyed[i] = (candOrderKey(L, e[i]) << 8) | (e[i] >> 24);
+  std::sort(keyed.begin(), keyed.end());
+  for (int i = 0; i < cnt && i < cap; i++) {
+    xyr[3 * i] = (float)((keyed[i] >> 8) & 0xfff);
+    xyr[3 * i + 1] = (float)((keyed[i] >> 20) & 0xfff);
+    xyr[3 * i + 2] = (float)(keyed[i] & 0xff);
+  }
+  return cnt;
+}
+
+int orbx_debug_distribute(const float* xyr, int n, int min_x, int max_x, int min_y, int max_y, int n_features, float* out_xyr,
+                          int cap) {
+  if (n < 0 || (n > 0 && !xyr) || max_x <= min_x || max_y <= min_y) return ORBX_E_BADARG;
+  std::vector<OctCand> c(n);
+  for (int i = 0; i < n; i++) c[i] = OctCand{xyr[3 * i], xyr[3 * i + 1], xyr[3 * i + 2]};
+  std::vector<int> chosen;
+  int r = octree_select(c.data(), n, min_x, max_x, min_y, max_y, n_features, chosen);
+  if (r < 0) return r;
+  for (int i = 0; i < (int)chosen.size() && i < cap; i++) {
+    out_xyr[3 * i] = c[chosen[i]].x;
+    out_xyr[3 * i + 1] = c[chosen[i]].y;
+    out_xyr[3 * i + 2] = c[chosen[i]].response;
+  }
+  return (int)chosen.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// orbx_device.h — POD structures shared between the host pipeline and the HIP kernels of liborbx.
+#pragma once
+#include <cstdint>
+
+#define ORBX_MAX_LEVELS 16
+#define ORBX_EDGE 19          // EDGE_THRESHOLD, Features/ORBextractor.cpp:90
+#define ORBX_MIN_BORDER 16    // EDGE_THRESHOLD - 3, cpp:1056
+#define ORBX_CELL_MAX 76      // widest/tallest FAST cell image: ceil(width/nCols) <= 70, +6 overlap
+#define ORBX_GRID_COLS 64     // FRAME_GRID_COLS, SlamTypes/Frame.hpp:16
+#define ORBX_GRID_ROWS 48     // FRAME_GRID_ROWS, SlamTypes/Frame.hpp:15
+
+namespace orbx {
+
+// geometry of one pyramid level for the current frame size
+struct LevelGeom {
+  int32_t w, h, stride;       // level image, row stride in bytes (level 0: caller's stride)
+  int32_t nCols, nRows;       // FAST cell grid (cpp:1067-1075)
+  int32_t wCell, hCell;
+  int32_t maxBX, maxBY;       // maxBorderX/Y (cpp:1058-1059); minBorder = 16
+  int32_t cellBase;           // index of this level's first cell in the flattened (level, row, col) list
+  int32_t candCap;            // capacity of one frame's candidate list on this level
+  int32_t quota;              // mnFeaturesPerLevel
+  int32_t xtabOff, ytabOff;   // offsets into the resize tables (entries)
+  int32_t patchSize;          // (int)(31 * scale), cpp:1165
+  float scale;                // mvScaleFactor
+  int64_t imgOff;             // byte offset of frame 0's image inside the pyramid buffer (levels >= 1)
+  int64_t frameStride;        // bytes between consecutive frames of this level
+  int64_t candOff;            // entry offset of frame 0's candidate list (frame stride = candCap)
+};
+
+struct Geom {
+  int32_t nlevels;
+  int32_t nCellsTotal;
+  int32_t iniTh, minTh;
+  int32_t selCap;             // per-frame capacity of the selected-keypoint list (== output capacity)
+  int32_t pad_;
+  LevelGeom L[ORBX_MAX_LEVELS];
+};
+
+// candidate entry written by the FAST kernel: x | y<<12 | score<<24, x/y relative to minBorder
+#if defined(__HIPCC__)
+#define ORBX_HD __host__ __device__
+#else
+#define ORBX_HD
+#endif
+ORBX_HD static inline uint32_t packCand(int x, int y, int score) { return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)score << 24); }
+
+// a keypoint chosen by the quadtree stage, input of the orientation/descriptor kernel
+struct SelKp {
+  uint16_t x, y;        // level coordinates (already + minBorder)
+  uint8_t level, response;  // response = FAST score (<= 254)
+  uint16_t pad;
+};
+
+// launch wrappers (orbx_kernels.hip)
+struct ResizeTab {
+  int32_t ofs;    // source index
+  int32_t coef;   // c0 | c1 << 16 (Q11)
+};
+
+}  // namespace orbx

@@ -1,0 +1,115 @@
+"""Deterministic synthetic frames and descriptor sets.  Integer-only numpy so that the build
+container and the GPU box generate identical bytes.  Used by tests/ and bench.py; no reference code involved.
+
+scene(w, h, seed): gradient background (0..96) + 0.0008*w*h filled rectangles (8..64 px, gray U[0,255]) +
+0.0002*w*h 3x3 checker stamps; frames are crops of the scene plus uniform noise.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_M64 = (1 << 64) - 1
+
+
+class XorShift64Star:
+    def __init__(self, seed: int):
+        self.s = (seed * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & _M64 or 0x2545F4914F6CDD1D
+
+    def next(self) -> int:
+        x = self.s
+        x ^= x >> 12
+        x ^= (x << 25) & _M64
+        x ^= x >> 27
+        self.s = x
+        return ((x * 0x2545F4914F6CDD1D) & _M64) >> 16
+
+    def below(self, n: int) -> int:
+        return self.next() % n
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (x + np.uint64(0x9E3779B97F4A7C15))
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def _noise(h: int, w: int, seed: int, amp: int) -> np.ndarray:
+    idx = np.arange(h * w, dtype=np.uint64) + np.uint64((seed * 0x100000001B3) & _M64)
+    with np.errstate(over="ignore"):
+        r = _splitmix64(idx)
+    return ((r >> np.uint64(33)) % np.uint64(2 * amp + 1)).astype(np.int32).reshape(h, w) - amp
+
+
+def scene(w: int, h: int, seed: int) -> np.ndarray:
+    """int32 canvas of (h, w) without noise."""
+    rng = XorShift64Star(seed)
+    x = np.arange(w, dtype=np.int32)[None, :]
+    y = np.arange(h, dtype=np.int32)[:, None]
+    img = (x * 96 // max(w - 1, 1) + y * 96 // max(h - 1, 1)) // 2
+    img = np.ascontiguousarray(np.broadcast_to(img, (h, w))).astype(np.int32)
+    for _ in range(int(0.0008 * w * h)):
+        rw, rh = 8 + rng.below(57), 8 + rng.below(57)
+        x0, y0 = rng.below(w), rng.below(h)
+        img[y0:y0 + rh, x0:x0 + rw] = rng.below(256)
+    for _ in range(int(0.0002 * w * h)):
+        x0, y0 = rng.below(max(w - 3, 1)), rng.below(max(h - 3, 1))
+        a, b = rng.below(256), rng.below(256)
+        stamp = np.array([[a, b, a], [b, a, b], [a, b, a]], np.int32)
+        img[y0:y0 + 3, x0:x0 + 3] = stamp[:min(3, h - y0), :min(3, w - x0)]
+    return img
+
+
+def synth_pair(w: int, h: int, seed: int, shift=(7, 4)):
+    """Two uint8 frames of the same scene: B is A translated by `shift` px, with independent +-3 / +-2 noise."""
+    sx, sy = shift
+    sc = scene(w + sx, h + sy, seed)
+    a = sc[sy:sy + h, sx:sx + w] + _noise(h, w, 2 * seed + 1, 3)
+    b = sc[0:h, 0:w] + _noise(h, w, 2 * seed + 2, 2)
+    return np.clip(a, 0, 255).astype(np.uint8), np.clip(b, 0, 255).astype(np.uint8)
+
+
+def synth(w: int, h: int, seed: int) -> np.ndarray:
+    return synth_pair(w, h, seed)[0]
+
+
+def synth_frames(n: int, w: int, h: int, seed0: int = 1000) -> np.ndarray:
+    """n frames [n,h,w] uint8; frames 2k and 2k+1 form a pair of the same scene (seed0 + k)."""
+    out = np.empty((n, h, w), np.uint8)
+    for k in range((n + 1) // 2):
+        a, b = synth_pair(w, h, seed0 + k)
+        out[2 * k] = a
+        if 2 * k + 1 < n:
+            out[2 * k + 1] = b
+    return out
+
+
+def synth_desc(n: int, seed: int, w: int = 3840, h: int = 2160, max_flips: int = 80):
+    """Descriptor-set pair for the brute-force match configs: set A = n random 256-bit descriptors with
+    uniform positions/angles at octave 0; set B = a permutation of A with k in U[0, max_flips] flipped bits per
+    descriptor, angle + 12 deg + U(-3, 3), position jitter of +-2 px.  Returns (kpsA, descA, kpsB, descB) with the
+    28-byte keypoint dtype of orb_slam_tracking_amd.KEYPOINT_DTYPE."""
+    from . import KEYPOINT_DTYPE
+    rng = XorShift64Star(seed)
+    dA = np.zeros((n, 32), np.uint8)
+    kA = np.zeros(n, KEYPOINT_DTYPE)
+    for i in range(n):
+        for j in range(4):
+            v = rng.next() | (rng.next() << 48)
+            dA[i, 8 * j:8 * j + 8] = np.frombuffer(int(v & _M64).to_bytes(8, "little"), np.uint8)
+        kA[i] = (float(rng.below(w)), float(rng.below(h)), 31.0, rng.below(36000) / 100.0, float(1 + rng.below(200)), 0, -1)
+    perm = list(range(n))
+    for i in range(n - 1, 0, -1):
+        j = rng.below(i + 1)
+        perm[i], perm[j] = perm[j], perm[i]
+    dB = dA[perm].copy()
+    kB = kA[perm].copy()
+    for i in range(n):
+        for _ in range(rng.below(max_flips + 1)):
+            bit = rng.below(256)
+            dB[i, bit >> 3] ^= np.uint8(1 << (bit & 7))
+        ang = float(kB["angle"][i]) + 12.0 + (rng.below(601) - 300) / 100.0
+        kB["angle"][i] = np.float32(ang % 360.0)
+        kB["x"][i] = np.float32(min(max(float(kB["x"][i]) + rng.below(5) - 2, 0), w - 1))
+        kB["y"][i] = np.float32(min(max(float(kB["y"][i]) + rng.below(5) - 2, 0), h - 1))
+    return kA, dA, kB, dB

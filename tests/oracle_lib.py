@@ -1,0 +1,248 @@
+"""ctypes wrapper around oracle/liborbx_oracle.so — the CPU restatement of the reference algorithm.
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, and only as
+the checker / timed CPU baseline.  The product (orb_slam_tracking_amd/) never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+SO = os.path.join(ORACLE_DIR, "liborbx_oracle.so")
+
+KP = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"),
+               ("class_id", "<i4")])
+
+_L = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(ORACLE_DIR, "orbx_oracle.cpp")
+    if force or not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", ORACLE_DIR], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return SO
+
+
+def lib() -> ctypes.CDLL:
+    global _L
+    if _L is not None:
+        return _L
+    build()
+    L = ctypes.CDLL(SO)
+    vp, i32, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    L.orbo_create.restype = vp
+    L.orbo_create.argtypes = [i32, f32, i32, i32, i32]
+    L.orbo_destroy.argtypes = [vp]
+    L.orbo_destroy.restype = None
+    L.orbo_get_tables.argtypes = [vp] * 7
+    L.orbo_get_tables.restype = None
+    L.orbo_extract.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]
+    L.orbo_keep_blurred.argtypes = [vp, i32]
+    L.orbo_keep_blurred.restype = None
+    L.orbo_level_size.argtypes = [vp, i32, vp, vp]
+    L.orbo_level_image.argtypes = [vp, i32, vp]
+    L.orbo_level_blurred.argtypes = [vp, i32, vp]
+    L.orbo_level_candidates.argtypes = [vp, i32, vp, i32]
+    L.orbo_level_selected.argtypes = [vp, i32, vp, i32]
+    L.orbo_resize_linear.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32]
+    L.orbo_resize_linear.restype = None
+    L.orbo_gaussian7.argtypes = [vp, i32, i32, i32, vp, i32]
+    L.orbo_gaussian7.restype = None
+    L.orbo_fast.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32]
+    L.orbo_fast_strength.argtypes = [vp, i32, i32, i32, i32, i32]
+    L.orbo_distribute.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32]
+    L.orbo_fast_atan2.argtypes = [f32, f32]
+    L.orbo_fast_atan2.restype = f32
+    L.orbo_ic_angle.argtypes = [vp, i32, i32, f32, f32, vp, vp]
+    L.orbo_ic_angle.restype = f32
+    L.orbo_descriptor.argtypes = [vp, i32, i32, f32, f32, f32, vp]
+    L.orbo_descriptor.restype = None
+    L.orbo_sincos_deg.argtypes = [f32, vp, vp]
+    L.orbo_sincos_deg.restype = None
+    L.orbo_hamming.argtypes = [vp, vp]
+    L.orbo_pos_in_grid.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.orbo_pos_in_grid.restype = None
+    L.orbo_features_in_area.argtypes = [vp, i32, vp, f32, f32, f32, i32, i32, vp, i32]
+    L.orbo_match_init.argtypes = [vp, vp, i32, vp, vp, i32, vp, i32, f32, i32, vp, vp]
+    L.orbo_bench_pairs.argtypes = [i32, f32, i32, i32, i32, vp, i32, i32, i32, i32, f32, i32, i32, vp, vp]
+    L.orbo_bench_pairs.restype = ctypes.c_double
+    _L = L
+    return L
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else None
+
+
+class Extractor:
+    """CPU oracle of ORBextractor (reference Features/ORBextractor.cpp:492-595, 1531-1653)."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7):
+        self.L = lib()
+        self.h = self.L.orbo_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+        if not self.h:
+            raise ValueError("bad extractor parameters")
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.orbo_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def tables(self):
+        n = self.nlevels
+        sc, inv, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        q = np.zeros(n, np.int32)
+        um = np.zeros(16, np.int32)
+        self.L.orbo_get_tables(self.h, _p(sc), _p(inv), _p(s2), _p(is2), _p(q), _p(um))
+        return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, quota=q, umax=um)
+
+    def __call__(self, img: np.ndarray, lap=(0, 0), cap: int | None = None):
+        img = np.ascontiguousarray(img)
+        cap = cap or max(self.nfeatures + 64, 64)
+        k = np.zeros(cap, KP)
+        d = np.zeros((cap, 32), np.uint8)
+        n = ctypes.c_int(0)
+        r = self.L.orbo_extract(self.h, _p(img), img.shape[1], img.shape[0], img.strides[0], lap[0], lap[1], _p(k), _p(d), cap,
+                                ctypes.byref(n))
+        return r, k[:n.value].copy(), d[:n.value].copy()
+
+    def level_size(self, level):
+        w, h = ctypes.c_int(0), ctypes.c_int(0)
+        assert self.L.orbo_level_size(self.h, level, ctypes.byref(w), ctypes.byref(h)) == 0
+        return w.value, h.value
+
+    def level_image(self, level):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        assert self.L.orbo_level_image(self.h, level, _p(out)) == 0
+        return out
+
+    def keep_blurred(self, on=True):
+        self.L.orbo_keep_blurred(self.h, int(on))
+
+    def level_blurred(self, level):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        r = self.L.orbo_level_blurred(self.h, level, _p(out))
+        return out if r == 0 else None
+
+    def level_candidates(self, level):
+        n = self.L.orbo_level_candidates(self.h, level, None, 0)
+        out = np.zeros((max(n, 1), 3), np.float32)
+        self.L.orbo_level_candidates(self.h, level, _p(out), n)
+        return out[:n]
+
+    def level_selected(self, level):
+        out = np.zeros(self.nfeatures + 64, KP)
+        n = self.L.orbo_level_selected(self.h, level, _p(out), len(out))
+        return out[:n]
+
+
+def resize_linear(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    src = np.ascontiguousarray(src)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orbo_resize_linear(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+    return dst
+
+
+def gaussian7(src: np.ndarray) -> np.ndarray:
+    src = np.ascontiguousarray(src)
+    dst = np.zeros_like(src)
+    lib().orbo_gaussian7(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0])
+    return dst
+
+
+def fast(img: np.ndarray, t: int, nms: bool = True) -> np.ndarray:
+    img = np.ascontiguousarray(img)
+    n = lib().orbo_fast(_p(img), img.shape[1], img.shape[0], img.strides[0], t, int(nms), None, 0)
+    out = np.zeros((max(n, 1), 3), np.float32)
+    lib().orbo_fast(_p(img), img.shape[1], img.shape[0], img.strides[0], t, int(nms), _p(out), n)
+    return out[:n]
+
+
+def fast_strength(img: np.ndarray, x: int, y: int) -> int:
+    img = np.ascontiguousarray(img)
+    return lib().orbo_fast_strength(_p(img), img.shape[1], img.shape[0], img.strides[0], x, y)
+
+
+def distribute(xyr: np.ndarray, min_x, max_x, min_y, max_y, n_features) -> np.ndarray:
+    xyr = np.ascontiguousarray(xyr, np.float32).reshape(-1, 3)
+    out = np.zeros((len(xyr) + 8, 3), np.float32)
+    n = lib().orbo_distribute(_p(xyr), len(xyr), min_x, max_x, min_y, max_y, n_features, _p(out), len(out))
+    return out[:n]
+
+
+def fast_atan2(y: float, x: float) -> float:
+    return float(lib().orbo_fast_atan2(y, x))
+
+
+def ic_angle(img: np.ndarray, x: float, y: float):
+    img = np.ascontiguousarray(img)
+    m10, m01 = ctypes.c_int(0), ctypes.c_int(0)
+    a = lib().orbo_ic_angle(_p(img), img.shape[1], img.shape[0], x, y, ctypes.byref(m10), ctypes.byref(m01))
+    return float(a), m10.value, m01.value
+
+
+def descriptor(blurred: np.ndarray, x: float, y: float, angle: float) -> np.ndarray:
+    blurred = np.ascontiguousarray(blurred)
+    d = np.zeros(32, np.uint8)
+    lib().orbo_descriptor(_p(blurred), blurred.shape[1], blurred.shape[0], x, y, angle, _p(d))
+    return d
+
+
+def hamming(a: np.ndarray, b: np.ndarray) -> int:
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orbo_hamming(_p(a), _p(b))
+
+
+def pos_in_grid(kps: np.ndarray, bounds):
+    kps = np.ascontiguousarray(kps, KP)
+    b = np.array(bounds, np.int32)
+    n = len(kps)
+    px, py, ok = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    lib().orbo_pos_in_grid(_p(kps), n, _p(b), _p(px), _p(py), _p(ok))
+    return px, py, ok.astype(bool)
+
+
+def features_in_area(kps: np.ndarray, bounds, x, y, r, min_level=-1, max_level=-1) -> np.ndarray:
+    kps = np.ascontiguousarray(kps, KP)
+    b = np.array(bounds, np.int32)
+    out = np.zeros(len(kps) + 1, np.int32)
+    n = lib().orbo_features_in_area(_p(kps), len(kps), _p(b), x, y, r, min_level, max_level, _p(out), len(out))
+    return out[:n]
+
+
+def match_init(k1, d1, k2, d2, bounds, window=100, nnratio=0.9, check_ori=True):
+    """Oracle of ORBmatcher::SearchForInitialization.  Returns (nmatches, matches12, stats[3])."""
+    k1 = np.ascontiguousarray(k1, KP)
+    k2 = np.ascontiguousarray(k2, KP)
+    d1 = np.ascontiguousarray(d1, np.uint8)
+    d2 = np.ascontiguousarray(d2, np.uint8)
+    b = np.array(bounds, np.int32)
+    m = np.full(max(len(k1), 1), -1, np.int32)
+    st = np.zeros(3, np.int32)
+    nm = lib().orbo_match_init(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), _p(b), window, nnratio, int(check_ori), _p(m),
+                               _p(st))
+    return nm, m[:len(k1)].copy(), st
+
+
+def bench_pairs(params, imgs: np.ndarray, window=100, nnratio=0.9, nthreads=1, reps=1):
+    """CPU baseline: extract(A) + extract(B) + SearchForInitialization per pair.  Returns (seconds, frames, checksum)."""
+    imgs = np.ascontiguousarray(imgs, np.uint8)
+    n, h, w = imgs.shape
+    frames = ctypes.c_long(0)
+    chk = ctypes.c_int(0)
+    sec = lib().orbo_bench_pairs(params[0], params[1], params[2], params[3], params[4], _p(imgs), n, w, h, window, nnratio,
+                                 nthreads, reps, ctypes.byref(frames), ctypes.byref(chk))
+    return float(sec), int(frames.value), int(chk.value)

@@ -1,0 +1,184 @@
+"""CPU-only: pins the oracle (oracle/orbx_oracle.cpp) against every known-answer the reference's source holds for this
+path (K1-K4, constants) and against the committed golden vectors."""
+import hashlib
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+QUOTAS = {1000: [217, 181, 151, 126, 105, 87, 73, 60], 1250: [271, 226, 189, 157, 131, 109, 91, 76],
+          2000: [434, 362, 302, 251, 209, 175, 145, 122], 4000: [869, 724, 603, 503, 419, 349, 291, 242],
+          8000: [1737, 1448, 1207, 1005, 838, 698, 582, 485]}
+UMAX = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+
+
+def test_quotas_and_umax(oracle):  # K1, K2 (Features/ORBextractor.cpp:529-548, 562-594)
+    for nf, q in QUOTAS.items():
+        t = oracle.Extractor(nf, 1.2, 8, 20, 7).tables()
+        assert t["quota"].tolist() == q and int(t["quota"].sum()) == nf  # "Sum of features", cpp:549
+        assert t["umax"].tolist() == UMAX
+    t = oracle.Extractor(1000, 1.2, 8, 20, 7).tables()
+    s = np.float32(1.0)
+    for l in range(8):
+        assert t["scale"][l] == s
+        assert t["inv_scale"][l] == np.float32(1.0) / s
+        s = np.float32(np.float64(s) * np.float64(np.float32(1.2)))
+
+
+@pytest.mark.parametrize("rel", ["oracle/orbx_pattern_data.inc", "orb_slam_tracking_amd/csrc/orbx_pattern_data.inc"])
+def test_pattern_table_sha(rel):  # K3 (cpp:233-490)
+    txt = open(os.path.join(ROOT, rel)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    vals = [int(v) for v in re.findall(r"-?\d+", txt)]
+    assert len(vals) == 1024 and min(vals) == -13 and max(vals) == 12
+    assert vals[:4] == [8, -3, 9, 5] and vals[-4:] == [-1, -6, 0, -11]
+    assert hashlib.sha256(struct.pack("<1024i", *vals)).hexdigest() == \
+        "7e645581387b82784797e8adddb9b6f0c12611859fda09ca8a9bec96d767a05f"
+
+
+def test_hamming_kats(oracle):  # K4 (Thirdparty/DBoW2/src/FORB.cpp:77-101)
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, 32, dtype=np.uint8)
+    assert oracle.hamming(a, a) == 0
+    assert oracle.hamming(np.zeros(32, np.uint8), np.full(32, 255, np.uint8)) == 256
+    b = a.copy()
+    b[7] ^= 0x10
+    assert oracle.hamming(a, b) == 1
+    for _ in range(50):
+        x, y = rng.integers(0, 256, (2, 32), dtype=np.uint8)
+        assert oracle.hamming(x, y) == int(np.unpackbits(x ^ y).sum())
+
+
+def test_fast_atan2(oracle):
+    assert oracle.fast_atan2(0.0, 0.0) == 0.0
+    rng = np.random.default_rng(1)
+    for _ in range(2000):
+        y, x = (float(v) for v in rng.integers(-1200000, 1200000, 2))
+        a = oracle.fast_atan2(y, x)
+        ref = np.degrees(np.arctan2(y, x)) % 360.0
+        d = abs(a - ref)
+        assert min(d, 360 - d) < 0.02  # cv::fastAtan2's documented accuracy is ~0.3 deg; the polynomial is far better
+        assert 0.0 <= a <= 360.0
+
+
+def test_resize_properties(oracle):
+    const = np.full((48, 64), 137, np.uint8)
+    assert (oracle.resize_linear(const, 53, 40) == 137).all()  # Q11 weights sum to 2048
+    ramp = np.tile(np.arange(0, 240, 2, dtype=np.uint8), (30, 1))
+    out = oracle.resize_linear(ramp, 100, 25)
+    assert (np.diff(out.astype(int), axis=1) >= 0).all()
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (40, 60), dtype=np.uint8)
+    assert np.array_equal(oracle.resize_linear(img, 60, 40), img)  # identity scale
+
+
+def test_gaussian_properties(oracle):
+    const = np.full((20, 30), 201, np.uint8)
+    assert (oracle.gaussian7(const) == 201).all()  # taps [18,34,48,56,48,34,18] sum to 256
+    imp = np.zeros((21, 21), np.uint8)
+    imp[10, 10] = 255
+    out = oracle.gaussian7(imp).astype(int)
+    k = np.array([18, 34, 48, 56, 48, 34, 18])
+    exp = (np.outer(k, k) * 255 + 32768) >> 16
+    assert np.array_equal(out[7:14, 7:14], exp) and out.sum() == exp.sum()
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (17, 23), dtype=np.uint8)
+    pad = np.pad(img, 3, mode="reflect").astype(np.int64)  # numpy 'reflect' == BORDER_REFLECT_101
+    hz = sum(k[i] * pad[:, i:i + 23] for i in range(7))
+    vt = sum(k[i] * hz[i:i + 17, :] for i in range(7))
+    assert np.array_equal(oracle.gaussian7(img), ((vt + 32768) >> 16).astype(np.uint8))
+
+
+def test_fast_definition(oracle):
+    """cv::FAST semantics against a literal numpy evaluation on a small random image."""
+    rng = np.random.default_rng(4)
+    img = (rng.integers(0, 256, (24, 28)) // 32 * 32).astype(np.uint8)
+    ring = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+            (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    h, w = img.shape
+    s = np.zeros((h, w), int)
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            d = [int(img[y, x]) - int(img[y + dy, x + dx]) for dx, dy in ring]
+            best = -999
+            for st in range(16):
+                arc = [d[(st + j) % 16] for j in range(9)]
+                best = max(best, min(arc), -max(arc))
+            s[y, x] = best
+            assert oracle.fast_strength(img, x, y) == best
+    for t in (0, 7, 20, 40):
+        score = np.where(s > t, s - 1, 0)
+        exp = []
+        for y in range(3, h - 3):
+            for x in range(3, w - 3):
+                if s[y, x] > t:
+                    nb = score[y - 1:y + 2, x - 1:x + 2].copy()
+                    nb[1, 1] = -1
+                    if (score[y, x] > nb).all():
+                        exp.append((x, y, score[y, x]))
+        got = oracle.fast(img, t, True)
+        assert [tuple(int(v) for v in r) for r in got] == exp
+        nonms = oracle.fast(img, t, False)
+        assert len(nonms) == int((s[3:h - 3, 3:w - 3] > t).sum())
+
+
+def test_golden_vectors(oracle, images, golden):
+    """Oracle reproduces the committed golden outputs bit for bit (regression pin; see tests/golden/make_fixtures.py)."""
+    presets = {"canonical": (1000, 1.2, 8, 20, 7), "as_shipped": (2000, 1.2, 8, 0, 0)}
+    for pname, p in presets.items():
+        ex = oracle.Extractor(*p)
+        res = {}
+        for name, im in images.items():
+            key = "%s/%s/kps" % (pname, name)
+            if key not in golden:
+                continue
+            r, k, d = ex(im, cap=p[0] + 64)
+            assert r == int(golden["%s/%s/ret" % (pname, name)])
+            assert k.tobytes() == golden[key].tobytes()
+            assert np.array_equal(d, golden["%s/%s/desc" % (pname, name)])
+            res[name] = (k, d)
+        for key in [k for k in golden if k.startswith(pname) and k.endswith("/matches12")]:
+            a, b = key.split("/")[1].split("-")
+            h, w = images[a].shape
+            nm, m12, st = oracle.match_init(res[a][0], res[a][1], res[b][0], res[b][1], (0, w, 0, h), 100, 0.9, True)
+            assert nm == int(golden[key.replace("matches12", "nmatches")])
+            assert np.array_equal(m12, golden[key]) and np.array_equal(st, golden[key.replace("matches12", "stats")])
+
+
+def test_behavioural_pins(golden):
+    """The only behavioural pins the reference holds: `Sum of features == nfeatures` and
+    `nmatches >= 100` on the two init images with the shipped settings (demo_initialization.cpp:110)."""
+    assert int(golden["as_shipped/init0-init1/nmatches"]) >= 100
+    assert len(golden["as_shipped/init0/kps"]) == 2000 and len(golden["as_shipped/init1/kps"]) == 2000
+    assert golden["canonical/dbow0/desc"].shape == (1000, 32) and golden["canonical/dbow0/desc"].dtype == np.uint8
+    k = golden["canonical/dbow0/kps"]
+    assert (np.diff(k["octave"]) >= 0).all()  # level-major output order (cpp:1587-1650)
+    assert (k["class_id"] == -1).all() and (k["x"] >= 19).all() and (k["y"] >= 19).all()
+
+
+def test_matcher_quirks(oracle):
+    """Q14/Q15/Q17/Q19 of SURVEY appendix B on hand-built inputs."""
+    KP = oracle.KP
+    k1 = np.zeros(3, KP)
+    k2 = np.zeros(2, KP)
+    k1["x"], k1["y"] = [100, 102, 104], [100, 100, 100]
+    k2["x"], k2["y"] = [101, 300], [100, 300]
+    k1["angle"] = [10, 10, 10]
+    k2["angle"] = [10, 10]
+    d2 = np.zeros((2, 32), np.uint8)
+    d1 = np.zeros((3, 32), np.uint8)
+    d1[0, 0] = 0b00000111  # dist 3 to train 0
+    d1[1, 0] = 0b00000001  # dist 1 -> steals train 0
+    d1[2, 0] = 0b00000011  # dist 2 -> train 0 hidden by vMatchedDistance (1 <= 2): bestDist stays INT_MAX
+    nm, m12, st = oracle.match_init(k1, d1, k2, d2, (0, 640, 0, 480), 100, 0.9, True)
+    assert m12.tolist() == [-1, 0, -1]
+    assert st.tolist() == [1, 0, 0]  # Q19: query 2 counted as invalid-by-distance
+    assert nm == 1                   # +1 (q0) -1 +1 (q1 steals); both share the kept histogram bin
+    # second-best absent => ratio test passes with INT_MAX (Q17); octave>0 queries/trains ignored (Q13)
+    k1["octave"] = [0, 1, 0]
+    nm, m12, st = oracle.match_init(k1, d1, k2, d2, (0, 640, 0, 480), 100, 0.9, False)
+    assert m12.tolist() == [-1, -1, 0] and nm == 1  # q2 (dist 2) steals from q0 (dist 3)
