@@ -44,6 +44,18 @@ def algorithmic_bytes(w, h, n_kp):
     }
 
 
+def cpu_share():
+    """Host cores this process may really use: cgroup quota if set, else the affinity mask; capped at 64."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,10 +163,10 @@ def main():
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O
-            cores = max(1, len(os.sched_getaffinity(0)))
+            cores = cpu_share()
             sample = frames[:8]
             sec1, fr1, _ = O.bench_pairs(PARAMS, sample, 100, 0.9, 1, 1)  # calibrate: one pass, one core
-            reps = max(1, int(args.cpu_seconds / max(sec1, 1e-3)))
+            reps = max(1, min(50, int(args.cpu_seconds / max(sec1, 1e-3))))
             sec, fr, _ = O.bench_pairs(PARAMS, sample, 100, 0.9, cores, reps)
             out["cpu_baseline"] = {"value": fr / sec, "unit": "frames/s", "cores": cores, "kind": "port",
                                    "sample": "oracle restatement (scalar C++, -O3, no SIMD): %d threads x %d reps of 8 of the same "
