@@ -148,6 +148,15 @@ int orbx_debug_candidates(orbx_ctx* ctx, int frame, int level, float* xyr, int c
 /* quadtree selection alone: DistributeOctTree (cpp:698-1011) on caller-supplied candidates. */
 int orbx_debug_distribute(const float* xyr, int n, int min_x, int max_x, int min_y, int max_y, int n_features,
                           float* out_xyr, int cap);
+/* The same selection on the device (the kernels the pipeline uses).  Candidates must be given in row-major (y, x)
+ * order with integer coordinates in [0, 4095] relative to (min_x, min_y) and integer responses in [0, 255].
+ * variant 0 = LDS-resident kernel (handing over to the global-scratch kernel when a unit does not fit),
+ * variant 1 = global-scratch kernel only. */
+int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min_x, int max_x, int min_y, int max_y,
+                                 int n_features, int variant, float* out_xyr, int cap);
+/* The device's literal replay of libstdc++ std::sort with the reference's compareNodes (cpp:684-696, 912) on n
+ * (count, UL.x, id) int32 triples, in place. */
+int orbx_debug_std_sort(orbx_ctx* ctx, int32_t* triples, int n);
 
 #ifdef __cplusplus
 }

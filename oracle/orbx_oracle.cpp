@@ -793,6 +793,18 @@ int orbo_distribute(const float* xyr, int n, int minX, int maxX, int minY, int m
   for (int i = 0; i < (int)r.size() && i < cap; i++) { out_xyr[3 * i] = r[i].x; out_xyr[3 * i + 1] = r[i].y; out_xyr[3 * i + 2] = r[i].response; }
   return (int)r.size();
 }
+// the std::sort call of cpp:912 in isolation: (count, UL.x, id) triples ordered with compareNodes (cpp:684-696)
+void orbo_std_sort_sized(int* triples, int n) {
+  struct T3 { int c, u, id; };
+  std::vector<T3> v(n);
+  for (int i = 0; i < n; i++) v[i] = {triples[3 * i], triples[3 * i + 1], triples[3 * i + 2]};
+  std::sort(v.begin(), v.end(), [](const T3& a, const T3& b) {
+    if (a.c < b.c) return true;
+    if (a.c > b.c) return false;
+    return a.u < b.u;
+  });
+  for (int i = 0; i < n; i++) { triples[3 * i] = v[i].c; triples[3 * i + 1] = v[i].u; triples[3 * i + 2] = v[i].id; }
+}
 float orbo_fast_atan2(float y, float x) { return fastAtan2(y, x); }
 float orbo_ic_angle(const uint8_t* img, int w, int h, float x, float y, int* m10, int* m01) {
   Image im; im.w = w; im.h = h; im.px.assign(img, img + (size_t)w * h);

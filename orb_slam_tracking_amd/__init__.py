@@ -92,6 +92,8 @@ def lib() -> ctypes.CDLL:
     L.orbx_profile_get.argtypes = [vp, vp, vp]
     L.orbx_debug_candidates.argtypes = [vp, i32, i32, vp, i32]
     L.orbx_debug_distribute.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32]
+    L.orbx_debug_distribute_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32]
+    L.orbx_debug_std_sort.argtypes = [vp, vp, i32]
     _LIB = L
     return L
 
@@ -256,6 +258,20 @@ class ORBextractor:
         cnt = np.zeros(len(STAGES), np.int64)
         self._L.orbx_profile_get(self._h, _ptr(ms), _ptr(cnt))
         return {s: (float(ms[i]), int(cnt[i])) for i, s in enumerate(STAGES)}
+
+    def debug_distribute_device(self, xyr: np.ndarray, min_x: int, max_x: int, min_y: int, max_y: int, n_features: int,
+                                variant: int = 0) -> np.ndarray:
+        """The device selection kernels on caller-supplied, row-major ordered candidates (test hook)."""
+        xyr = np.ascontiguousarray(xyr, np.float32).reshape(-1, 3)
+        out = np.zeros((max(n_features, 1), 3), np.float32)
+        r = self._check(self._L.orbx_debug_distribute_device(self._h, _ptr(xyr), len(xyr), min_x, max_x, min_y, max_y,
+                                                             n_features, variant, _ptr(out), len(out)))
+        return out[:r]
+
+    def debug_std_sort(self, triples: np.ndarray) -> np.ndarray:
+        t = np.ascontiguousarray(triples, np.int32).reshape(-1, 3).copy()
+        self._check(self._L.orbx_debug_std_sort(self._h, _ptr(t), len(t)))
+        return t
 
     def debug_candidates(self, frame: int, level: int) -> np.ndarray:
         n = self._check(self._L.orbx_debug_candidates(self._h, frame, level, None, 0))

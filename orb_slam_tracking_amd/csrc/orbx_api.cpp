@@ -1,23 +1,18 @@
 // orbx_api.cpp — host side of liborbx: context, per-batch pipeline and the C ABI of include/orbx.h.
 //
 // Pipeline of one batch (B frames, all on one HIP stream):
-//   k_resize x (nlevels-1)  ->  k_fast (all cells of all levels of all frames)  ->  candidate counts D2H
-//   -> candidates D2H -> quadtree selection on host threads (orbx_octree.cpp) -> selected keypoints H2D
+//   k_resize x (nlevels-1)  ->  k_fast (all cells of all levels of all frames)
+//   -> k_octree_* (quadtree selection, one workgroup per frame x level) -> k_sel_compact
 //   -> k_describe (orientation + blur + descriptors) -> results stay in HBM (device API) or D2H (host API)
-// and, for matching, k_match with one workgroup per frame pair.
+// and, for matching, k_match with one workgroup per frame pair.  No host round trip inside a batch: the host only
+// issues the launches and reads two error flags + the per-frame counts at the end.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <atomic>
-#include <chrono>
 #include <cmath>
-#include <condition_variable>
 #include <cstdio>
 #include <cstring>
-#include <functional>
-#include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "orbx_device.h"
@@ -36,88 +31,17 @@ hipError_t launch_describe(hipStream_t st, int nFrames, int maxSel, const uint8_
 hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int* dSecond, const orbx_keypoint* kps,
                         const uint8_t* desc, const int* nkp, int capacity, orbx_bounds b, int window, float nnratio, int checkOri,
                         int* matches12, int* nmatches, int* stats, int* scratch);
+hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, const int* candCount, const OctLaunch& P,
+                         SelKp* selStage, int* nselLevel, uint8_t* scratch, int maxQuota);
+hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage, const int* nselLevel, const OctLaunch& P,
+                              SelKp* sel, int* nsel, int selCap, int* err);
+size_t octScratchBytes(int nMax, int qMax);
 
 namespace {
 
 inline int cvRoundF(float v) { return (int)lrintf(v); }  // round half to even
 inline int cvRoundD(double v) { return (int)lrint(v); }
 inline int alignUp(int v, int a) { return (v + a - 1) / a * a; }
-
-// ---------------------------------------------------------------------------------------------
-// small persistent thread pool for the host-side selection stage
-// ---------------------------------------------------------------------------------------------
-class ThreadPool {
- public:
-  explicit ThreadPool(int n) {
-    for (int i = 0; i < n; i++) workers_.emplace_back([this] { loop(); });
-  }
-  ~ThreadPool() {
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      stop_ = true;
-    }
-    cv_.notify_all();
-    for (auto& t : workers_) t.join();
-  }
-  void parallelFor(int n, const std::function<void(int)>& fn) {
-    if (n <= 0) return;
-    if (workers_.empty() || n == 1) {
-      for (int i = 0; i < n; i++) fn(i);
-      return;
-    }
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      fn_ = &fn;
-      total_ = n;
-      next_ = 0;
-      done_ = 0;
-      gen_++;
-    }
-    cv_.notify_all();
-    work();  // the caller helps
-    std::unique_lock<std::mutex> lk(m_);
-    doneCv_.wait(lk, [this] { return done_ == total_; });
-    fn_ = nullptr;
-  }
-
- private:
-  void work() {
-    for (;;) {
-      int i;
-      const std::function<void(int)>* fn;
-      {
-        std::lock_guard<std::mutex> lk(m_);
-        if (!fn_ || next_ >= total_) return;
-        i = next_++;
-        fn = fn_;
-      }
-      (*fn)(i);
-      {
-        std::lock_guard<std::mutex> lk(m_);
-        if (++done_ == total_) doneCv_.notify_all();
-      }
-    }
-  }
-  void loop() {
-    unsigned long seen = 0;
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
-        if (stop_) return;
-        seen = gen_;
-      }
-      work();
-    }
-  }
-  std::vector<std::thread> workers_;
-  std::mutex m_;
-  std::condition_variable cv_, doneCv_;
-  const std::function<void(int)>* fn_ = nullptr;
-  int total_ = 0, next_ = 0, done_ = 0;
-  unsigned long gen_ = 0;
-  bool stop_ = false;
-};
 
 }  // namespace
 }  // namespace orbx
@@ -151,16 +75,20 @@ struct orbx_ctx {
   size_t tabEntries = 0;
   SelKp* dSel = nullptr;
   int* dNsel = nullptr;
+  // quadtree selection stage (device)
+  OctLaunch oct{};
+  int maxQuota = 0;
+  SelKp* dSelStage = nullptr;
+  int* dNselLevel = nullptr;
+  uint8_t* dOctScratch = nullptr;
+  size_t octScratchBytes = 0;
+  int* hFlags = nullptr;  // pinned: [0] candidate overflow, [1] selection error
   uint8_t* dIn = nullptr;
   size_t inBytes = 0;
   orbx_keypoint* dKps = nullptr;
   uint8_t* dDesc = nullptr;
   // pinned host mirrors
-  int* hCandCount = nullptr;
-  uint32_t* hCand = nullptr;
-  SelKp* hSel = nullptr;
   int* hNsel = nullptr;
-  int* hOverflow = nullptr;
   // matcher
   int* dMatchScratch = nullptr;
   size_t matchScratchInts = 0;
@@ -175,7 +103,6 @@ struct orbx_ctx {
   const uint8_t* lastImg0 = nullptr;
   long long lastFrameStride0 = 0;
   int lastB = 0;
-  std::vector<int> lastCandCount;
 
   // profiling
   bool prof = false;
@@ -184,7 +111,6 @@ struct orbx_ctx {
   int64_t launches[ORBX_STAGE_COUNT]{};
 
   std::string err;
-  ThreadPool* pool = nullptr;
 };
 
 namespace {
@@ -351,6 +277,37 @@ Sizes sizesOf(const orbx_ctx* c, const Geom& g, size_t tabEntries) {
   return s;
 }
 
+// launch constants of the quadtree selection stage; returns the bytes of global scratch it needs
+size_t buildOctLaunch(const orbx_ctx* c, const Geom& g, OctLaunch* out) {
+  OctLaunch P{};
+  P.nlevels = g.nlevels;
+  P.selStride = g.selCap;
+  int selOff = 0;
+  int64_t scr = 0;
+  for (int l = 0; l < g.nlevels; l++) {
+    const LevelGeom& L = g.L[l];
+    OctLevel& O = P.lev[l];
+    O.width = L.maxBX - ORBX_MIN_BORDER;
+    O.height = L.maxBY - ORBX_MIN_BORDER;
+    O.nIni = (int)std::round((float)O.width / (float)O.height);  // cpp:706
+    O.hX = (float)O.width / (float)O.nIni;                       // cpp:709
+    O.wCell = L.wCell;
+    O.hCell = L.hCell;
+    O.nCols = L.nCols;
+    O.quota = L.quota;
+    P.candOff[l] = L.candOff;
+    P.candCap[l] = L.candCap;
+    P.selOff[l] = selOff;
+    selOff += L.quota;
+    P.scrNMax[l] = std::min(L.candCap, ORBX_OCT_MAX_CAND);
+    P.scrStride[l] = (int64_t)octScratchBytes(P.scrNMax[l], L.quota);
+    P.scrOff[l] = scr;
+    scr += P.scrStride[l] * c->maxB;
+  }
+  *out = P;
+  return (size_t)scr;
+}
+
 int ensureGeometry(orbx_ctx* ctx, int w, int h, int stride0) {
   if (w == ctx->curW && h == ctx->curH && stride0 == ctx->curStride0) return ORBX_OK;
   if (w <= 0 || h <= 0) return ORBX_E_EMPTY;
@@ -360,11 +317,15 @@ int ensureGeometry(orbx_ctx* ctx, int w, int h, int stride0) {
   int r = buildGeometry(ctx, w, h, stride0, &g, &tab);
   if (r != ORBX_OK) return r;
   Sizes s = sizesOf(ctx, g, tab.size());
-  if (s.pyrBytes > ctx->pyrBytes || s.candEntries > ctx->candEntries || s.tabEntries > ctx->tabEntries) {
+  OctLaunch oct;
+  const size_t octBytes = buildOctLaunch(ctx, g, &oct);
+  if (s.pyrBytes > ctx->pyrBytes || s.candEntries > ctx->candEntries || s.tabEntries > ctx->tabEntries ||
+      octBytes > ctx->octScratchBytes) {
     ctx->err = "internal: geometry exceeds the buffers sized at orbx_create";
     return ORBX_E_BADARG;
   }
   ctx->g = g;
+  ctx->oct = oct;
   ctx->hTab = tab;
   if (!tab.empty()) HIPCHK(hipMemcpyAsync(ctx->dTab, ctx->hTab.data(), tab.size() * sizeof(ResizeTab), hipMemcpyHostToDevice, ctx->st));
   HIPCHK(hipStreamSynchronize(ctx->st));
@@ -417,7 +378,7 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
   const int aligned0 = (((uintptr_t)dImg0 | (uintptr_t)stride0 | (uintptr_t)frameStride0) & 3) == 0;
   bool used[ORBX_STAGE_COUNT] = {false, false, false, false, false};
 
-  HIPCHK(hipMemsetAsync(ctx->dCandCount, 0, sizeof(int) * (size_t)B * nl + sizeof(int), st));  // counts + overflow flag
+  HIPCHK(hipMemsetAsync(ctx->dCandCount, 0, sizeof(int) * ((size_t)ctx->maxB * nl + 2), st));  // counts + overflow + selection-error flags
   {
     StageTimer tm(ctx, ORBX_STAGE_PYRAMID);
     for (int l = 1; l < nl; l++) {
@@ -437,84 +398,32 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
     tm.stop(1);
     used[ORBX_STAGE_FAST] = true;
   }
-  // ---- selection stage: candidates to the host, quadtree on host threads, selection back ----
-  auto tSel0 = std::chrono::steady_clock::now();
-  HIPCHK(hipMemcpyAsync(ctx->hCandCount, ctx->dCandCount, sizeof(int) * (size_t)B * nl + sizeof(int), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  if (ctx->hCandCount[(size_t)B * nl]) { ctx->err = "internal: candidate buffer overflow"; return ORBX_E_CAPACITY; }
-  std::vector<int> maxCount(nl, 0);
-  std::vector<size_t> hostOff(nl, 0);
-  size_t hostTotal = 0;
-  for (int l = 0; l < nl; l++) {
-    for (int f = 0; f < B; f++) maxCount[l] = std::max(maxCount[l], ctx->hCandCount[f * nl + l]);
-    hostOff[l] = hostTotal;
-    hostTotal += (size_t)maxCount[l] * B;
-    if (maxCount[l] > 0)
-      HIPCHK(hipMemcpy2DAsync(ctx->hCand + hostOff[l], (size_t)maxCount[l] * 4, ctx->dCand + g.L[l].candOff,
-                              (size_t)g.L[l].candCap * 4, (size_t)maxCount[l] * 4, B, hipMemcpyDeviceToHost, st));
-  }
-  HIPCHK(hipStreamSynchronize(st));
-  std::atomic<int> selErr{0};
-  ctx->pool->parallelFor(B, [&](int f) {
-    std::vector<uint64_t> keyed;
-    std::vector<OctCand> oc;
-    std::vector<int> chosen;
-    SelKp* out = ctx->hSel + (size_t)f * g.selCap;
-    int n = 0;
-    for (int l = 0; l < nl; l++) {
-      const LevelGeom& L = g.L[l];
-      const int cnt = ctx->hCandCount[f * nl + l];
-      const uint32_t* src = ctx->hCand + hostOff[l] + (size_t)f * maxCount[l];
-      keyed.resize(cnt);
-      for (int i = 0; i < cnt; i++) keyed[i] = (candOrderKey(L, src[i]) << 8) | (src[i] >> 24);
-      std::sort(keyed.begin(), keyed.end());
-      oc.resize(cnt);
-      for (int i = 0; i < cnt; i++) {
-        oc[i].x = (float)((keyed[i] >> 8) & 0xfff);
-        oc[i].y = (float)((keyed[i] >> 20) & 0xfff);
-        oc[i].response = (float)(keyed[i] & 0xff);
-      }
-      int rs = octree_select(oc.data(), cnt, ORBX_MIN_BORDER, L.maxBX, ORBX_MIN_BORDER, L.maxBY, L.quota, chosen);
-      if (rs < 0) { selErr = rs; return; }
-      const int keep = std::min((int)chosen.size(), L.quota);  // cpp:1159-1161
-      for (int i = 0; i < keep; i++) {
-        const OctCand& c = oc[chosen[i]];
-        SelKp k;
-        k.x = (uint16_t)((int)c.x + ORBX_MIN_BORDER);  // cpp:1171-1172
-        k.y = (uint16_t)((int)c.y + ORBX_MIN_BORDER);
-        k.level = (uint8_t)l;
-        k.response = (uint8_t)c.response;
-        k.pad = 0;
-        out[n++] = k;
-      }
-    }
-    ctx->hNsel[f] = n;
-  });
-  if (selErr.load() < 0) return selErr.load();
-  int maxSel = 0;
-  for (int f = 0; f < B; f++) maxSel = std::max(maxSel, ctx->hNsel[f]);
-  HIPCHK(hipMemcpyAsync(ctx->dNsel, ctx->hNsel, sizeof(int) * B, hipMemcpyHostToDevice, st));
-  if (maxSel > 0)
-    HIPCHK(hipMemcpy2DAsync(ctx->dSel, (size_t)g.selCap * sizeof(SelKp), ctx->hSel, (size_t)g.selCap * sizeof(SelKp),
-                            (size_t)maxSel * sizeof(SelKp), B, hipMemcpyHostToDevice, st));
-  if (ctx->prof) {
-    HIPCHK(hipStreamSynchronize(st));
-    ctx->ms[ORBX_STAGE_SELECT] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tSel0).count();
-    ctx->launches[ORBX_STAGE_SELECT] += 1;
+  // ---- selection stage on the device: quadtree per (frame, level), then level-major compaction ----
+  {
+    StageTimer tm(ctx, ORBX_STAGE_SELECT);
+    HIPCHK(launch_octree(st, B, ctx->dCand, ctx->dCandCount, ctx->oct, ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch,
+                         ctx->maxQuota));
+    HIPCHK(launch_sel_compact(st, B, ctx->dSelStage, ctx->dNselLevel, ctx->oct, ctx->dSel, ctx->dNsel, g.selCap,
+                              ctx->dOverflow + 1));
+    tm.stop(ctx->maxQuota <= 256 ? 3 : 2);
+    used[ORBX_STAGE_SELECT] = true;
   }
   {
     StageTimer tm(ctx, ORBX_STAGE_DESCRIBE);
-    HIPCHK(launch_describe(st, B, maxSel, dImg0, frameStride0, ctx->dPyr, g, ctx->dSel, ctx->dNsel, dKps, dDesc, capacity));
-    tm.stop(maxSel > 0 ? 1 : 0);
+    HIPCHK(launch_describe(st, B, g.selCap, dImg0, frameStride0, ctx->dPyr, g, ctx->dSel, ctx->dNsel, dKps, dDesc, capacity));
+    tm.stop(1);
     used[ORBX_STAGE_DESCRIBE] = true;
   }
   if (dNout) HIPCHK(hipMemcpyAsync(dNout, ctx->dNsel, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->hNsel, ctx->dNsel, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(ctx->hFlags, ctx->dOverflow, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   collectProfile(ctx, used);
   ctx->lastImg0 = dImg0;
   ctx->lastFrameStride0 = frameStride0;
   ctx->lastB = B;
-  ctx->lastCandCount.assign(ctx->hCandCount, ctx->hCandCount + (size_t)B * nl);
+  if (ctx->hFlags[0]) { ctx->err = "internal: candidate buffer overflow"; return ORBX_E_CAPACITY; }
+  if (ctx->hFlags[1]) { ctx->err = "selection stage: more candidates or nodes than its scratch can hold"; return ORBX_E_CAPACITY; }
   return ORBX_OK;
 }
 
@@ -570,27 +479,30 @@ int orbx_create(const orbx_params* params, int device_id, int max_width, int max
   if (hipHostMalloc((void**)&(ptr), std::max<size_t>((bytes), 16), hipHostMallocDefault) != hipSuccess) return fail(ORBX_E_HIP)
   ALLOC(ctx->dPyr, ctx->pyrBytes);
   ALLOC(ctx->dCand, ctx->candEntries * 4);
-  ALLOC(ctx->dCandCount, (B * nl + 1) * sizeof(int));
-  ctx->dOverflow = ctx->dCandCount + B * nl;
+  ALLOC(ctx->dCandCount, (B * nl + 2) * sizeof(int));
+  ctx->dOverflow = ctx->dCandCount + B * nl;  // [0] candidate overflow, [1] selection error
   ALLOC(ctx->dTab, ctx->tabEntries * sizeof(ResizeTab));
   ALLOC(ctx->dSel, B * cap * sizeof(SelKp));
   ALLOC(ctx->dNsel, B * sizeof(int));
+  ALLOC(ctx->dSelStage, B * cap * sizeof(SelKp));
+  ALLOC(ctx->dNselLevel, B * nl * sizeof(int));
+  {
+    OctLaunch oct;
+    ctx->octScratchBytes = buildOctLaunch(ctx, g, &oct) + 4096;
+    ctx->maxQuota = 0;
+    for (int q : ctx->quota) ctx->maxQuota = std::max(ctx->maxQuota, q);
+  }
+  ALLOC(ctx->dOctScratch, ctx->octScratchBytes);
   ALLOC(ctx->dIn, ctx->inBytes);
   ALLOC(ctx->dKps, B * cap * sizeof(orbx_keypoint));
   ALLOC(ctx->dDesc, B * cap * 32);
-  ALLOCH(ctx->hCandCount, (B * nl + 1) * sizeof(int));
-  ALLOCH(ctx->hCand, ctx->candEntries * 4);
-  ALLOCH(ctx->hSel, B * cap * sizeof(SelKp));
   ALLOCH(ctx->hNsel, B * sizeof(int));
+  ALLOCH(ctx->hFlags, 2 * sizeof(int));
 #undef ALLOC
 #undef ALLOCH
   for (int s2 = 0; s2 < ORBX_STAGE_COUNT; s2++)
     for (int k = 0; k < 2; k++)
       if (hipEventCreate(&ctx->ev[s2][k]) != hipSuccess) return fail(ORBX_E_HIP);
-  int nthreads = (int)std::thread::hardware_concurrency();
-  if (const char* e = getenv("ORBX_HOST_THREADS")) nthreads = atoi(e);
-  nthreads = std::min(std::max(nthreads, 1), 64);
-  ctx->pool = new ThreadPool(std::min(nthreads, max_batch) - 1);
   *out = ctx;
   return ORBX_OK;
 }
@@ -599,12 +511,12 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->st) (void)hipStreamSynchronize(ctx->st);
-  delete ctx->pool;
-  void* dev[] = {ctx->dPyr, ctx->dCand, ctx->dCandCount, ctx->dTab, ctx->dSel, ctx->dNsel, ctx->dIn, ctx->dKps, ctx->dDesc,
-                 ctx->dMatchScratch, ctx->dPairs, ctx->dMk, ctx->dMd, ctx->dMi};
+  void* dev[] = {ctx->dPyr, ctx->dCand, ctx->dCandCount, ctx->dTab, ctx->dSel, ctx->dNsel, ctx->dSelStage, ctx->dNselLevel,
+                 ctx->dOctScratch, ctx->dIn, ctx->dKps, ctx->dDesc, ctx->dMatchScratch, ctx->dPairs, ctx->dMk, ctx->dMd,
+                 ctx->dMi};
   for (void* p : dev)
     if (p) (void)hipFree(p);
-  void* host[] = {ctx->hCandCount, ctx->hCand, ctx->hSel, ctx->hNsel};
+  void* host[] = {ctx->hNsel, ctx->hFlags};
   for (void* p : host)
     if (p) (void)hipHostFree(p);
   for (int s = 0; s < ORBX_STAGE_COUNT; s++)
@@ -862,7 +774,8 @@ int orbx_debug_candidates(orbx_ctx* ctx, int frame, int level, float* xyr, int c
   if (!ctx || frame < 0 || frame >= ctx->lastB || level < 0 || level >= ctx->p.nlevels) return ORBX_E_BADARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
   const LevelGeom& L = ctx->g.L[level];
-  const int cnt = ctx->lastCandCount[(size_t)frame * ctx->p.nlevels + level];
+  int cnt = 0;
+  HIPCHK(hipMemcpy(&cnt, ctx->dCandCount + (size_t)frame * ctx->p.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
   std::vector<uint32_t> e(std::max(cnt, 1));
   if (cnt > 0) HIPCHK(hipMemcpy(e.data(), ctx->dCand + L.candOff + (int64_t)frame * L.candCap, (size_t)cnt * 4, hipMemcpyDeviceToHost));
   std::vector<uint64_t> keyed(cnt);
@@ -890,6 +803,98 @@ int orbx_debug_distribute(const float* xyr, int n, int min_x, int max_x, int min
     out_xyr[3 * i + 2] = c[chosen[i]].response;
   }
   return (int)chosen.size();
+}
+
+}  // extern "C"
+
+// ---- device-side test hooks for the selection stage ------------------------------------------------------------
+namespace orbx {
+hipError_t launch_debug_sort(hipStream_t st, int* triples, int n);
+}
+
+extern "C" {
+
+// DistributeOctTree on the device for caller-supplied candidates given in row-major (y, x) order, integer coordinates
+// relative to (min_x, min_y) in [0, 4095], integer responses in [0, 255].  variant 0 = LDS kernel (falls through to
+// the global-scratch kernel when it cannot take the unit), 1 = global-scratch kernel only.
+int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min_x, int max_x, int min_y, int max_y,
+                                 int n_features, int variant, float* out_xyr, int cap) {
+  if (!ctx || n < 0 || (n > 0 && !xyr) || max_x <= min_x || max_y <= min_y || n_features < 0 || n > ORBX_OCT_MAX_CAND)
+    return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  OctLaunch P{};
+  P.nlevels = 1;
+  P.selStride = std::max(n_features, 1);
+  OctLevel& O = P.lev[0];
+  O.width = max_x - min_x;
+  O.height = max_y - min_y;
+  O.nIni = (int)std::round((float)O.width / (float)O.height);
+  if (O.nIni < 1 || O.nIni > 255) return ORBX_E_TOOSMALL;
+  O.hX = (float)O.width / (float)O.nIni;
+  O.wCell = O.hCell = 1 << 20;  // one "cell": candidate order = row-major
+  O.nCols = 1;
+  O.quota = n_features;
+  P.candCap[0] = std::max(n, 1);
+  P.scrNMax[0] = std::max(n, 1);
+  P.scrStride[0] = (int64_t)octScratchBytes(P.scrNMax[0], n_features);
+  std::vector<uint32_t> packed(std::max(n, 1));
+  for (int i = 0; i < n; i++) {
+    const int x = (int)xyr[3 * i], y = (int)xyr[3 * i + 1], r = (int)xyr[3 * i + 2];
+    if (x < 0 || x > 4095 || y < 0 || y > 4095 || r < 0 || r > 255) return ORBX_E_BADARG;
+    packed[i] = packCand(x, y, r);
+  }
+  uint32_t* dC = nullptr;
+  int* dI = nullptr;
+  SelKp* dS = nullptr;
+  uint8_t* dScr = nullptr;
+  std::vector<SelKp> sel(std::max(n_features, 1));
+  int res[2] = {0, 0};
+  auto body = [&]() -> int {
+    HIPCHK(hipMalloc((void**)&dC, packed.size() * 4));
+    HIPCHK(hipMalloc((void**)&dI, 2 * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&dS, sel.size() * sizeof(SelKp)));
+    HIPCHK(hipMalloc((void**)&dScr, (size_t)P.scrStride[0]));
+    HIPCHK(hipMemcpyAsync(dC, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->st));
+    int hi[2] = {n, -7};
+    HIPCHK(hipMemcpyAsync(dI, hi, sizeof hi, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(launch_octree(ctx->st, 1, dC, dI, P, dS, dI + 1, dScr, variant == 0 ? n_features : (1 << 30)));
+    HIPCHK(hipMemcpyAsync(res, dI, sizeof res, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(sel.data(), dS, sel.size() * sizeof(SelKp), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    return ORBX_OK;
+  };
+  const int rc = body();
+  if (dC) (void)hipFree(dC);
+  if (dI) (void)hipFree(dI);
+  if (dS) (void)hipFree(dS);
+  if (dScr) (void)hipFree(dScr);
+  if (rc != ORBX_OK) return rc;
+  if (res[1] < 0) return ORBX_E_CAPACITY;
+  for (int i = 0; i < res[1] && i < cap; i++) {
+    out_xyr[3 * i] = (float)(sel[i].x - ORBX_MIN_BORDER);
+    out_xyr[3 * i + 1] = (float)(sel[i].y - ORBX_MIN_BORDER);
+    out_xyr[3 * i + 2] = (float)sel[i].response;
+  }
+  return res[1];
+}
+
+// runs the device replay of libstdc++'s std::sort on n (count, ulx, id) triples in place
+int orbx_debug_std_sort(orbx_ctx* ctx, int32_t* triples, int n) {
+  if (!ctx || n < 0 || (n > 0 && !triples)) return ORBX_E_BADARG;
+  if (n == 0) return ORBX_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  int* d = nullptr;
+  auto body = [&]() -> int {
+    HIPCHK(hipMalloc((void**)&d, (size_t)n * 3 * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(d, triples, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(launch_debug_sort(ctx->st, d, n));
+    HIPCHK(hipMemcpyAsync(triples, d, (size_t)n * 3 * sizeof(int), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    return ORBX_OK;
+  };
+  const int rc = body();
+  if (d) (void)hipFree(d);
+  return rc;
 }
 
 }  // extern "C"

@@ -52,7 +52,28 @@ struct SelKp {
   uint16_t pad;
 };
 
-// launch wrappers (orbx_kernels.hip)
+// quadtree selection stage (orbx_octree_kernel.hip): per-level constants of DistributeOctTree
+struct OctLevel {
+  int32_t width, height;   // maxBorder - minBorder
+  int32_t nIni;            // cpp:706
+  float hX;                // cpp:709
+  int32_t wCell, hCell, nCols;  // FAST cell grid: defines the reference's candidate order
+  int32_t quota;
+};
+
+struct OctLaunch {
+  OctLevel lev[ORBX_MAX_LEVELS];
+  int64_t candOff[ORBX_MAX_LEVELS];
+  int64_t scrOff[ORBX_MAX_LEVELS];     // global-scratch placement (k_octree_global)
+  int64_t scrStride[ORBX_MAX_LEVELS];
+  int32_t candCap[ORBX_MAX_LEVELS];
+  int32_t selOff[ORBX_MAX_LEVELS];     // offset of the level inside one frame's SelKp staging area
+  int32_t scrNMax[ORBX_MAX_LEVELS];
+  int32_t nlevels, selStride;          // SelKp staging entries per frame
+};
+
+#define ORBX_OCT_MAX_CAND ((1 << 19) - 1)  // candidates per (frame, level) the selection stage can index
+
 struct ResizeTab {
   int32_t ofs;    // source index
   int32_t coef;   // c0 | c1 << 16 (Q11)

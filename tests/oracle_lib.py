@@ -246,3 +246,13 @@ def bench_pairs(params, imgs: np.ndarray, window=100, nnratio=0.9, nthreads=1, r
     sec = lib().orbo_bench_pairs(params[0], params[1], params[2], params[3], params[4], _p(imgs), n, w, h, window, nnratio,
                                  nthreads, reps, ctypes.byref(frames), ctypes.byref(chk))
     return float(sec), int(frames.value), int(chk.value)
+
+
+def std_sort_sized(triples: np.ndarray) -> np.ndarray:
+    """libstdc++ std::sort with the reference's compareNodes on (count, UL.x, id) triples (cpp:684-696, 912)."""
+    t = np.ascontiguousarray(triples, np.int32).reshape(-1, 3).copy()
+    L = lib()
+    L.orbo_std_sort_sized.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.orbo_std_sort_sized.restype = None
+    L.orbo_std_sort_sized(_p(t), len(t))
+    return t

@@ -265,3 +265,75 @@ def test_full_size_configs(orbx, oracle, cfg):
     dy = res[1][1]["y"][m12[ok]] - res[0][1]["y"][ok]
     assert ok.sum() > 100 and abs(np.median(dx) - 7) <= 1 and abs(np.median(dy) - 4) <= 1  # B is A shifted by (+7, +4)
     e.close()
+
+
+def _rowmajor_cands(rng, W, H, n):
+    pos = np.sort(rng.choice(W * H, size=n, replace=False))
+    r = rng.integers(1, int(rng.integers(2, 200)), size=n)
+    return np.stack([pos % W, pos // W, r], 1).astype(np.float32)
+
+
+def test_device_std_sort_replay(orbx, ext640, oracle):
+    """The one-lane replay of libstdc++'s introsort gives the library's exact permutation, ties included."""
+    rng = np.random.default_rng(21)
+    cases = []
+    for n in (1, 2, 3, 15, 16, 17, 18, 33, 100, 257, 1000, 2500):
+        for hi in (2, 5, 60):
+            t = np.stack([rng.integers(2, 2 + hi, n), rng.integers(0, 40, n) * 16, np.arange(n)], 1)
+            cases.append(t)
+    cases.append(np.stack([np.arange(3000), np.zeros(3000, int), np.arange(3000)], 1))         # sorted
+    cases.append(np.stack([np.arange(3000)[::-1], np.zeros(3000, int), np.arange(3000)], 1))   # reversed
+    cases.append(np.stack([np.full(3000, 7), np.full(3000, 3), np.arange(3000)], 1))           # all equal
+    # median-of-3 killer (drives introsort into its heapsort fallback)
+    n = 4096
+    k = n // 2
+    killer = np.zeros(n, int)
+    for i in range(1, k + 1):
+        if i & 1:
+            killer[i - 1] = i
+            killer[i] = k + i
+        killer[k + i - 1] = 2 * i
+    cases.append(np.stack([killer, np.zeros(n, int), np.arange(n)], 1))
+    for t in cases:
+        got = ext640.debug_std_sort(t)
+        exp = oracle.std_sort_sized(t)
+        assert np.array_equal(got, exp), len(t)
+
+
+def test_device_octree_random(orbx, ext640, oracle):
+    """Device DistributeOctTree (both kernels) vs the oracle on random candidate sets: same keys, same list order."""
+    rng = np.random.default_rng(5)
+    done = 0
+    for it in range(160):
+        W, H = int(rng.integers(40, 900)), int(rng.integers(40, 700))
+        if round(float(np.float32(W) / np.float32(H))) < 1:
+            continue
+        n = int(rng.integers(0, min(W * H // 4, 1800 if it % 3 else 6000)))
+        xyr = _rowmajor_cands(rng, W, H, n)
+        N = int(rng.integers(0, max(2, 2 * n // 3 + 2)))
+        exp = oracle.distribute(xyr, 16, 16 + W, 16, 16 + H, N)[:N]  # the pipeline truncates to the quota (cpp:1159-1161)
+        for variant in (0, 1):
+            got = ext640.debug_distribute_device(xyr, 16, 16 + W, 16, 16 + H, N, variant)
+            assert got.shape == exp.shape and np.array_equal(got, exp), (it, variant, W, H, n, N)
+        done += 1
+    assert done > 100
+
+
+@pytest.mark.parametrize("shape", [(608, 448, 217), (720, 448, 434), (1888, 1048, 869), (3808, 2128, 1737), (147, 102, 60)])
+def test_device_octree_level_geometries(orbx, ext640, oracle, shape):
+    W, H, N = shape
+    rng = np.random.default_rng(W)
+    for dens in (0.002, 0.01, 0.05):
+        n = int(W * H * dens)
+        xyr = _rowmajor_cands(rng, W, H, n)
+        xyr[:, 2] = rng.integers(6, 12, n)  # heavy response ties
+        half = n // 2  # cluster half of the points
+        xyr[:half, 0] = np.clip(np.round(W * 0.3 + rng.normal(0, W * 0.05, half)), 0, W - 1)
+        xyr[:half, 1] = np.clip(np.round(H * 0.6 + rng.normal(0, H * 0.05, half)), 0, H - 1)
+        key = xyr[:, 1] * 4096 + xyr[:, 0]
+        _, uniq = np.unique(key, return_index=True)
+        xyr = xyr[uniq]  # unique, and sorted row-major by construction of np.unique
+        exp = oracle.distribute(xyr, 16, 16 + W, 16, 16 + H, N)[:N]
+        for variant in (0, 1):
+            got = ext640.debug_distribute_device(xyr, 16, 16 + W, 16, 16 + H, N, variant)
+            assert np.array_equal(got, exp), (dens, variant)
