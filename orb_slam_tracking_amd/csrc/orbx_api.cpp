@@ -809,7 +809,7 @@ int orbx_debug_distribute(const float* xyr, int n, int min_x, int max_x, int min
 
 // ---- device-side test hooks for the selection stage ------------------------------------------------------------
 namespace orbx {
-hipError_t launch_debug_sort(hipStream_t st, int* triples, int n);
+hipError_t launch_debug_sort(hipStream_t st, int* triples, int n, unsigned long long* a, unsigned long long* b);
 }
 
 extern "C" {
@@ -884,16 +884,19 @@ int orbx_debug_std_sort(orbx_ctx* ctx, int32_t* triples, int n) {
   if (n == 0) return ORBX_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
   int* d = nullptr;
+  unsigned long long* w = nullptr;
   auto body = [&]() -> int {
     HIPCHK(hipMalloc((void**)&d, (size_t)n * 3 * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&w, (size_t)n * 2 * sizeof(unsigned long long)));
     HIPCHK(hipMemcpyAsync(d, triples, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(launch_debug_sort(ctx->st, d, n));
+    HIPCHK(launch_debug_sort(ctx->st, d, n, w, w + n));
     HIPCHK(hipMemcpyAsync(triples, d, (size_t)n * 3 * sizeof(int), hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));
     return ORBX_OK;
   };
   const int rc = body();
   if (d) (void)hipFree(d);
+  if (w) (void)hipFree(w);
   return rc;
 }
 

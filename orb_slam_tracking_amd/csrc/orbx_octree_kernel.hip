@@ -2,12 +2,17 @@
 // (reference: ORBextractor::DistributeOctTree, Features/ORBextractor.cpp:698-1011; DivideNode cpp:617-676;
 //  compareNodes cpp:684-696; truncation to the level quota cpp:1159-1161; coordinate fix-up cpp:1165-1179).
 //
-// One workgroup per (frame, pyramid level).  Same array formulation as the host implementation in orbx_octree.cpp:
+// One workgroup per (frame, pyramid level).  Same array formulation as the host prototype in orbx_octree.cpp:
 // every candidate gets a path code (root index + one quadrant digit per depth); with the codes sorted, every tree
 // node is a contiguous range and the reference's std::list bookkeeping becomes arithmetic on common-prefix lengths.
-// The partial last pass ("split the biggest nodes first until N nodes exist") needs the exact permutation produced by
-// libstdc++'s UNSTABLE std::sort on (count, UL.x); it is replayed by one lane with a literal re-implementation of
-// libstdc++'s introsort (median-of-3 quicksort, heapsort fallback, final insertion sort, threshold 16).
+//
+// The partial last pass ("split the biggest nodes first until N nodes exist", cpp:897-965) needs the exact
+// permutation libstdc++'s UNSTABLE std::sort produces on (count, UL.x).  libstdc++'s sort is
+//   __introsort_loop (median-of-3 quicksort partitions down to ranges of <= 16, heapsort on depth exhaustion)
+//   followed by __final_insertion_sort, and an insertion sort is a STABLE sort of whatever it is given.
+// So only the partition phase is replayed literally (one lane, O(E log(E/16)) steps); the final insertion sort is
+// computed as a parallel stable rank sort.  Everything else (node creation, cut point, list order) is parallel.
+//
 // The candidates arrive unordered from k_fast; the reference's candidate order (cell row, cell col, y, x) only
 // matters as the tie-breaker "first of the highest responses", so it is carried as an order key, never materialised.
 #include <hip/hip_runtime.h>
@@ -25,18 +30,19 @@ namespace orbx {
 typedef unsigned long long u64;
 
 struct OctScratch {
-  u64* keys;        // [nPad]   (code << 24) | candidate index, sorted ascending
-  u64* nodes;       // [mPad]   (17 - blockDepth) << 59 | orderKey << 19 | lo, sorted ascending = std::list order
-  uint8_t* div;     // [n + 1]  divergence depth between sorted neighbours (div[0] = div[n] = 255 -> "separated")
-  uint8_t* alone;   // [n]
-  uint32_t* hiOf;   // [n]      end of the node that starts at sorted position lo
-  int* nodeLo;      // [mCap + fCap]  node records: list nodes first, then the nodes pushed during the partial pass
+  u64* keys;          // [nPad]   (code << 24) | candidate index, sorted ascending
+  u64* nodes;         // [mPad]   (17 - blockDepth) << 59 | orderKey << 19 | lo, sorted ascending = std::list order
+  uint8_t* div;       // [n + 1]  divergence depth between sorted neighbours (255 at both ends = "separated")
+  uint8_t* alone;     // [n]      first depth at which a key is the only key of its node
+  uint32_t* hiOf;     // [n]      end of the node that starts at sorted position lo
+  int* nodeLo;        // [mCap + fCap]  node records: list nodes first, then the nodes pushed during the partial pass
   int* nodeHi;
   uint8_t* nodeDepth;
   uint8_t* nodeAlive;
-  int* sized;       // [3 * qCap]  (count, ulx, node) triples for the emulated std::sort
-  int* pending;     // [2 * qCap]
-  int* pos;         // [mCap + fCap] output position of every node
+  u64* sized;         // [2 * qCap]  count << 40 | UL.x << 20 | node, two buffers (partitioned / stably sorted)
+  int* pending;       // [2 * qCap]  two buffers
+  int* childCnt;      // [qCap]      per sorted entry: children | multi-key children << 8
+  const uint32_t* cand;  // packed candidates (LDS copy or global)
 };
 
 __device__ __forceinline__ int divDepth(u64 a, u64 b) {  // first depth at which two path codes differ
@@ -61,150 +67,114 @@ __device__ __forceinline__ void bitonicSort(u64* a, int nPow2, int tid) {
     }
 }
 
-// ---- literal replay of libstdc++'s std::sort (bits/stl_algo.h) on (count, ulx, node) triples -------------------
-struct SizedRef {
-  int* p;  // triples
-  __device__ __forceinline__ bool less(int i, int j) const {  // compareNodes
-    const int ci = p[3 * i], cj = p[3 * j];
-    if (ci < cj) return true;
-    if (ci > cj) return false;
-    return p[3 * i + 1] < p[3 * j + 1];
+// exclusive prefix sum of one int per thread over the workgroup; *total = sum.  `ws` = 4 ints of LDS.
+__device__ __forceinline__ int blockScanExcl(int v, int tid, int* ws, int* total) {
+  const int lane = tid & 63, wave = tid >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
   }
-  __device__ __forceinline__ void swap(int i, int j) const {
-    for (int k = 0; k < 3; k++) { const int t = p[3 * i + k]; p[3 * i + k] = p[3 * j + k]; p[3 * j + k] = t; }
+  __syncthreads();  // ws may still be read from a previous call
+  if (lane == 63) ws[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < OCT_T / 64; w++) {
+    const int s = ws[w];
+    if (w < wave) base += s;
+    tot += s;
   }
-  __device__ __forceinline__ void move(int dst, int src) const {
-    p[3 * dst] = p[3 * src]; p[3 * dst + 1] = p[3 * src + 1]; p[3 * dst + 2] = p[3 * src + 2];
-  }
-};
-struct SizedVal {
-  int c, u, n;
-};
-__device__ __forceinline__ bool valLess(const SizedVal& a, const int* p, int j) {  // comp(val, *j)
-  if (a.c < p[3 * j]) return true;
-  if (a.c > p[3 * j]) return false;
-  return a.u < p[3 * j + 1];
-}
-__device__ __forceinline__ bool lessVal(const int* p, int i, const SizedVal& b) {  // comp(*i, val)
-  if (p[3 * i] < b.c) return true;
-  if (p[3 * i] > b.c) return false;
-  return p[3 * i + 1] < b.u;
+  *total = tot;
+  return base + inc - v;
 }
 
-__device__ void stdAdjustHeap(int* p, int first, int holeIndex, int len, SizedVal value) {
-  SizedRef r{p};
+// ---- literal replay of the PARTITION PHASE of libstdc++'s std::sort (bits/stl_algo.h: __introsort_loop) on packed
+//      keys; the comparator (compareNodes: count, then UL.x) is "a >> 20 < b >> 20" -----------------------------------
+#define SLESS(a, b) (((a) >> 20) < ((b) >> 20))
+
+__device__ void stdAdjustHeap(u64* p, int first, int holeIndex, int len, u64 value) {
   const int topIndex = holeIndex;
   int secondChild = holeIndex;
   while (secondChild < (len - 1) / 2) {
     secondChild = 2 * (secondChild + 1);
-    if (r.less(first + secondChild, first + (secondChild - 1))) secondChild--;
-    r.move(first + holeIndex, first + secondChild);
+    if (SLESS(p[first + secondChild], p[first + (secondChild - 1)])) secondChild--;
+    p[first + holeIndex] = p[first + secondChild];
     holeIndex = secondChild;
   }
   if ((len & 1) == 0 && secondChild == (len - 2) / 2) {
     secondChild = 2 * (secondChild + 1);
-    r.move(first + holeIndex, first + (secondChild - 1));
+    p[first + holeIndex] = p[first + (secondChild - 1)];
     holeIndex = secondChild - 1;
   }
-  // __push_heap
-  int parent = (holeIndex - 1) / 2;
-  while (holeIndex > topIndex && lessVal(p, first + parent, value)) {
-    r.move(first + holeIndex, first + parent);
+  int parent = (holeIndex - 1) / 2;  // __push_heap
+  while (holeIndex > topIndex && SLESS(p[first + parent], value)) {
+    p[first + holeIndex] = p[first + parent];
     holeIndex = parent;
     parent = (holeIndex - 1) / 2;
   }
-  p[3 * (first + holeIndex)] = value.c; p[3 * (first + holeIndex) + 1] = value.u; p[3 * (first + holeIndex) + 2] = value.n;
+  p[first + holeIndex] = value;
 }
 
-__device__ void stdHeapSortRange(int* p, int first, int last) {  // __partial_sort(first, last, last)
+__device__ void stdHeapSortRange(u64* p, int first, int last) {  // __partial_sort(first, last, last)
   const int len = last - first;
   if (len >= 2) {  // __make_heap
     int parent = (len - 2) / 2;
     for (;;) {
-      SizedVal v{p[3 * (first + parent)], p[3 * (first + parent) + 1], p[3 * (first + parent) + 2]};
-      stdAdjustHeap(p, first, parent, len, v);
+      stdAdjustHeap(p, first, parent, len, p[first + parent]);
       if (parent == 0) break;
       parent--;
     }
   }
-  // __heap_select's loop over [middle, last) is empty; __sort_heap:
-  int l = last;
+  int l = last;  // __sort_heap
   while (l - first > 1) {
     --l;
-    SizedVal v{p[3 * l], p[3 * l + 1], p[3 * l + 2]};  // __pop_heap(first, l, l)
-    SizedRef{p}.move(l, first);
+    const u64 v = p[l];  // __pop_heap(first, l, l)
+    p[l] = p[first];
     stdAdjustHeap(p, first, 0, l - first, v);
   }
 }
 
-__device__ void stdSortSized(int* p, int n) {
-  if (n <= 1) return;
-  SizedRef r{p};
-  // __introsort_loop with an explicit stack of (first, last, depth) for the recursive right halves
+__device__ void stdIntrosortLoop(u64* p, int n) {
+  if (n <= 16) return;
   int stackF[64], stackL[64], stackD[64];
-  int sp = 0;
-  int first = 0, last = n;
+  int sp = 0, first = 0, last = n;
   int depth = 2 * (31 - __builtin_clz((unsigned)n));
   for (;;) {
     while (last - first > 16) {
       if (depth == 0) { stdHeapSortRange(p, first, last); break; }
       --depth;
-      // __unguarded_partition_pivot
       const int mid = first + (last - first) / 2;
       {  // __move_median_to_first(first, first + 1, mid, last - 1)
-        const int a = first + 1, b = mid, c = last - 1;
-        if (r.less(a, b)) {
-          if (r.less(b, c)) r.swap(first, b);
-          else if (r.less(a, c)) r.swap(first, c);
-          else r.swap(first, a);
-        } else if (r.less(a, c)) r.swap(first, a);
-        else if (r.less(b, c)) r.swap(first, c);
-        else r.swap(first, b);
+        const int ia = first + 1, ib = mid, ic = last - 1;
+        const u64 a = p[ia], b = p[ib], c = p[ic], f = p[first];
+        int sel;
+        if (SLESS(a, b)) sel = SLESS(b, c) ? ib : (SLESS(a, c) ? ic : ia);
+        else sel = SLESS(a, c) ? ia : (SLESS(b, c) ? ic : ib);
+        p[first] = p[sel];
+        p[sel] = f;
       }
+      const u64 pivot = p[first];
       int lo = first + 1, hi = last;
       for (;;) {  // __unguarded_partition(first + 1, last, first)
-        while (r.less(lo, first)) ++lo;
+        u64 vlo = p[lo];
+        while (SLESS(vlo, pivot)) vlo = p[++lo];
         --hi;
-        while (r.less(first, hi)) --hi;
+        u64 vhi = p[hi];
+        while (SLESS(pivot, vhi)) vhi = p[--hi];
         if (!(lo < hi)) break;
-        r.swap(lo, hi);
+        p[lo] = vhi;
+        p[hi] = vlo;
         ++lo;
       }
-      const int cut = lo;
-      // recurse on [cut, last) first (as the library does), then continue with [first, cut)
-      stackF[sp] = first; stackL[sp] = cut; stackD[sp] = depth; sp++;
-      first = cut;
+      // the library recurses on [cut, last) and loops on [first, cut): disjoint ranges, same depth budget
+      stackF[sp] = first; stackL[sp] = lo; stackD[sp] = depth; sp++;
+      first = lo;
     }
     if (sp == 0) break;
     --sp;
     first = stackF[sp]; last = stackL[sp]; depth = stackD[sp];
-  }
-  // __final_insertion_sort
-  auto insertionSort = [&](int f, int l) {
-    if (f == l) return;
-    for (int i = f + 1; i != l; ++i) {
-      if (r.less(i, f)) {
-        SizedVal v{p[3 * i], p[3 * i + 1], p[3 * i + 2]};
-        for (int k = i; k > f; --k) r.move(k, k - 1);  // move_backward
-        p[3 * f] = v.c; p[3 * f + 1] = v.u; p[3 * f + 2] = v.n;
-      } else {  // __unguarded_linear_insert
-        SizedVal v{p[3 * i], p[3 * i + 1], p[3 * i + 2]};
-        int lastPos = i, next = i - 1;
-        while (valLess(v, p, next)) { r.move(lastPos, next); lastPos = next; --next; }
-        p[3 * lastPos] = v.c; p[3 * lastPos + 1] = v.u; p[3 * lastPos + 2] = v.n;
-      }
-    }
-  };
-  if (n > 16) {
-    insertionSort(0, 16);
-    for (int i = 16; i != n; ++i) {  // __unguarded_insertion_sort
-      SizedVal v{p[3 * i], p[3 * i + 1], p[3 * i + 2]};
-      int lastPos = i, next = i - 1;
-      while (valLess(v, p, next)) { r.move(lastPos, next); lastPos = next; --next; }
-      p[3 * lastPos] = v.c; p[3 * lastPos + 1] = v.u; p[3 * lastPos + 2] = v.n;
-    }
-  } else {
-    insertionSort(0, n);
   }
 }
 
@@ -222,13 +192,13 @@ __device__ __forceinline__ void rootRect(const OctLevel& L, int root, int& ulx, 
   bry = L.height;
 }
 
-// The whole selection for one (frame, level).  cand: n unordered packed candidates.  Writes min(#nodes, quota)
-// SelKp records (list order) to `out` and returns that count in *nOut (by thread 0).
-__device__ void octreeSelect(const OctScratch S, const uint32_t* __restrict__ cand, int n, const OctLevel L, int level,
-                             SelKp* __restrict__ out, int* __restrict__ nOut, int mCap, int fCap, int qCap) {
+// The whole selection for one (frame, level).  S.cand: n unordered packed candidates.  Writes min(#nodes, quota) SelKp
+// records (list order) to `out` and the count to *nOut (-2: scratch too small for this unit).
+__device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int level, SelKp* __restrict__ out,
+                             int* __restrict__ nOut, int mCap, int fCap, int qCap) {
   __shared__ int cntDiv[OCT_DEPTH + 2], cntAlone[OCT_DEPTH + 2];
-  __shared__ int sK, sPhase2, sM, sFront, sTotal;
-  __shared__ int partial[OCT_T];
+  __shared__ int sK, sPhase2, sM, sFront, sSize, sCut, sFinish;
+  __shared__ int ws[OCT_T / 64];
   const int tid = threadIdx.x;
   const int N = L.quota;
   if (n <= 0 || N <= 0) {  // nothing to select (an empty quota truncates everything, cpp:1159-1161)
@@ -238,18 +208,19 @@ __device__ void octreeSelect(const OctScratch S, const uint32_t* __restrict__ ca
   int nPad = 1;
   while (nPad < n) nPad <<= 1;
 
-  // ---- 1. path codes --------------------------------------------------------------------------------------
+  // ---- 1. path codes -----------------------------------------------------------------------------------------
   for (int i = tid; i < nPad; i += OCT_T) {
     u64 key = ~0ull;
     if (i < n) {
-      const uint32_t e = cand[i];
+      const uint32_t e = S.cand[i];
       const float x = (float)(e & 0xfff), y = (float)((e >> 12) & 0xfff);
       int root = (int)(x / L.hX);  // cpp:747
       root = min(max(root, 0), L.nIni - 1);
       int ulx, uly, brx, bry;
       rootRect(L, root, ulx, uly, brx, bry);
       u64 code = (u64)root;
-      for (int d = 0; d < OCT_DEPTH; d++) {  // DivideNode, cpp:617-676
+#pragma unroll 4
+      for (int d = 0; d < OCT_DEPTH; d++) {  // DivideNode, cpp:617-676: half = ceil(extent / 2)
         const int midX = ulx + ((brx - ulx + 1) >> 1), midY = uly + ((bry - uly + 1) >> 1);
         const int qx = !(x < (float)midX), qy = !(y < (float)midY);
         if (qx) ulx = midX; else brx = midX;
@@ -264,7 +235,7 @@ __device__ void octreeSelect(const OctScratch S, const uint32_t* __restrict__ ca
   __syncthreads();
   bitonicSort(S.keys, nPad, tid);
 
-  // ---- 2. divergence depths, S_d, singles_d ---------------------------------------------------------------
+  // ---- 2. divergence depths, S_d (distinct depth-d prefixes), singles_d -----------------------------------------
   for (int i = tid; i <= n; i += OCT_T) {
     int d = 255;
     if (i > 0 && i < n) {
@@ -281,7 +252,7 @@ __device__ void octreeSelect(const OctScratch S, const uint32_t* __restrict__ ca
     atomicAdd(&cntAlone[a], 1);
   }
   __syncthreads();
-  // ---- 3. replay the pass loop on sizes only (cpp:781-895) ----------------------------------------------
+  // ---- 3. replay the pass loop on sizes only (cpp:781-895) ------------------------------------------------------
   if (tid == 0) {
     int Sd[OCT_DEPTH + 2], sg[OCT_DEPTH + 2];
     int accD = 0, accA = 0;
@@ -313,28 +284,22 @@ __device__ void octreeSelect(const OctScratch S, const uint32_t* __restrict__ ca
     if (tid == 0) *nOut = -2;
     return;
   }
-  // ---- 4. node list in std::list order ---------------------------------------------------------------------
+  // ---- 4. node list in std::list order ---------------------------------------------------------------------------
   // node starts: a leaf key (alone < k) or the first key of a depth-k group
   {
     const int chunk = (n + OCT_T - 1) / OCT_T;
-    const int b = tid * chunk, e = min(b + chunk, n);
+    const int b = min(tid * chunk, n), e = min(b + chunk, n);
     int c = 0;
     for (int i = b; i < e; i++) c += (S.alone[i] < k) || (S.div[i] == 255 || (int)S.div[i] <= k);
-    partial[tid] = c;
-    __syncthreads();
-    if (tid == 0) {
-      int acc = 0;
-      for (int i = 0; i < OCT_T; i++) { const int v = partial[i]; partial[i] = acc; acc += v; }
-    }
-    __syncthreads();
-    int m = partial[tid];
+    int tot;
+    int m = blockScanExcl(c, tid, ws, &tot);
     for (int i = b; i < e; i++) {
       const bool leaf = S.alone[i] < k;
       if (leaf || (S.div[i] == 255 || (int)S.div[i] <= k)) {
         const int j = leaf ? (int)S.alone[i] : k;  // block depth
         const u64 code = S.keys[i] >> 24;
         // order key: first j digits, digit m flipped when (j - m) is even, root flipped when j is odd
-        u64 prefix = code >> (2 * (OCT_DEPTH - j));
+        const u64 prefix = code >> (2 * (OCT_DEPTH - j));
         u64 flip = 0;
         for (int mm = j; mm >= 1; mm -= 2) flip |= (u64)3 << (2 * (j - mm));
         u64 okey = prefix ^ flip;
@@ -345,17 +310,16 @@ __device__ void octreeSelect(const OctScratch S, const uint32_t* __restrict__ ca
         S.nodes[m++] = ((u64)(OCT_DEPTH + 1 - j) << 59) | (okey << 19) | (u64)i;
       }
     }
-    // hiOf[start] = next start
     __syncthreads();
   }
   int mPad = 1;
   while (mPad < M) mPad <<= 1;
-  // ends of the nodes, found from the position-ordered list before it is re-sorted
-  for (int m = tid; m < M; m += OCT_T) {
+  for (int m = tid; m < M; m += OCT_T) {  // ends of the nodes, from the position-ordered list before it is re-sorted
     const int lo = (int)(S.nodes[m] & 0x7ffff);
     const int hi = (m + 1 < M) ? (int)(S.nodes[m + 1] & 0x7ffff) : n;
     S.hiOf[lo] = (uint32_t)hi;
   }
+  __syncthreads();
   for (int m = M + tid; m < mPad; m += OCT_T) S.nodes[m] = ~0ull;
   __syncthreads();
   bitonicSort(S.nodes, mPad, tid);
@@ -369,21 +333,41 @@ __device__ void octreeSelect(const OctScratch S, const uint32_t* __restrict__ ca
   }
   __syncthreads();
 
-  // ---- 5. partial pass(es), cpp:897-965: replayed by one lane ----------------------------------------------
-  if (sPhase2 && tid == 0) {
-    int size = M;
-    int nPend = 0;
-    for (int i = M - 1; i >= 0; i--)  // creation order = reverse of the depth-k block order
-      if (S.nodeDepth[i] == k && S.nodeHi[i] - S.nodeLo[i] > 1) S.pending[nPend++] = i;  // < N <= qCap entries
+  // ---- 5. partial pass(es), cpp:897-965 ---------------------------------------------------------------------------
+  if (sPhase2) {
+    int* pendA = S.pending;
+    int* pendB = S.pending + qCap;
+    u64* sizedA = S.sized;
+    u64* sizedB = S.sized + qCap;
+    // pending = multi-key depth-k nodes in creation order = reverse of the depth-k block order
+    int nPend;
+    {
+      const int chunk = (M + OCT_T - 1) / OCT_T;
+      const int b = min(tid * chunk, M), e = min(b + chunk, M);
+      int c = 0;
+      for (int r = b; r < e; r++) {  // r = reversed list index
+        const int i = M - 1 - r;
+        c += (S.nodeDepth[i] == k) && (S.nodeHi[i] - S.nodeLo[i] > 1);
+      }
+      int p = blockScanExcl(c, tid, ws, &nPend);
+      if (nPend <= qCap)
+        for (int r = b; r < e; r++) {
+          const int i = M - 1 - r;
+          if ((S.nodeDepth[i] == k) && (S.nodeHi[i] - S.nodeLo[i] > 1)) pendA[p++] = i;
+        }
+    }
+    if (tid == 0) { sSize = M; sFinish = 0; }
+    __syncthreads();
+    if (nPend > qCap) {  // E_k < N <= qCap always; guard anyway
+      if (tid == 0) *nOut = -2;
+      return;
+    }
     int nFront = 0;
-    bool finish = false, overflow = false;
-    while (!finish) {
-      const int prevSize = size;
-      const int np = min(nPend, qCap);
-      for (int i = 0; i < np; i++) {
-        const int nd = S.pending[i];
+    for (;;) {
+      // (a) sort keys: count << 40 | UL.x << 20 | node
+      for (int j = tid; j < nPend; j += OCT_T) {
+        const int nd = pendA[j];
         const int lo = S.nodeLo[nd];
-        // UL.x of the node: walk its digits from the root rectangle
         const u64 code = S.keys[lo] >> 24;
         int ulx, uly, brx, bry;
         rootRect(L, (int)(code >> (2 * OCT_DEPTH)), ulx, uly, brx, bry);
@@ -394,102 +378,144 @@ __device__ void octreeSelect(const OctScratch S, const uint32_t* __restrict__ ca
           if (q & 1) ulx += halfX; else brx = ulx + halfX;
           if (q & 2) uly += halfY; else bry = uly + halfY;
         }
-        S.sized[3 * i] = S.nodeHi[nd] - lo;
-        S.sized[3 * i + 1] = ulx;
-        S.sized[3 * i + 2] = nd;
+        sizedA[j] = ((u64)(S.nodeHi[nd] - lo) << 40) | ((u64)(ulx & 0xfffff) << 20) | (u64)nd;
       }
-      nPend = 0;
-      stdSortSized(S.sized, np);  // cpp:912
-      for (int j = np - 1; j >= 0; j--) {
-        const int parent = S.sized[3 * j + 2];
-        const int plo = S.nodeLo[parent], phi = S.nodeHi[parent], pd = S.nodeDepth[parent];
-        int nChildren = 0;
-        if (pd >= OCT_DEPTH) {  // coincident keys: cannot be split further
-          if (nFront < fCap && nPend < 2 * qCap) {
-            const int id = mCap + nFront++;
-            S.nodeLo[id] = plo; S.nodeHi[id] = phi; S.nodeDepth[id] = (uint8_t)pd; S.nodeAlive[id] = 1;
-            S.pending[nPend++] = id;
-          } else {
-            overflow = true;
-          }
-          nChildren = 1;
-        } else {
-          int lo = plo;
-          while (lo < phi) {
-            int hi = lo + 1;
-            while (hi < phi && (int)S.div[hi] > pd + 1) hi++;
-            if (nFront < fCap && (hi - lo == 1 || nPend < 2 * qCap)) {
-              const int id = mCap + nFront++;
-              S.nodeLo[id] = lo; S.nodeHi[id] = hi; S.nodeDepth[id] = (uint8_t)(pd + 1); S.nodeAlive[id] = 1;
-              if (hi - lo > 1) S.pending[nPend++] = id;
-            } else {
-              overflow = true;
-            }
-            nChildren++;
-            lo = hi;
-          }
+      __syncthreads();
+      // (b) std::sort (cpp:912): partition phase on one lane, final insertion sort as a parallel stable rank sort
+      if (tid == 0) stdIntrosortLoop(sizedA, nPend);
+      __syncthreads();
+      for (int j = tid; j < nPend; j += OCT_T) {
+        const u64 v = sizedA[j];
+        const u64 kv = v >> 20;
+        int rank = 0;
+        for (int i = 0; i < nPend; i++) {
+          const u64 ki = sizedA[i] >> 20;
+          rank += (ki < kv) || (ki == kv && i < j);
         }
-        S.nodeAlive[parent] = 0;
-        size += nChildren - 1;
-        if (size >= N) break;
+        sizedB[rank] = v;
       }
-      if (size >= N || size == prevSize || overflow) finish = true;
+      __syncthreads();
+      // (c) children of every pending node (in sorted order)
+      for (int j = tid; j < nPend; j += OCT_T) {
+        const int nd = (int)(sizedB[j] & 0xfffff);
+        const int lo = S.nodeLo[nd], hi = S.nodeHi[nd], pd = S.nodeDepth[nd];
+        int nch = 1, nmulti = 1;
+        if (pd < OCT_DEPTH) {
+          nch = 0;
+          nmulti = 0;
+          int start = lo;
+          for (int i = lo + 1; i <= hi; i++)
+            if (i == hi || (int)S.div[i] <= pd + 1) {
+              nch++;
+              nmulti += (i - start > 1);
+              start = i;
+            }
+        }
+        S.childCnt[j] = nch | (nmulti << 8);
+      }
+      __syncthreads();
+      // (d) cut point: nodes are split from the back of the sorted array until the list holds N nodes
+      if (tid == 0) {
+        const int prevSize = sSize;
+        int size = prevSize, j = nPend - 1;
+        for (; j >= 0; j--) {
+          size += (S.childCnt[j] & 0xff) - 1;
+          if (size >= N) break;
+        }
+        sCut = max(j, 0);
+        sSize = size;
+        sFinish = (size >= N || size == prevSize) ? 1 : 0;
+      }
+      __syncthreads();
+      const int cut = sCut, finish = sFinish;
+      // (e) create the children: processing order t = nPend-1-j; children are push_front'ed in quadrant order
+      {
+        const int nProc = nPend - cut;
+        const int chunk = (nProc + OCT_T - 1) / OCT_T;
+        const int b = min(tid * chunk, nProc), e = min(b + chunk, nProc);
+        int cc = 0, cm = 0;
+        for (int t = b; t < e; t++) {
+          const int v = S.childCnt[nPend - 1 - t];
+          cc += v & 0xff;
+          cm += v >> 8;
+        }
+        int totC, totM;
+        int offC = blockScanExcl(cc, tid, ws, &totC);
+        int offM = blockScanExcl(cm, tid, ws, &totM);
+        if (nFront + totC > fCap || totM > qCap) {  // scratch too small: the caller re-runs the unit with more
+          if (tid == 0) *nOut = -2;
+          return;
+        }
+        for (int t = b; t < e; t++) {
+          const int j = nPend - 1 - t;
+          const int nd = (int)(sizedB[j] & 0xfffff);
+          const int lo = S.nodeLo[nd], hi = S.nodeHi[nd], pd = S.nodeDepth[nd];
+          if (pd >= OCT_DEPTH) {  // coincident keys: cannot be split further, stays one node
+            const int id = mCap + nFront + offC++;
+            S.nodeLo[id] = lo; S.nodeHi[id] = hi; S.nodeDepth[id] = (uint8_t)pd; S.nodeAlive[id] = 1;
+            pendB[offM++] = id;
+          } else {
+            int start = lo;
+            for (int i = lo + 1; i <= hi; i++)
+              if (i == hi || (int)S.div[i] <= pd + 1) {
+                const int id = mCap + nFront + offC++;
+                S.nodeLo[id] = start; S.nodeHi[id] = i; S.nodeDepth[id] = (uint8_t)(pd + 1); S.nodeAlive[id] = 1;
+                if (i - start > 1) pendB[offM++] = id;
+                start = i;
+              }
+          }
+          S.nodeAlive[nd] = 0;
+        }
+        nFront += totC;
+        nPend = totM;
+      }
+      __syncthreads();
+      if (finish) break;
+      { int* t = pendA; pendA = pendB; pendB = t; }
     }
-    sFront = overflow ? -1 : nFront;
+    if (tid == 0) sFront = nFront;
+    __syncthreads();
   }
-  __syncthreads();
-  if (sFront < 0) {  // scratch too small for this unit: report, the caller re-runs it with larger scratch
-    if (tid == 0) *nOut = -2;
-    return;
-  }
-  // ---- 6. output positions: reverse(front alive) ++ list alive; keep the first `quota` ----------------------
+  // ---- 6. output positions: reverse(front alive) ++ list alive; keep the first `quota` ------------------------------
   const int nFront = sFront;
-  const int total = nFront + M;  // virtual sequence: front nodes in reverse push order, then the list
+  const int total = nFront + M;  // virtual sequence: pushed nodes in reverse push order, then the list
   {
     const int chunk = (total + OCT_T - 1) / OCT_T;
-    const int b = tid * chunk, e = min(b + chunk, total);
+    const int b = min(tid * chunk, total), e = min(b + chunk, total);
     auto nodeAt = [&](int v) { return v < nFront ? mCap + (nFront - 1 - v) : v - nFront; };
     int c = 0;
     for (int v = b; v < e; v++) c += S.nodeAlive[nodeAt(v)];
-    partial[tid] = c;
-    __syncthreads();
-    if (tid == 0) {
-      int acc = 0;
-      for (int i = 0; i < OCT_T; i++) { const int v = partial[i]; partial[i] = acc; acc += v; }
-      sTotal = acc;
-    }
-    __syncthreads();
-    int p = partial[tid];
-    for (int v = b; v < e; v++) {
+    int alive;
+    int p = blockScanExcl(c, tid, ws, &alive);
+    for (int v = b; v < e && p < N; v++) {
       const int nd = nodeAt(v);
       if (!S.nodeAlive[nd]) continue;
-      if (p < N) {
-        // first key with the highest response (cpp:984-1007); "first" = reference candidate order
-        const int lo = S.nodeLo[nd], hi = S.nodeHi[nd];
-        uint32_t bestE = cand[(int)(S.keys[lo] & 0xffffff)];
+      // first key with the highest response (cpp:984-1007); "first" = reference candidate order
+      const int lo = S.nodeLo[nd], hi = S.nodeHi[nd];
+      uint32_t bestE = S.cand[(int)(S.keys[lo] & 0xffffff)];
+      if (hi - lo > 1) {
         u64 bestRank = candRank(bestE, L);
         for (int i = lo + 1; i < hi; i++) {
-          const uint32_t e2 = cand[(int)(S.keys[i] & 0xffffff)];
-          const u64 r2 = candRank(e2, L);
+          const uint32_t e2 = S.cand[(int)(S.keys[i] & 0xffffff)];
           const uint32_t s1 = bestE >> 24, s2 = e2 >> 24;
-          if (s2 > s1 || (s2 == s1 && r2 < bestRank)) { bestE = e2; bestRank = r2; }
+          if (s2 < s1) continue;
+          const u64 r2 = candRank(e2, L);
+          if (s2 > s1 || r2 < bestRank) { bestE = e2; bestRank = r2; }
         }
-        SelKp kp;
-        kp.x = (uint16_t)((bestE & 0xfff) + ORBX_MIN_BORDER);        // cpp:1171-1172
-        kp.y = (uint16_t)(((bestE >> 12) & 0xfff) + ORBX_MIN_BORDER);
-        kp.level = (uint8_t)level;
-        kp.response = (uint8_t)(bestE >> 24);
-        kp.pad = 0;
-        out[p] = kp;
       }
-      p++;
+      SelKp kp;
+      kp.x = (uint16_t)((bestE & 0xfff) + ORBX_MIN_BORDER);  // cpp:1171-1172
+      kp.y = (uint16_t)(((bestE >> 12) & 0xfff) + ORBX_MIN_BORDER);
+      kp.level = (uint8_t)level;
+      kp.response = (uint8_t)(bestE >> 24);
+      kp.pad = 0;
+      out[p++] = kp;
     }
+    if (tid == 0) *nOut = min(alive, N);
   }
-  __syncthreads();
-  if (tid == 0) *nOut = min(sTotal, N);
 }
 
-// ---- kernels -------------------------------------------------------------------------------------------------
+// ---- kernels ---------------------------------------------------------------------------------------------------------
 
 // LDS-resident variant: n <= NMAX candidates, quota <= QMAX
 template <int NMAX, int QMAX>
@@ -500,11 +526,13 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   static_assert((NMAX & (NMAX - 1)) == 0 && (MCAP & (MCAP - 1)) == 0, "sort buffers must be powers of two");
   __shared__ u64 keys[NMAX];
   __shared__ u64 nodes[MCAP];
-  __shared__ uint8_t div[NMAX + 4], alone[NMAX];
+  __shared__ u64 sized[2 * QMAX];
+  __shared__ uint32_t candL[NMAX];
   __shared__ uint32_t hiOf[NMAX];
   __shared__ int nodeLo[MCAP + FCAP], nodeHi[MCAP + FCAP];
+  __shared__ int pending[2 * QMAX], childCnt[QMAX];
+  __shared__ uint8_t div[NMAX + 4], alone[NMAX];
   __shared__ uint8_t nodeDepth[MCAP + FCAP], nodeAlive[MCAP + FCAP];
-  __shared__ int sized[3 * QMAX], pending[2 * QMAX];
   const int level = blockIdx.x, f = blockIdx.y;
   const int n = candCount[f * P.nlevels + level];
   int* nOut = &nselLevel[f * P.nlevels + level];
@@ -512,9 +540,11 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
     if (threadIdx.x == 0) *nOut = -2;
     return;
   }
-  OctScratch S{keys, nodes, div, alone, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, nullptr};
-  octreeSelect(S, cand + P.candOff[level] + (int64_t)f * P.candCap[level], n, P.lev[level], level,
-               selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, MCAP, FCAP, QMAX);
+  const uint32_t* src = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
+  for (int i = threadIdx.x; i < n; i += OCT_T) candL[i] = src[i];
+  __syncthreads();
+  OctScratch S{keys, nodes, div, alone, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, childCnt, candL};
+  octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, MCAP, FCAP, QMAX);
 }
 
 // global-scratch variant for the (frame, level) units the LDS variant left (nselLevel == -2), or for all units when
@@ -540,18 +570,19 @@ __global__ __launch_bounds__(OCT_T) void k_octree_global(const uint32_t* __restr
   OctScratch S;
   S.keys = (u64*)p; p += nPad * 8;
   S.nodes = (u64*)p; p += mPad * 8;
+  S.sized = (u64*)p; p += (size_t)2 * qMax * 8;
   S.hiOf = (uint32_t*)p; p += nPad * 4;
   S.nodeLo = (int*)p; p += (size_t)(mCap + fCap) * 4;
   S.nodeHi = (int*)p; p += (size_t)(mCap + fCap) * 4;
-  S.sized = (int*)p; p += (size_t)3 * qMax * 4;
   S.pending = (int*)p; p += (size_t)2 * qMax * 4;
+  S.childCnt = (int*)p; p += (size_t)qMax * 4;
   S.div = p; p += nPad + 8;
   S.alone = p; p += nPad + 8;
   S.nodeDepth = p; p += (size_t)(mCap + fCap + 8);
   S.nodeAlive = p;
-  S.pos = nullptr;
-  octreeSelect(S, cand + P.candOff[level] + (int64_t)f * P.candCap[level], n, P.lev[level], level,
-               selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, mCap, fCap, qMax);
+  S.cand = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
+  octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, mCap, fCap, qMax);
+  __syncthreads();
   if (threadIdx.x == 0 && *nOut == -2) *nOut = -1;  // even the large scratch was too small: hard error
 }
 
@@ -562,7 +593,8 @@ size_t octScratchBytes(int nMax, int qMax) {
   const size_t mCap = 4 * (size_t)qMax, fCap = 16 * (size_t)qMax;
   size_t mPad = 1;
   while (mPad < mCap) mPad <<= 1;
-  size_t b = nPad * 8 + mPad * 8 + nPad * 4 + (mCap + fCap) * 8 + (size_t)5 * qMax * 4 + 2 * (nPad + 8) + 2 * (mCap + fCap + 8);
+  size_t b = nPad * 8 + mPad * 8 + (size_t)2 * qMax * 8 + nPad * 4 + (mCap + fCap) * 8 + (size_t)3 * qMax * 4 + 2 * (nPad + 8) +
+             2 * (mCap + fCap + 8);
   return (b + 255) / 256 * 256;
 }
 
@@ -577,7 +609,7 @@ __global__ __launch_bounds__(256) void k_sel_compact(const SelKp* __restrict__ s
     for (int l = 0; l < P.nlevels; l++) {
       off[l] = acc;
       const int c = nselLevel[f * P.nlevels + l];
-      if (c < 0) { *err = 1; }
+      if (c < 0) *err = 1;
       acc += max(c, 0);
     }
     off[P.nlevels] = acc;
@@ -596,8 +628,8 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
                          SelKp* selStage, int* nselLevel, uint8_t* scratch, int maxQuota) {
   dim3 grid(P.nlevels, nFrames, 1), block(OCT_T, 1, 1);
   const bool lds = maxQuota <= 256;
-  if (lds) hipLaunchKernelGGL((k_octree_lds<1024, 256>), grid, block, 0, st, cand, candCount, P, selStage, nselLevel);
-  // units the LDS variant could not take (more than 1024 candidates, or scratch overflow) exit at once otherwise
+  if (lds) hipLaunchKernelGGL((k_octree_lds<2048, 256>), grid, block, 0, st, cand, candCount, P, selStage, nselLevel);
+  // units the LDS variant could not take (more than 2048 candidates, or scratch overflow) exit at once otherwise
   hipLaunchKernelGGL(k_octree_global, grid, block, 0, st, cand, candCount, P, selStage, nselLevel, scratch, lds ? 0 : 1);
   return hipGetLastError();
 }
@@ -608,12 +640,33 @@ hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage
   return hipGetLastError();
 }
 
-// ---- test hook: the std::sort replay alone ---------------------------------------------------------------------
-__global__ void k_debug_sort(int* p, int n) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) stdSortSized(p, n);
+// ---- test hook: the std::sort replay alone (partition phase on one lane + parallel stable rank sort) ---------------
+__global__ __launch_bounds__(OCT_T) void k_debug_sort(int* triples, int n, u64* a, u64* b) {
+  const int tid = threadIdx.x;
+  for (int j = tid; j < n; j += OCT_T)
+    a[j] = ((u64)(uint32_t)triples[3 * j] << 40) | ((u64)((uint32_t)triples[3 * j + 1] & 0xfffff) << 20) |
+           (u64)((uint32_t)triples[3 * j + 2] & 0xfffff);
+  __syncthreads();
+  if (tid == 0) stdIntrosortLoop(a, n);
+  __syncthreads();
+  for (int j = tid; j < n; j += OCT_T) {
+    const u64 v = a[j], kv = v >> 20;
+    int rank = 0;
+    for (int i = 0; i < n; i++) {
+      const u64 ki = a[i] >> 20;
+      rank += (ki < kv) || (ki == kv && i < j);
+    }
+    b[rank] = v;
+  }
+  __syncthreads();
+  for (int j = tid; j < n; j += OCT_T) {
+    triples[3 * j] = (int)(b[j] >> 40);
+    triples[3 * j + 1] = (int)((b[j] >> 20) & 0xfffff);
+    triples[3 * j + 2] = (int)(b[j] & 0xfffff);
+  }
 }
-hipError_t launch_debug_sort(hipStream_t st, int* triples, int n) {
-  hipLaunchKernelGGL(k_debug_sort, dim3(1), dim3(64), 0, st, triples, n);
+hipError_t launch_debug_sort(hipStream_t st, int* triples, int n, unsigned long long* a, unsigned long long* b) {
+  hipLaunchKernelGGL(k_debug_sort, dim3(1), dim3(OCT_T), 0, st, triples, n, a, b);
   return hipGetLastError();
 }
 
