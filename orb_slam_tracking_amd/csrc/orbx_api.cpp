@@ -696,7 +696,7 @@ int orbx_match_init_batch_device(orbx_ctx* ctx, int n_pairs, const int32_t* h_fi
     StageTimer tm(ctx, ORBX_STAGE_MATCH);
     HIPCHK(launch_match(ctx->st, n_pairs, ctx->dPairs, ctx->dPairs + n_pairs, d_kps, d_desc32, d_n, capacity, *bounds, window_size,
                         nnratio, check_orientation, d_matches12, d_nmatches, d_stats, ctx->dMatchScratch));
-    tm.stop(1);
+    tm.stop(2);  // k_match_wave + k_match (pending pairs only)
   }
   HIPCHK(hipStreamSynchronize(ctx->st));
   collectProfile(ctx, used);

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img0, 
   __shared__ __attribute__((aligned(16))) uint8_t smap[SMAP_STRIDE * SMAP_STRIDE];
   __shared__ uint16_t list[70 * 70];
   __shared__ uint32_t outl[FAST_OUT_MAX];
-  __shared__ int nList, nOut, anyIni, outBase;
+  __shared__ int nList, nOut, outBase;
 
   const int t = threadIdx.x;
   const int f = blockIdx.y;
@@ -133,83 +133,85 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img0, 
     uint32_t* smap32 = reinterpret_cast<uint32_t*>(smap);
     for (int idx = t; idx < SMAP_STRIDE * SMAP_STRIDE / 4; idx += 256) smap32[idx] = 0;
   }
-  if (t == 0) { nList = 0; nOut = 0; anyIni = 0; }
+  if (t == 0) { nList = 0; nOut = 0; }
   __syncthreads();
 
-  const int tlo = min(g.iniTh, g.minTh);
   // ring offsets inside the LDS tile, k = 0..15 (dx,dy) = (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)...
   constexpr int RS = TILE_STRIDE;
   constexpr int ro[16] = {3 * RS,      3 * RS + 1,  2 * RS + 2,  RS + 3,  3,       -RS + 3,     -2 * RS + 2, -3 * RS + 1,
                           -3 * RS,     -3 * RS - 1, -2 * RS - 2, -RS - 3, -3,      RS - 3,      2 * RS - 2,  3 * RS - 1};
-  // ---- phase 1: cheap arc test at the lower threshold, compact the passing pixels ----
-  for (int idx = t; idx < iw * ih; idx += 256) {
-    const int py = idx / iw, px = idx - py * iw;
-    const uint8_t* p = &tile[(py + 3) * TILE_STRIDE + xoff + px + 3];
-    const int v = p[0], hi = v + tlo, lo = v - tlo;
-    uint32_t br = 0, dk = 0;
+  // per-thread pixel walk without divisions inside the loops: idx += 256  <=>  (px, py) += (256 % iw, 256 / iw)
+  const int py0 = t / iw, px0 = t - py0 * iw;
+  const int dpy = 256 / iw, dpx = 256 - dpy * iw;
+  const int npix = iw * ih;
+  // The reference runs cv::FAST at iniThFAST and, only if the cell yields nothing, again at minThFAST (cpp:1109-1123).
+  // Same here: pass 0 at iniTh, pass 1 at minTh only for cells without a survivor.  The strength map is threshold
+  // independent, so what pass 0 wrote stays valid for pass 1.
+  for (int pass = 0; pass < 2; pass++) {
+    const int th = pass == 0 ? g.iniTh : g.minTh;
+    // ---- phase 0: necessary condition on the 4 compass pixels (an arc of 9 holds two adjacent ones) ----
+    {
+      int px = px0, py = py0;
+      for (int idx = t; idx < npix; idx += 256) {
+        const uint8_t* p = &tile[(py + 3) * TILE_STRIDE + xoff + px + 3];
+        const int v = p[0], hi = v + th, lo = v - th;
+        const int q0 = p[ro[0]], q4 = p[ro[4]], q8 = p[ro[8]], q12 = p[ro[12]];
+        const bool b0 = q0 > hi, b4 = q4 > hi, b8 = q8 > hi, b12 = q12 > hi;
+        const bool d0 = q0 < lo, d4 = q4 < lo, d8 = q8 < lo, d12 = q12 < lo;
+        const bool cand0 = ((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12));
+        if (cand0) list[atomicAdd(&nList, 1)] = (uint16_t)((py << 7) | px);
+        px += dpx;
+        py += dpy;
+        if (px >= iw) { px -= iw; py++; }
+      }
+    }
+    __syncthreads();
+    const int nl = nList;
+    // ---- phase 1: exact strength of the remaining pixels; corners (s > th) enter the strength map ----
+    for (int e = t; e < nl; e += 256) {
+      const int code = list[e];
+      const int py = code >> 7, px = code & 127;
+      const uint8_t* p = &tile[(py + 3) * TILE_STRIDE + xoff + px + 3];
+      const int v = p[0];
+      int d[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const int q = p[ro[k]];
-      br |= (uint32_t)(q > hi) << k;
-      dk |= (uint32_t)(q < lo) << k;
-    }
-    if (arc9(br) || arc9(dk)) list[atomicAdd(&nList, 1)] = (uint16_t)idx;
-  }
-  __syncthreads();
-  const int nl = nList;
-  // ---- phase 2: exact strength of the passing pixels ----
-  for (int e = t; e < nl; e += 256) {
-    const int idx = list[e];
-    const int py = idx / iw, px = idx - py * iw;
-    const uint8_t* p = &tile[(py + 3) * TILE_STRIDE + xoff + px + 3];
-    const int v = p[0];
-    int d[16];
+      for (int k = 0; k < 16; k++) d[k] = v - (int)p[ro[k]];
+      int mn3[16], mx3[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = v - (int)p[ro[k]];
-    int mn3[16], mx3[16];
+      for (int k = 0; k < 16; k++) {
+        mn3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+        mx3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+      }
+      int smn = -256, smx = 256;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      mn3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-      mx3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+      for (int k = 0; k < 16; k++) {
+        smn = max(smn, min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]));
+        smx = min(smx, max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]));
+      }
+      const int s = max(smn, -smx);
+      if (s > th) smap[(py + 1) * SMAP_STRIDE + px + 1] = (uint8_t)s;
+      else list[e] = 0xFFFF;
     }
-    int s = -256;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const int mn9 = min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]);
-      const int mx9 = max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]);
-      s = max(s, max(mn9, -mx9));
+    __syncthreads();
+    // ---- phase 2: in-cell NMS on the strength map; survivors are the cell's keypoints ----
+    for (int e = t; e < nl; e += 256) {
+      const int code = list[e];
+      if (code == 0xFFFF) continue;
+      const int py = code >> 7, px = code & 127;
+      const uint8_t* q = &smap[(py + 1) * SMAP_STRIDE + px + 1];
+      const int s = q[0];
+      const bool keep = s > 1 && s > q[-SMAP_STRIDE - 1] && s > q[-SMAP_STRIDE] && s > q[-SMAP_STRIDE + 1] && s > q[-1] &&
+                        s > q[1] && s > q[SMAP_STRIDE - 1] && s > q[SMAP_STRIDE] && s > q[SMAP_STRIDE + 1];
+      if (keep) {
+        const int slot = atomicAdd(&nOut, 1);
+        if (slot < FAST_OUT_MAX) outl[slot] = packCand(px + 3 + cj * L.wCell, py + 3 + ci * L.hCell, s - 1);
+      }
     }
-    smap[(py + 1) * SMAP_STRIDE + px + 1] = (uint8_t)s;  // s in (tlo, 255]
+    __syncthreads();
+    if (nOut > 0 || pass == 1 || g.minTh >= g.iniTh) break;
+    if (t == 0) nList = 0;  // retry the whole cell at minThFAST
+    __syncthreads();
   }
-  __syncthreads();
-  // ---- phase 3: in-cell NMS on the strength map ----
-  for (int e = t; e < nl; e += 256) {
-    const int idx = list[e];
-    const int py = idx / iw, px = idx - py * iw;
-    const uint8_t* q = &smap[(py + 1) * SMAP_STRIDE + px + 1];
-    const int s = q[0];
-    const bool keep = s > 1 && s > q[-SMAP_STRIDE - 1] && s > q[-SMAP_STRIDE] && s > q[-SMAP_STRIDE + 1] && s > q[-1] &&
-                      s > q[1] && s > q[SMAP_STRIDE - 1] && s > q[SMAP_STRIDE] && s > q[SMAP_STRIDE + 1];
-    if (keep) {
-      list[e] = (uint16_t)(idx | 0x8000);
-      if (s > g.iniTh) anyIni = 1;
-    }
-  }
-  __syncthreads();
-  // ---- phase 4: emit survivors at the cell's threshold ----
-  const int th = anyIni ? g.iniTh : g.minTh;
-  for (int e = t; e < nl; e += 256) {
-    const int raw = list[e];
-    if (!(raw & 0x8000)) continue;
-    const int idx = raw & 0x7fff;
-    const int py = idx / iw, px = idx - py * iw;
-    const int s = smap[(py + 1) * SMAP_STRIDE + px + 1];
-    if (s > th) {
-      const int slot = atomicAdd(&nOut, 1);
-      if (slot < FAST_OUT_MAX) outl[slot] = packCand(px + 3 + cj * L.wCell, py + 3 + ci * L.hCell, s - 1);
-    }
-  }
-  __syncthreads();
   const int no = min(nOut, FAST_OUT_MAX);
   if (t == 0) outBase = no ? atomicAdd(&candCount[f * g.nlevels + level], no) : 0;
   __syncthreads();
@@ -373,11 +375,14 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ img
 #define INF_DIST 0x7fffffff
 #define MATCH_NONE 0x7fffffffffffffffull
 
+#define MATCH_PENDING ((int)0x80000000)  // nmatches value meaning "left for the general kernel"
+
 struct MatchParams {
   int capacity;
   int window;
   float nnratio;
   int checkOri;
+  int onlyPending;
   orbx_bounds b;
 };
 
@@ -385,6 +390,208 @@ __device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const 
   const uint4 b0 = reinterpret_cast<const uint4*>(b)[0], b1 = reinterpret_cast<const uint4*>(b)[1];
   return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
          __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// -------------------------------------------------------------------------------------------------
+// k_match_wave: one WAVE per frame pair, everything the sequential query loop touches lives in LDS:
+// the octave-0 queries of F1 and the grid-eligible octave-0 trains of F2 (position, cell, angle, descriptor words
+// stored word-major so that lane e reading word w is bank-conflict free), vMatchedDistance, vnMatches21 and the
+// rotation bins.  No barriers inside the query loop (a single wave executes its LDS operations in order).
+// Pairs that do not fit (more than MW_CAP eligible trains / octave-0 queries, or n1 > MW_N1) are marked
+// MATCH_PENDING and done by the general kernel k_match right after.
+// -------------------------------------------------------------------------------------------------
+#define MW_CAP 512
+#define MW_N1 4096
+
+__global__ __launch_bounds__(64) void k_match_wave(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
+                                                   const orbx_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                   const int* __restrict__ nkp, const MatchParams mp,
+                                                   int* __restrict__ matches12, int* __restrict__ nmatchesOut,
+                                                   int* __restrict__ statsOut) {
+  __shared__ float tX[MW_CAP], tY[MW_CAP], tAng[MW_CAP];
+  __shared__ uint32_t tDesc[8][MW_CAP];
+  __shared__ int tMd[MW_CAP], tM21[MW_CAP];
+  __shared__ uint16_t tIdx[MW_CAP], tCell[MW_CAP];
+  __shared__ float qX[MW_CAP], qY[MW_CAP], qAng[MW_CAP];
+  __shared__ uint32_t qDesc[MW_CAP][8];
+  __shared__ uint16_t qIdx[MW_CAP];
+  __shared__ uint8_t accBin[MW_N1];  // rotation bin per F1 index, 255 = not in rotHist
+  __shared__ int hist[HISTO_LENGTH];
+
+  const int lane = threadIdx.x;
+  const int pair = blockIdx.x;
+  const int fa = pairFirst[pair], fb = pairSecond[pair];
+  const int n1 = nkp[fa], n2 = nkp[fb];
+  const int cap = mp.capacity;
+  const orbx_keypoint* k1 = kps + (long long)fa * cap;
+  const orbx_keypoint* k2 = kps + (long long)fb * cap;
+  const uint32_t* d1 = reinterpret_cast<const uint32_t*>(desc + (long long)fa * cap * 32);
+  const uint32_t* d2 = reinterpret_cast<const uint32_t*>(desc + (long long)fb * cap * 32);
+  int* m12 = matches12 + (long long)pair * cap;
+
+  const float wInv = (float)ORBX_GRID_COLS / (float)(mp.b.max_x - mp.b.min_x);  // Frame.cpp:46-47
+  const float hInv = (float)ORBX_GRID_ROWS / (float)(mp.b.max_y - mp.b.min_y);
+  const float fminX = (float)mp.b.min_x, fminY = (float)mp.b.min_y;
+
+  // ---- stage the eligible trains of F2 (index order kept) ----
+  int nT = 0;
+  bool fits = n1 <= MW_N1 && n2 <= 65535;
+  for (int j0 = 0; j0 < n2 && fits; j0 += 64) {
+    const int j = j0 + lane;
+    bool ok = false;
+    orbx_keypoint kp;
+    int cell = 0;
+    if (j < n2) {
+      kp = k2[j];
+      // Frame::PosInGrid (Frame.cpp:89-99) + the octave filter of GetFeaturesInArea (Frame.cpp:179,191)
+      const int px = (int)roundf((kp.x - fminX) * wInv), py = (int)roundf((kp.y - fminY) * hInv);
+      ok = kp.octave == 0 && px >= 0 && px < ORBX_GRID_COLS && py >= 0 && py < ORBX_GRID_ROWS;
+      cell = px * ORBX_GRID_ROWS + py;
+    }
+    const unsigned long long m = __ballot(ok);
+    const int pos = nT + __popcll(m & ((1ull << lane) - 1ull));
+    if (nT + __popcll(m) > MW_CAP) { fits = false; break; }
+    if (ok) {
+      tX[pos] = kp.x; tY[pos] = kp.y; tAng[pos] = kp.angle;
+      tIdx[pos] = (uint16_t)j; tCell[pos] = (uint16_t)cell;
+      tMd[pos] = INF_DIST; tM21[pos] = -1;
+#pragma unroll
+      for (int w = 0; w < 8; w++) tDesc[w][pos] = d2[(long long)j * 8 + w];
+    }
+    nT += __popcll(m);
+  }
+  // ---- stage the octave-0 queries of F1 ----
+  int nQ = 0;
+  for (int i0 = 0; i0 < n1 && fits; i0 += 64) {
+    const int i = i0 + lane;
+    bool ok = false;
+    orbx_keypoint kp;
+    if (i < n1) {
+      kp = k1[i];
+      ok = !(kp.octave > 0);  // ORBmatcher.cpp:38-39
+      accBin[i] = 255;
+      m12[i] = -1;
+    }
+    const unsigned long long m = __ballot(ok);
+    const int pos = nQ + __popcll(m & ((1ull << lane) - 1ull));
+    if (nQ + __popcll(m) > MW_CAP) { fits = false; break; }
+    if (ok) {
+      qX[pos] = kp.x; qY[pos] = kp.y; qAng[pos] = kp.angle; qIdx[pos] = (uint16_t)i;
+#pragma unroll
+      for (int w = 0; w < 8; w++) qDesc[pos][w] = d1[(long long)i * 8 + w];
+    }
+    nQ += __popcll(m);
+  }
+  if (!fits) {  // wave-uniform
+    if (lane == 0) nmatchesOut[pair] = MATCH_PENDING;
+    return;
+  }
+  if (lane < HISTO_LENGTH) hist[lane] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+
+  int nm = 0, badDist = 0, badRatio = 0, badOri = 0;
+  const float r = (float)mp.window;
+  const float factor = HISTO_LENGTH / 360.0f;
+  for (int q = 0; q < nQ; q++) {
+    const float x1 = qX[q], y1 = qY[q];
+    // cell window, Frame.cpp:167-177
+    const int minCX = max(0, (int)floorf((x1 - fminX - r) * wInv));
+    const int maxCX = min(ORBX_GRID_COLS - 1, (int)ceilf((x1 - fminX + r) * wInv));
+    const int minCY = max(0, (int)floorf((y1 - fminY - r) * hInv));
+    const int maxCY = min(ORBX_GRID_ROWS - 1, (int)ceilf((y1 - fminY + r) * hInv));
+    if (minCX >= ORBX_GRID_COLS || maxCX < 0 || minCY >= ORBX_GRID_ROWS || maxCY < 0) continue;
+    uint32_t qd[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) qd[w] = qDesc[q][w];
+    unsigned long long best = MATCH_NONE;  // dist << 32 | cell << 20 | train index
+    int second = INF_DIST, any = 0, bestE = -1;
+    for (int e = lane; e < nT; e += 64) {
+      const int c = tCell[e];
+      const int cx = c / ORBX_GRID_ROWS, cy = c - cx * ORBX_GRID_ROWS;
+      if (cx < minCX || cx > maxCX || cy < minCY || cy > maxCY) continue;
+      const float dx = tX[e] - x1, dy = tY[e] - y1;
+      if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
+      any = 1;
+      int dist = 0;
+#pragma unroll
+      for (int w = 0; w < 8; w++) dist += __popc(qd[w] ^ tDesc[w][e]);
+      if (tMd[e] <= dist) continue;  // ORBmatcher.cpp:67
+      const unsigned long long key = ((unsigned long long)dist << 32) | ((unsigned long long)c << 20) | (unsigned)tIdx[e];
+      if (key < best) {
+        second = min(second, (int)(best >> 32));
+        best = key;
+        bestE = e;
+      } else {
+        second = min(second, dist);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const unsigned long long ob = __shfl_xor(best, o);
+      const int os = __shfl_xor(second, o), oe = __shfl_xor(bestE, o);
+      any |= __shfl_xor(any, o);
+      const bool take = ob < best;
+      second = min(min(second, os), (int)((take ? best : ob) >> 32));
+      best = take ? ob : best;
+      bestE = take ? oe : bestE;
+    }
+    if (!any) continue;  // vIndices2.empty(), ORBmatcher.cpp:45
+    const int bestDist = (int)(best >> 32);
+    if (best == MATCH_NONE || bestDist > TH_LOW) { badDist++; continue; }
+    if ((float)bestDist > mp.nnratio * (float)second) { badRatio++; continue; }
+    // all lanes hold the same decision; lane 0 commits it
+    const int i1 = qIdx[q];
+    const int bestIdx2 = (int)(best & 0xFFFFF);
+    const int old = tM21[bestE];
+    if (old >= 0) nm--;
+    nm++;
+    int bin = -1;
+    if (mp.checkOri) {
+      float rot = qAng[q] - tAng[bestE];
+      if (rot < 0.0f) rot += 360.0f;
+      bin = (int)roundf(rot * factor);
+      if (bin == HISTO_LENGTH) bin = 0;
+      if (bin < 0 || bin >= HISTO_LENGTH) bin = -1;
+    }
+    if (lane == 0) {
+      if (old >= 0) m12[old] = -1;
+      m12[i1] = bestIdx2;
+      tM21[bestE] = i1;
+      tMd[bestE] = bestDist;
+      if (bin >= 0) { accBin[i1] = (uint8_t)bin; hist[bin]++; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- rotation histogram: keep the three largest bins (ComputeThreeMaxima, ORBmatcher.cpp:152-183) ----
+  if (mp.checkOri) {
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      const int s = hist[i];
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+      else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+    int dropped = 0;
+    for (int i = lane; i < n1; i += 64) {
+      const int b = accBin[i];
+      if (b != 255 && b != ind1 && b != ind2 && b != ind3) {  // also hits queries whose match was stolen (quirk, :130-138)
+        m12[i] = -1;
+        dropped++;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) dropped += __shfl_xor(dropped, o);
+    nm -= dropped;
+    badOri += dropped;
+  }
+  if (lane == 0) {
+    nmatchesOut[pair] = nm;
+    if (statsOut) { statsOut[pair * 3] = badDist; statsOut[pair * 3 + 1] = badRatio; statsOut[pair * 3 + 2] = badOri; }
+  }
 }
 
 __global__ __launch_bounds__(MATCH_T) void k_match(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
@@ -399,6 +606,7 @@ __global__ __launch_bounds__(MATCH_T) void k_match(const int* __restrict__ pairF
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int pair = blockIdx.x;
+  if (mp.onlyPending && nmatchesOut[pair] != MATCH_PENDING) return;  // already done by k_match_wave
   const int fa = pairFirst[pair], fb = pairSecond[pair];
   const int n1 = nkp[fa], n2 = nkp[fb];
   const int cap = mp.capacity;
@@ -582,6 +790,10 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
   if (nPairs <= 0) return hipSuccess;
   MatchParams mp;
   mp.capacity = capacity; mp.window = window; mp.nnratio = nnratio; mp.checkOri = checkOri; mp.b = b;
+  mp.onlyPending = 1;
+  // small pairs: one wave each, LDS resident; whatever it marks MATCH_PENDING is done by the general kernel
+  hipLaunchKernelGGL(k_match_wave, dim3(nPairs), dim3(64), 0, st, dFirst, dSecond, kps, desc, nkp, mp, matches12, nmatches,
+                     stats);
   hipLaunchKernelGGL(k_match, dim3(nPairs), dim3(MATCH_T), 0, st, dFirst, dSecond, kps, desc, nkp, mp, matches12, nmatches,
                      stats, scratch);
   return hipGetLastError();
