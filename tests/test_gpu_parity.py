@@ -337,3 +337,32 @@ def test_device_octree_level_geometries(orbx, ext640, oracle, shape):
         for variant in (0, 1):
             got = ext640.debug_distribute_device(xyr, 16, 16 + W, 16, 16 + H, N, variant)
             assert np.array_equal(got, exp), (dens, variant)
+
+
+def test_cpp_shim_equals_oracle(orbx, oracle, tmp_path):
+    """The reference's demo call sequence through the C++ drop-in classes (include/orbx_shim.hpp)."""
+    import subprocess
+    from orb_slam_tracking_amd import synth
+    from test_host import build_shim_demo
+    exe = build_shim_demo(orbx, str(tmp_path))
+    a, b = synth.synth_pair(640, 480, 77)
+    fa, fb = tmp_path / "a.raw", tmp_path / "b.raw"
+    fa.write_bytes(a.tobytes())
+    fb.write_bytes(b.tobytes())
+    p = subprocess.run([exe, "640", "480", str(fa), str(fb), "1000", "20", "7"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True)
+    assert p.returncode == 0, p.stdout
+    assert "Sum of features = 1000" in p.stdout and "invalidMatchByDistance:" in p.stdout  # cpp:549, ORBmatcher.cpp:144-147
+    res = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][0].split()[1:]
+    oe = oracle.Extractor(*CANON)
+    _, ka, da = oe(a)
+    _, kb, db = oe(b)
+    nm, m12, _ = oracle.match_init(ka, da, kb, db, (0, 640, 0, 480), 100, 0.9, True)
+
+    def fnv(buf):
+        h = 1469598103934665603
+        for byte in buf:
+            h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    assert [int(v) for v in res[:3]] == [len(ka), len(kb), nm]
+    assert int(res[3]) == fnv(ka.tobytes()) and int(res[4]) == fnv(da.tobytes()) and int(res[5]) == fnv(m12.astype(np.int32).tobytes())

@@ -111,3 +111,28 @@ def test_synth_is_deterministic():
     assert np.array_equal(a, a2) and np.array_equal(b, b2) and not np.array_equal(a, b)
     import hashlib
     assert hashlib.sha256(a.tobytes()).hexdigest()[:16] == hashlib.sha256(synth.synth(160, 120, 5).tobytes()).hexdigest()[:16]
+
+
+def build_shim_demo(orbx, out_dir):
+    """Compiles tests/cpp/shim_demo.cpp (the reference's demo call sequence over include/orbx_shim.hpp) with plain g++."""
+    import subprocess
+    exe = os.path.join(out_dir, "shim_demo")
+    libdir = os.path.dirname(orbx.lib_path())
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "shim_demo.cpp"),
+           "-L", libdir, "-lorbx", "-Wl,-rpath," + libdir, "-o", exe]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout
+    return exe
+
+
+def test_cpp_shim_compiles_and_links(orbx, tmp_path):
+    """The C++ drop-in classes (ORB_SLAM_Tracking::ORBextractor / ORBmatcher) build against the C ABI alone."""
+    exe = build_shim_demo(orbx, str(tmp_path))
+    assert os.path.exists(exe)
+    if not _has_gpu():  # without a device the shim must fail loudly, not compute on the CPU
+        import subprocess
+        raw = tmp_path / "z.raw"
+        raw.write_bytes(bytes(640 * 480))
+        p = subprocess.run([exe, "640", "480", str(raw), str(raw), "1000", "20", "7"], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+        assert p.returncode != 0 and "RESULT" not in p.stdout
