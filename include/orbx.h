@@ -133,7 +133,8 @@ int orbx_match_init_batch_device(orbx_ctx* ctx, int n_pairs, const int32_t* h_fi
 #define ORBX_STAGE_SELECT 2 /* quadtree selection incl. its transfers */
 #define ORBX_STAGE_DESCRIBE 3
 #define ORBX_STAGE_MATCH 4
-#define ORBX_STAGE_COUNT 5
+#define ORBX_STAGE_BLUR 5 /* whole-level Gaussian blur (runs between FAST/selection and DESCRIBE) */
+#define ORBX_STAGE_COUNT 6
 /* enable: record hipEvents around every stage; accumulated device ms and launch counts since the
  * last reset are returned by orbx_profile_get (arrays of ORBX_STAGE_COUNT). */
 int orbx_profile_enable(orbx_ctx* ctx, int on);
