@@ -103,8 +103,10 @@ def main():
     ext = orbx.ORBextractor(*PARAMS, max_width=W, max_height=H, max_batch=B, device=local_rank)
 
     def step():
-        ext.extract_batch_device(d_img, B, W, H, W, W * H, d_k, d_d, d_n, cap)
-        ext.match_pairs_device(first, second, d_k, d_d, d_n, (0, W, 0, H), d_m, d_nm, None, 100, 0.9, True, cap)
+        # one call = the whole hot path of the batch (orbx_extract_match_batch_device): extraction of B frames and
+        # SearchForInitialization of the B/2 consecutive pairs
+        ext.extract_match_batch_device(d_img, B, W, H, W, W * H, d_k, d_d, d_n, first, second, (0, W, 0, H), d_m, d_nm, None,
+                                       100, 0.9, True, cap)
         if world > 1:
             sharding.gather_counts(d_n, counts_all)  # RCCL all_gather over xGMI
 

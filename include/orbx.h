@@ -127,6 +127,18 @@ int orbx_match_init_batch_device(orbx_ctx* ctx, int n_pairs, const int32_t* h_fi
                                  int check_orientation, int32_t* d_matches12, int32_t* d_nmatches,
                                  int32_t* d_stats);
 
+/* The whole hot path of one batch in one call: orbx_extract_batch_device followed by
+ * orbx_match_init_batch_device on pairs of frames of the same batch (first[p], second[p] in [0, n_frames)).
+ * Large batches are issued as two half-batches on two HIP streams, and a pair whose frames lie in the same half
+ * is matched right behind that half's extraction, so the latency-bound stages (quadtree selection, sequential
+ * matching) of one half overlap the arithmetic-bound stages of the other.  Results are identical to the two
+ * separate calls.  n_pairs may be 0. */
+int orbx_extract_match_batch_device(orbx_ctx* ctx, int n_frames, const uint8_t* d_imgs, int width, int height,
+                                    int stride, size_t frame_stride_bytes, orbx_keypoint* d_kps, uint8_t* d_desc32,
+                                    int capacity, int32_t* d_n_out, int n_pairs, const int32_t* h_first,
+                                    const int32_t* h_second, const orbx_bounds* bounds, int window_size, float nnratio,
+                                    int check_orientation, int32_t* d_matches12, int32_t* d_nmatches, int32_t* d_stats);
+
 /* ---- measurement hooks (bench.py; HIP events on the ctx stream) ---------------------------- */
 #define ORBX_STAGE_PYRAMID 0
 #define ORBX_STAGE_FAST 1

@@ -87,6 +87,8 @@ def lib() -> ctypes.CDLL:
                                   ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_Stats)]
     L.orbx_match_init_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, ctypes.POINTER(_Bounds), i32, f32, i32,
                                                vp, vp, vp]
+    L.orbx_extract_match_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, sz, vp, vp, i32, vp, i32, vp, vp,
+                                                  ctypes.POINTER(_Bounds), i32, f32, i32, vp, vp, vp]
     L.orbx_profile_enable.argtypes = [vp, i32]
     L.orbx_profile_reset.argtypes = [vp]
     L.orbx_profile_get.argtypes = [vp, vp, vp]
@@ -233,6 +235,22 @@ class ORBextractor:
                                                  float(nnratio), int(bool(checkOri)), _ptr(d_matches12), _ptr(d_nmatches),
                                                  _ptr(d_stats))
         self._check(r, "orbx_match_init_batch_device")
+
+    def extract_match_batch_device(self, d_imgs, n_frames: int, width: int, height: int, stride: int, frame_stride: int,
+                                   d_kps, d_desc, d_n, first: np.ndarray, second: np.ndarray,
+                                   bounds: Tuple[int, int, int, int], d_matches12, d_nmatches, d_stats=None,
+                                   windowSize: int = 100, nnratio: float = 0.9, checkOri: bool = True,
+                                   capacity: Optional[int] = None) -> None:
+        """The whole hot path of one batch (extract + match of pairs inside the batch), two half-batches on two streams."""
+        first = np.ascontiguousarray(first, np.int32)
+        second = np.ascontiguousarray(second, np.int32)
+        b = _Bounds(*[int(v) for v in bounds])
+        r = self._L.orbx_extract_match_batch_device(self._h, int(n_frames), _ptr(d_imgs), int(width), int(height), int(stride),
+                                                    int(frame_stride), _ptr(d_kps), _ptr(d_desc), int(capacity or self.capacity),
+                                                    _ptr(d_n), len(first), _ptr(first), _ptr(second), ctypes.byref(b),
+                                                    int(windowSize), float(nnratio), int(bool(checkOri)), _ptr(d_matches12),
+                                                    _ptr(d_nmatches), _ptr(d_stats))
+        self._check(r, "orbx_extract_match_batch_device")
 
     # -- mvImagePyramid (hpp:111) ----------------------------------------------------------------
     def level_size(self, level: int) -> Tuple[int, int]:

@@ -22,7 +22,7 @@ namespace orbx {
 
 hipError_t launch_resize(hipStream_t st, int nFrames, const uint8_t* src, long long srcFrameStride, int sw, int sh, int sstride,
                          uint8_t* dst, long long dstFrameStride, int dw, int dh, int dstride, const ResizeTab* xtab,
-                         const ResizeTab* ytab);
+                         const ResizeTab* ytab, int dwordPath);
 hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, int img0Aligned,
                        const uint8_t* pyr, const Geom& g, uint32_t* cand, int* candCount, int* overflow);
 hipError_t launch_blur(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, int img0Aligned,
@@ -35,7 +35,7 @@ hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const 
                                  orbx_keypoint* kps, uint8_t* desc, int capacity);
 hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int* dSecond, const orbx_keypoint* kps,
                         const uint8_t* desc, const int* nkp, int capacity, orbx_bounds b, int window, float nnratio, int checkOri,
-                        int* matches12, int* nmatches, int* stats, int* scratch);
+                        int* matches12, int* nmatches, int* stats, int* scratch, int pair0);
 hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, const int* candCount, const OctLaunch& P,
                          SelKp* selStage, int* nselLevel, uint8_t* scratch, int maxQuota);
 hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage, const int* nselLevel, const OctLaunch& P,
@@ -111,9 +111,13 @@ struct orbx_ctx {
   long long lastFrameStride0 = 0;
   int lastB = 0;
 
+  hipStream_t st2 = nullptr;  // second stream: half-batches overlap (extractCore)
+  hipEvent_t evFork = nullptr, evJoin = nullptr;
+
   // profiling
   bool prof = false;
-  hipEvent_t ev[ORBX_STAGE_COUNT][2]{};
+  hipEvent_t ev[2][ORBX_STAGE_COUNT][2]{};
+  bool used[2][ORBX_STAGE_COUNT]{};
   double ms[ORBX_STAGE_COUNT]{};
   int64_t launches[ORBX_STAGE_COUNT]{};
 
@@ -259,6 +263,10 @@ int buildGeometry(orbx_ctx* c, int w, int h, int stride0, Geom* out, std::vector
           const int c0 = cvRoundF((1.f - fx) * 2048), c1 = cvRoundF(fx * 2048);
           tab->push_back(ResizeTab{sx, (c0 & 0xffff) | (c1 << 16)});
         }
+        int span = 0;
+        for (int dx = 0; dx + 3 < dwPad; dx += 4)
+          span = std::max(span, (*tab)[L.xtabOff + dx + 3].ofs - (*tab)[L.xtabOff + dx].ofs);
+        L.resizeSpanOk = span <= 7 ? 1 : 0;
         tabOff += dwPad;
         L.ytabOff = tabOff;
         for (int dy = 0; dy < dh; dy++) {
@@ -353,24 +361,28 @@ int ensureGeometry(orbx_ctx* ctx, int w, int h, int stride0) {
 
 struct StageTimer {
   orbx_ctx* c;
-  int stage;
-  StageTimer(orbx_ctx* c_, int s) : c(c_), stage(s) {
-    if (c->prof) (void)hipEventRecord(c->ev[s][0], c->st);
+  int stage, si;
+  hipStream_t st;
+  StageTimer(orbx_ctx* c_, int s, int si_, hipStream_t st_) : c(c_), stage(s), si(si_), st(st_) {
+    if (c->prof) (void)hipEventRecord(c->ev[si][s][0], st);
   }
   void stop(int nLaunches) {
     if (c->prof) {
-      (void)hipEventRecord(c->ev[stage][1], c->st);
+      (void)hipEventRecord(c->ev[si][stage][1], st);
       c->launches[stage] += nLaunches;
+      c->used[si][stage] = true;
     }
   }
 };
-void collectProfile(orbx_ctx* c, const bool used[ORBX_STAGE_COUNT]) {
+void collectProfile(orbx_ctx* c) {
   if (!c->prof) return;
-  for (int s = 0; s < ORBX_STAGE_COUNT; s++) {
-    if (!used[s]) continue;
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, c->ev[s][0], c->ev[s][1]) == hipSuccess) c->ms[s] += ms;
-  }
+  for (int si = 0; si < 2; si++)
+    for (int s = 0; s < ORBX_STAGE_COUNT; s++) {
+      if (!c->used[si][s]) continue;
+      c->used[si][s] = false;
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, c->ev[si][s][0], c->ev[si][s][1]) == hipSuccess) c->ms[s] += ms;
+    }
 }
 
 // candidate order of the reference: cell row, cell col, y, x (cpp:1078-1137; cv::FAST emits row-major)
@@ -380,75 +392,156 @@ inline uint64_t candOrderKey(const LevelGeom& L, uint32_t e) {
   return ((uint64_t)(cr * L.nCols + cc) << 24) | ((uint64_t)y << 12) | (uint64_t)x;
 }
 
-// The whole extraction of one batch.  d_img0: device pointer of frame 0 / level 0.
+struct ExtractArgs {
+  const uint8_t* dImg0;
+  int stride0;
+  long long frameStride0;
+  int aligned0;
+  orbx_keypoint* dKps;
+  uint8_t* dDesc;
+  int capacity;
+};
+
+// issues every kernel of the extraction of frames [f0, f0 + n) on stream `st` (stream slot si); no synchronisation
+int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const ExtractArgs& a) {
+  Geom g = ctx->g;
+  g.frame0 = f0;
+  OctLaunch oct = ctx->oct;
+  oct.frame0 = f0;
+  const int nl = g.nlevels;
+  HIPCHK(hipMemsetAsync(ctx->dCandCount + (size_t)f0 * nl, 0, sizeof(int) * (size_t)n * nl, st));
+  {
+    StageTimer tm(ctx, ORBX_STAGE_PYRAMID, si, st);
+    for (int l = 1; l < nl; l++) {
+      const LevelGeom& S = g.L[l - 1];
+      const LevelGeom& D = g.L[l];
+      const uint8_t* src = l == 1 ? a.dImg0 : ctx->dPyr + S.imgOff;
+      const long long sfs = l == 1 ? a.frameStride0 : S.frameStride;
+      HIPCHK(launch_resize(st, n, src + (long long)f0 * sfs, sfs, S.w, S.h, S.stride, ctx->dPyr + D.imgOff + (long long)f0 * D.frameStride,
+                           D.frameStride, D.w, D.h, D.stride, ctx->dTab + D.xtabOff, ctx->dTab + D.ytabOff,
+                           D.resizeSpanOk && (l > 1 || a.aligned0)));
+    }
+    if (nl > 1) tm.stop(nl - 1);
+  }
+  {
+    StageTimer tm(ctx, ORBX_STAGE_FAST, si, st);
+    HIPCHK(launch_fast(st, n, a.dImg0, a.frameStride0, a.aligned0, ctx->dPyr, g, ctx->dCand, ctx->dCandCount, ctx->dOverflow));
+    tm.stop(1);
+  }
+  {  // selection stage: quadtree per (frame, level), then level-major compaction
+    StageTimer tm(ctx, ORBX_STAGE_SELECT, si, st);
+    HIPCHK(launch_octree(st, n, ctx->dCand, ctx->dCandCount, oct, ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, ctx->maxQuota));
+    HIPCHK(launch_sel_compact(st, n, ctx->dSelStage, ctx->dNselLevel, oct, ctx->dSel, ctx->dNsel, g.selCap, ctx->dOverflow + 1));
+    tm.stop(ctx->maxQuota <= 256 ? 3 : 2);
+  }
+  static const bool useLevelBlur = getenv("ORBX_LEVEL_BLUR") != nullptr;  // A/B switch between the two describe designs
+  if (useLevelBlur) {
+    {
+      StageTimer tm(ctx, ORBX_STAGE_BLUR, si, st);
+      HIPCHK(launch_blur(st, n, a.dImg0, a.frameStride0, a.aligned0, ctx->dPyr, g, ctx->dBlur));
+      tm.stop(1);
+    }
+    StageTimer tm(ctx, ORBX_STAGE_DESCRIBE, si, st);
+    HIPCHK(launch_describe(st, n, g.selCap, a.dImg0, a.frameStride0, ctx->dPyr, ctx->dBlur, g, ctx->dSel, ctx->dNsel, a.dKps,
+                           a.dDesc, a.capacity));
+    tm.stop(1);
+  } else {
+    StageTimer tm(ctx, ORBX_STAGE_DESCRIBE, si, st);
+    HIPCHK(launch_describe_patch(st, n, g.selCap, a.dImg0, a.frameStride0, a.aligned0, ctx->dPyr, g, ctx->dSel, ctx->dNsel,
+                                 a.dKps, a.dDesc, a.capacity));
+    tm.stop(1);
+  }
+  return ORBX_OK;
+}
+
+struct MatchArgs {  // optional matching fused behind the extraction (pairs of frames of the same batch)
+  int nPairs = 0;
+  const int32_t* hFirst = nullptr;
+  const int32_t* hSecond = nullptr;
+  orbx_bounds b{};
+  int window = 0;
+  float nnratio = 0;
+  int checkOri = 0;
+  int32_t* dMatches12 = nullptr;
+  int32_t* dNmatches = nullptr;
+  int32_t* dStats = nullptr;
+};
+
+int ensureMatchScratch(orbx_ctx* ctx, int nPairs, int capacity);
+
+int issueMatch(orbx_ctx* ctx, int si, hipStream_t st, int pair0, int n, const MatchArgs& m, const orbx_keypoint* dKps,
+               const uint8_t* dDesc, const int* dN, int capacity) {
+  if (n <= 0) return ORBX_OK;
+  StageTimer tm(ctx, ORBX_STAGE_MATCH, si, st);
+  HIPCHK(launch_match(st, n, ctx->dPairs, ctx->dPairs + m.nPairs, dKps, dDesc, dN, capacity, m.b, m.window, m.nnratio, m.checkOri,
+                      m.dMatches12, m.dNmatches, m.dStats, ctx->dMatchScratch, pair0));
+  tm.stop(2);  // k_match_wave + k_match (pending pairs only)
+  return ORBX_OK;
+}
+
+// The whole extraction (and optionally the pair matching) of one batch.  d_img0: device pointer of frame 0 / level 0.
+// Large batches are issued as two half-batches on two streams so that the latency-bound stages of one half (quadtree
+// selection, matching) overlap the VALU-bound stages of the other (FAST, descriptors).
 int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int stride0, long long frameStride0,
-                orbx_keypoint* dKps, uint8_t* dDesc, int capacity, int* dNout) {
+                orbx_keypoint* dKps, uint8_t* dDesc, int capacity, int* dNout, const MatchArgs* match) {
   if (B <= 0) return ORBX_E_BADARG;
   if (B > ctx->maxB) { ctx->err = "batch larger than max_batch"; return ORBX_E_BADARG; }
   if (capacity < ctx->selCap) return ORBX_E_CAPACITY;
   int r = ensureGeometry(ctx, w, h, stride0);
   if (r != ORBX_OK) return r;
-  const Geom& g = ctx->g;
-  const int nl = g.nlevels;
   hipStream_t st = ctx->st;
-  const int aligned0 = (((uintptr_t)dImg0 | (uintptr_t)stride0 | (uintptr_t)frameStride0) & 3) == 0;
-  bool used[ORBX_STAGE_COUNT] = {false, false, false, false, false, false};
+  ExtractArgs a;
+  a.dImg0 = dImg0; a.stride0 = stride0; a.frameStride0 = frameStride0;
+  a.aligned0 = (((uintptr_t)dImg0 | (uintptr_t)stride0 | (uintptr_t)frameStride0) & 3) == 0;
+  a.dKps = dKps; a.dDesc = dDesc; a.capacity = capacity;
+  int* dN = dNout ? dNout : ctx->dNsel;
+  const int nPairs = match ? match->nPairs : 0;
+  if (nPairs > 0) {
+    if (capacity >= (1 << 20)) return ORBX_E_BADARG;
+    for (int p = 0; p < nPairs; p++)
+      if (match->hFirst[p] < 0 || match->hFirst[p] >= B || match->hSecond[p] < 0 || match->hSecond[p] >= B) return ORBX_E_BADARG;
+    r = ensureMatchScratch(ctx, nPairs, capacity);
+    if (r != ORBX_OK) return r;
+    HIPCHK(hipMemcpyAsync(ctx->dPairs, match->hFirst, sizeof(int) * nPairs, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->dPairs + nPairs, match->hSecond, sizeof(int) * nPairs, hipMemcpyHostToDevice, st));
+  }
+  HIPCHK(hipMemsetAsync(ctx->dOverflow, 0, sizeof(int) * 2, st));  // candidate-overflow + selection-error flags
 
-  HIPCHK(hipMemsetAsync(ctx->dCandCount, 0, sizeof(int) * ((size_t)ctx->maxB * nl + 2), st));  // counts + overflow + selection-error flags
-  {
-    StageTimer tm(ctx, ORBX_STAGE_PYRAMID);
-    for (int l = 1; l < nl; l++) {
-      const LevelGeom& S = g.L[l - 1];
-      const LevelGeom& D = g.L[l];
-      const uint8_t* src = l == 1 ? dImg0 : ctx->dPyr + S.imgOff;
-      const long long sfs = l == 1 ? frameStride0 : S.frameStride;
-      HIPCHK(launch_resize(st, B, src, sfs, S.w, S.h, S.stride, ctx->dPyr + D.imgOff, D.frameStride, D.w, D.h, D.stride,
-                           ctx->dTab + D.xtabOff, ctx->dTab + D.ytabOff));
-    }
-    tm.stop(nl - 1);
-    used[ORBX_STAGE_PYRAMID] = nl > 1;
+  static const int splitMin = getenv("ORBX_NO_SPLIT") ? (1 << 30) : 16;
+  const bool split = ctx->st2 != nullptr && B >= splitMin;
+  const int n0 = split ? ((B / 2) & ~1) : B;
+  // pairs whose frames both lie in one half can run right behind that half's extraction, on its stream; this needs
+  // the pair list to be ordered [half 0][half 1][rest] (true for consecutive pairs (2k, 2k+1))
+  int p0 = 0, p1 = 0;
+  if (nPairs > 0 && split) {
+    while (p0 < nPairs && match->hFirst[p0] < n0 && match->hSecond[p0] < n0) p0++;
+    p1 = p0;
+    while (p1 < nPairs && match->hFirst[p1] >= n0 && match->hSecond[p1] >= n0) p1++;
   }
-  {
-    StageTimer tm(ctx, ORBX_STAGE_FAST);
-    HIPCHK(launch_fast(st, B, dImg0, frameStride0, aligned0, ctx->dPyr, g, ctx->dCand, ctx->dCandCount, ctx->dOverflow));
-    tm.stop(1);
-    used[ORBX_STAGE_FAST] = true;
-  }
-  // ---- selection stage on the device: quadtree per (frame, level), then level-major compaction ----
-  {
-    StageTimer tm(ctx, ORBX_STAGE_SELECT);
-    HIPCHK(launch_octree(st, B, ctx->dCand, ctx->dCandCount, ctx->oct, ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch,
-                         ctx->maxQuota));
-    HIPCHK(launch_sel_compact(st, B, ctx->dSelStage, ctx->dNselLevel, ctx->oct, ctx->dSel, ctx->dNsel, g.selCap,
-                              ctx->dOverflow + 1));
-    tm.stop(ctx->maxQuota <= 256 ? 3 : 2);
-    used[ORBX_STAGE_SELECT] = true;
-  }
-  static const bool useLevelBlur = getenv("ORBX_LEVEL_BLUR") != nullptr;  // A/B switch between the two describe designs
-  if (useLevelBlur) {
-    {
-      StageTimer tm(ctx, ORBX_STAGE_BLUR);
-      HIPCHK(launch_blur(st, B, dImg0, frameStride0, aligned0, ctx->dPyr, g, ctx->dBlur));
-      tm.stop(1);
-      used[ORBX_STAGE_BLUR] = true;
-    }
-    StageTimer tm(ctx, ORBX_STAGE_DESCRIBE);
-    HIPCHK(launch_describe(st, B, g.selCap, dImg0, frameStride0, ctx->dPyr, ctx->dBlur, g, ctx->dSel, ctx->dNsel, dKps, dDesc,
-                           capacity));
-    tm.stop(1);
-    used[ORBX_STAGE_DESCRIBE] = true;
+  if (split) {
+    HIPCHK(hipEventRecord(ctx->evFork, st));
+    HIPCHK(hipStreamWaitEvent(ctx->st2, ctx->evFork, 0));
+    r = issueExtract(ctx, 0, st, 0, n0, a);
+    if (r != ORBX_OK) return r;
+    if (dNout) HIPCHK(hipMemcpyAsync(dNout, ctx->dNsel, sizeof(int) * n0, hipMemcpyDeviceToDevice, st));
+    if (nPairs > 0) { r = issueMatch(ctx, 0, st, 0, p0, *match, dKps, dDesc, dN, capacity); if (r != ORBX_OK) return r; }
+    r = issueExtract(ctx, 1, ctx->st2, n0, B - n0, a);
+    if (r != ORBX_OK) return r;
+    if (dNout) HIPCHK(hipMemcpyAsync(dNout + n0, ctx->dNsel + n0, sizeof(int) * (B - n0), hipMemcpyDeviceToDevice, ctx->st2));
+    if (nPairs > 0) { r = issueMatch(ctx, 1, ctx->st2, p0, p1 - p0, *match, dKps, dDesc, dN, capacity); if (r != ORBX_OK) return r; }
+    HIPCHK(hipEventRecord(ctx->evJoin, ctx->st2));
+    HIPCHK(hipStreamWaitEvent(st, ctx->evJoin, 0));
+    if (nPairs > p1) { r = issueMatch(ctx, 0, st, p1, nPairs - p1, *match, dKps, dDesc, dN, capacity); if (r != ORBX_OK) return r; }
   } else {
-    StageTimer tm(ctx, ORBX_STAGE_DESCRIBE);
-    HIPCHK(launch_describe_patch(st, B, g.selCap, dImg0, frameStride0, aligned0, ctx->dPyr, g, ctx->dSel, ctx->dNsel, dKps,
-                                 dDesc, capacity));
-    tm.stop(1);
-    used[ORBX_STAGE_DESCRIBE] = true;
+    r = issueExtract(ctx, 0, st, 0, B, a);
+    if (r != ORBX_OK) return r;
+    if (dNout) HIPCHK(hipMemcpyAsync(dNout, ctx->dNsel, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
+    if (nPairs > 0) { r = issueMatch(ctx, 0, st, 0, nPairs, *match, dKps, dDesc, dN, capacity); if (r != ORBX_OK) return r; }
   }
-  if (dNout) HIPCHK(hipMemcpyAsync(dNout, ctx->dNsel, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(ctx->hNsel, ctx->dNsel, sizeof(int) * B, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(ctx->hFlags, ctx->dOverflow, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  collectProfile(ctx, used);
+  collectProfile(ctx);
   ctx->lastImg0 = dImg0;
   ctx->lastFrameStride0 = frameStride0;
   ctx->lastB = B;
@@ -532,9 +625,13 @@ int orbx_create(const orbx_params* params, int device_id, int max_width, int max
   ALLOCH(ctx->hFlags, 2 * sizeof(int));
 #undef ALLOC
 #undef ALLOCH
-  for (int s2 = 0; s2 < ORBX_STAGE_COUNT; s2++)
-    for (int k = 0; k < 2; k++)
-      if (hipEventCreate(&ctx->ev[s2][k]) != hipSuccess) return fail(ORBX_E_HIP);
+  for (int si = 0; si < 2; si++)
+    for (int s2 = 0; s2 < ORBX_STAGE_COUNT; s2++)
+      for (int k = 0; k < 2; k++)
+        if (hipEventCreate(&ctx->ev[si][s2][k]) != hipSuccess) return fail(ORBX_E_HIP);
+  if (hipStreamCreateWithFlags(&ctx->st2, hipStreamNonBlocking) != hipSuccess) return fail(ORBX_E_HIP);
+  if (hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming) != hipSuccess) return fail(ORBX_E_HIP);
+  if (hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming) != hipSuccess) return fail(ORBX_E_HIP);
   *out = ctx;
   return ORBX_OK;
 }
@@ -551,9 +648,14 @@ void orbx_destroy(orbx_ctx* ctx) {
   void* host[] = {ctx->hNsel, ctx->hFlags};
   for (void* p : host)
     if (p) (void)hipHostFree(p);
-  for (int s = 0; s < ORBX_STAGE_COUNT; s++)
-    for (int k = 0; k < 2; k++)
-      if (ctx->ev[s][k]) (void)hipEventDestroy(ctx->ev[s][k]);
+  if (ctx->st2) (void)hipStreamSynchronize(ctx->st2);
+  for (int si = 0; si < 2; si++)
+    for (int s = 0; s < ORBX_STAGE_COUNT; s++)
+      for (int k = 0; k < 2; k++)
+        if (ctx->ev[si][s][k]) (void)hipEventDestroy(ctx->ev[si][s][k]);
+  if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
+  if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
+  if (ctx->st2) (void)hipStreamDestroy(ctx->st2);
   if (ctx->ownStream && ctx->st) (void)hipStreamDestroy(ctx->st);
   delete ctx;
 }
@@ -588,7 +690,7 @@ int orbx_extract_batch_device(orbx_ctx* ctx, int n_frames, const uint8_t* d_imgs
   if (!d_kps || !d_desc32 || stride < width) return ORBX_E_BADARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
   return extractCore(ctx, n_frames, d_imgs, width, height, stride, (long long)frame_stride_bytes, d_kps, d_desc32, capacity,
-                     d_n_out);
+                     d_n_out, nullptr);
 }
 
 int orbx_extract_batch(orbx_ctx* ctx, int n_frames, const uint8_t* imgs, int width, int height, int stride,
@@ -608,7 +710,7 @@ int orbx_extract_batch(orbx_ctx* ctx, int n_frames, const uint8_t* imgs, int wid
     for (int f = 0; f < B; f++)
       HIPCHK(hipMemcpy2DAsync(ctx->dIn + f * dfs, dstride, imgs + (size_t)(f0 + f) * frame_stride_bytes, stride, width, height,
                               hipMemcpyHostToDevice, ctx->st));
-    int r = extractCore(ctx, B, ctx->dIn, width, height, dstride, (long long)dfs, ctx->dKps, ctx->dDesc, cap, nullptr);
+    int r = extractCore(ctx, B, ctx->dIn, width, height, dstride, (long long)dfs, ctx->dKps, ctx->dDesc, cap, nullptr, nullptr);
     if (r != ORBX_OK) return r;
     for (int f = 0; f < B; f++) {
       const int n = ctx->hNsel[f];
@@ -690,7 +792,9 @@ int orbx_download_pyramid(orbx_ctx* ctx, int frame, int level, int border, uint8
 }
 
 // ---- matching ------------------------------------------------------------------------------------
-static int ensureMatchScratch(orbx_ctx* ctx, int nPairs, int capacity) {
+}  // extern "C"
+namespace {
+int ensureMatchScratch(orbx_ctx* ctx, int nPairs, int capacity) {
   const size_t need = (size_t)nPairs * capacity * 4;
   if (need > ctx->matchScratchInts) {
     if (ctx->dMatchScratch) (void)hipFree(ctx->dMatchScratch);
@@ -708,6 +812,9 @@ static int ensureMatchScratch(orbx_ctx* ctx, int nPairs, int capacity) {
   }
   return ORBX_OK;
 }
+}  // namespace
+
+extern "C" {
 
 int orbx_match_init_batch_device(orbx_ctx* ctx, int n_pairs, const int32_t* h_first, const int32_t* h_second,
                                  const orbx_keypoint* d_kps, const uint8_t* d_desc32, const int32_t* d_n, int capacity,
@@ -721,18 +828,36 @@ int orbx_match_init_batch_device(orbx_ctx* ctx, int n_pairs, const int32_t* h_fi
   if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
   int r = ensureMatchScratch(ctx, n_pairs, capacity);
   if (r != ORBX_OK) return r;
-  bool used[ORBX_STAGE_COUNT] = {false, false, false, false, true, false};
   HIPCHK(hipMemcpyAsync(ctx->dPairs, h_first, sizeof(int) * n_pairs, hipMemcpyHostToDevice, ctx->st));
   HIPCHK(hipMemcpyAsync(ctx->dPairs + n_pairs, h_second, sizeof(int) * n_pairs, hipMemcpyHostToDevice, ctx->st));
-  {
-    StageTimer tm(ctx, ORBX_STAGE_MATCH);
-    HIPCHK(launch_match(ctx->st, n_pairs, ctx->dPairs, ctx->dPairs + n_pairs, d_kps, d_desc32, d_n, capacity, *bounds, window_size,
-                        nnratio, check_orientation, d_matches12, d_nmatches, d_stats, ctx->dMatchScratch));
-    tm.stop(2);  // k_match_wave + k_match (pending pairs only)
-  }
+  MatchArgs m;
+  m.nPairs = n_pairs; m.b = *bounds; m.window = window_size; m.nnratio = nnratio; m.checkOri = check_orientation;
+  m.dMatches12 = d_matches12; m.dNmatches = d_nmatches; m.dStats = d_stats;
+  r = issueMatch(ctx, 0, ctx->st, 0, n_pairs, m, d_kps, d_desc32, d_n, capacity);
+  if (r != ORBX_OK) return r;
   HIPCHK(hipStreamSynchronize(ctx->st));
-  collectProfile(ctx, used);
+  collectProfile(ctx);
   return ORBX_OK;
+}
+
+int orbx_extract_match_batch_device(orbx_ctx* ctx, int n_frames, const uint8_t* d_imgs, int width, int height, int stride,
+                                    size_t frame_stride_bytes, orbx_keypoint* d_kps, uint8_t* d_desc32, int capacity,
+                                    int32_t* d_n_out, int n_pairs, const int32_t* h_first, const int32_t* h_second,
+                                    const orbx_bounds* bounds, int window_size, float nnratio, int check_orientation,
+                                    int32_t* d_matches12, int32_t* d_nmatches, int32_t* d_stats) {
+  if (!ctx) return ORBX_E_BADARG;
+  if (!d_imgs || width <= 0 || height <= 0) return ORBX_E_EMPTY;
+  if (!d_kps || !d_desc32 || !d_n_out || stride < width || n_pairs < 0) return ORBX_E_BADARG;
+  if (n_pairs > 0 && (!h_first || !h_second || !bounds || !d_matches12 || !d_nmatches || bounds->max_x <= bounds->min_x ||
+                      bounds->max_y <= bounds->min_y))
+    return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  MatchArgs m;
+  m.nPairs = n_pairs; m.hFirst = h_first; m.hSecond = h_second;
+  if (n_pairs > 0) { m.b = *bounds; m.window = window_size; m.nnratio = nnratio; m.checkOri = check_orientation; }
+  m.dMatches12 = d_matches12; m.dNmatches = d_nmatches; m.dStats = d_stats;
+  return extractCore(ctx, n_frames, d_imgs, width, height, stride, (long long)frame_stride_bytes, d_kps, d_desc32, capacity,
+                     d_n_out, &m);
 }
 
 int orbx_match_init(orbx_ctx* ctx, const orbx_keypoint* k1, const uint8_t* d1, int n1, const orbx_keypoint* k2, const uint8_t* d2,

@@ -30,7 +30,8 @@ struct LevelGeom {
   int64_t blurFrameStride;    // bytes between consecutive frames of this blurred level
   int32_t blurStride;         // row stride of the blurred level (multiple of 64)
   int32_t blurTileBase;       // index of this level's first 128x32 blur tile in the flattened tile list
-  int32_t blurTilesX, pad2_;
+  int32_t blurTilesX;
+  int32_t resizeSpanOk;       // 1 if the taps of any 4 consecutive outputs span <= 8 source pixels (k_resize_dw usable)
 };
 
 struct Geom {
@@ -39,6 +40,8 @@ struct Geom {
   int32_t iniTh, minTh;
   int32_t selCap;             // per-frame capacity of the selected-keypoint list (== output capacity)
   int32_t nBlurTiles;
+  int32_t frame0;             // first frame of this launch (a batch may be issued as several sub-batches / streams)
+  int32_t pad_;
   LevelGeom L[ORBX_MAX_LEVELS];
 };
 
@@ -75,6 +78,7 @@ struct OctLaunch {
   int32_t selOff[ORBX_MAX_LEVELS];     // offset of the level inside one frame's SelKp staging area
   int32_t scrNMax[ORBX_MAX_LEVELS];
   int32_t nlevels, selStride;          // SelKp staging entries per frame
+  int32_t frame0, pad_;                // first frame of this launch
 };
 
 #define ORBX_OCT_MAX_CAND ((1 << 19) - 1)  // candidates per (frame, level) the selection stage can index

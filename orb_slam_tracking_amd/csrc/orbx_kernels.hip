@@ -54,6 +54,53 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
   *reinterpret_cast<uint32_t*>(dst + (long long)f * dstFrameStride + (long long)dy * dstride + dx0) = packed;
 }
 
+// Same arithmetic, but the source taps of the 4 outputs are fetched as 3 aligned dwords per source row (the taps of
+// 4 consecutive outputs span at most 11 bytes from the aligned start when the scale is <= 2) instead of 8 byte loads,
+// and extracted with v_alignbyte.  Needs 4-byte aligned source rows; the launcher falls back to k_resize otherwise.
+__global__ __launch_bounds__(256) void k_resize_dw(const uint8_t* __restrict__ src, long long srcFrameStride, int sw, int sh,
+                                                   int sstride, uint8_t* __restrict__ dst, long long dstFrameStride, int dw,
+                                                   int dh, int dstride, const ResizeTab* __restrict__ xtab,
+                                                   const ResizeTab* __restrict__ ytab) {
+  const int f = blockIdx.z;
+  const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+  const int dy = blockIdx.y * 4 + threadIdx.y;
+  if (dx0 >= dw || dy >= dh) return;
+  const ResizeTab ty = ytab[dy];
+  const int sy0 = min(max(ty.ofs, 0), sh - 1), sy1 = min(max(ty.ofs + 1, 0), sh - 1);
+  const int b0 = ty.coef & 0xffff, b1 = ty.coef >> 16;
+  const uint8_t* S0 = src + (long long)f * srcFrameStride + (long long)sy0 * sstride;
+  const uint8_t* S1 = src + (long long)f * srcFrameStride + (long long)sy1 * sstride;
+  const uint4 tA = reinterpret_cast<const uint4*>(xtab + dx0)[0];  // entries dx0, dx0+1 (ofs, coef, ofs, coef)
+  const uint4 tB = reinterpret_cast<const uint4*>(xtab + dx0)[1];  // entries dx0+2, dx0+3
+  const int sxs[4] = {(int)tA.x, (int)tA.z, (int)tB.x, (int)tB.z};
+  const uint32_t cfs[4] = {tA.y, tA.w, tB.y, tB.w};
+  const int base = sxs[0] & ~3;
+  const int lim = (sw - 1) & ~3;  // last dword that holds a pixel of the row: never read beyond it
+  const int o0 = base, o1 = min(base + 4, lim), o2 = min(base + 8, lim);
+  const uint32_t r0a = *reinterpret_cast<const uint32_t*>(S0 + o0), r0b = *reinterpret_cast<const uint32_t*>(S0 + o1),
+                 r0c = *reinterpret_cast<const uint32_t*>(S0 + o2);
+  const uint32_t r1a = *reinterpret_cast<const uint32_t*>(S1 + o0), r1b = *reinterpret_cast<const uint32_t*>(S1 + o1),
+                 r1c = *reinterpret_cast<const uint32_t*>(S1 + o2);
+  uint32_t packed = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int k = sxs[i] - base;  // 0..10
+    const int sh8 = k & 3;
+    // 32-bit window starting at byte k: low byte = S[sx], next byte = S[sx+1] (a clamped or missing dword can only
+    // supply bytes beyond the last pixel, whose weight is 0)
+    const uint32_t lo0 = k < 4 ? r0a : (k < 8 ? r0b : r0c), hi0 = k < 4 ? r0b : r0c;
+    const uint32_t lo1 = k < 4 ? r1a : (k < 8 ? r1b : r1c), hi1 = k < 4 ? r1b : r1c;
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(hi0, lo0, sh8), w1 = __builtin_amdgcn_alignbyte(hi1, lo1, sh8);
+    const int a0 = cfs[i] & 0xffff, a1 = cfs[i] >> 16;
+    const int t0 = (int)(w0 & 255) * a0 + (int)((w0 >> 8) & 255) * a1;
+    const int t1 = (int)(w1 & 255) * a0 + (int)((w1 >> 8) & 255) * a1;
+    int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+    v = min(max(v, 0), 255);
+    packed |= (uint32_t)v << (8 * i);
+  }
+  *reinterpret_cast<uint32_t*>(dst + (long long)f * dstFrameStride + (long long)dy * dstride + dx0) = packed;
+}
+
 // =================================================================================================
 // K2  FAST-9-16 per cell.  One workgroup (256 threads) per (cell, frame).
 //   strength(p) = max over the 16 arcs of 9 contiguous ring pixels of min(+-(v - p_k))
@@ -86,7 +133,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img0, 
   __shared__ int nList, nOut, outBase;
 
   const int t = threadIdx.x;
-  const int f = blockIdx.y;
+  const int f = blockIdx.y + g.frame0;
   int level = 0;
   const int cid = blockIdx.x;
   while (level + 1 < g.nlevels && cid >= g.L[level + 1].cellBase) level++;
@@ -283,7 +330,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ img0, 
   // 2rp (low half) and 2rp+1 (high half) at column x0+c
   __shared__ __attribute__((aligned(16))) uint32_t in32[BLUR_ROWS * BLUR_IN_WORDS];
   __shared__ __attribute__((aligned(16))) uint32_t hz2[(BLUR_ROWS / 2) * BLUR_W];
-  const int t = threadIdx.x, f = blockIdx.y;
+  const int t = threadIdx.x, f = blockIdx.y + g.frame0;
   int level = 0;
   const int tid = blockIdx.x;
   while (level + 1 < g.nlevels && tid >= g.L[level + 1].blurTileBase) level++;
@@ -387,7 +434,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ im
                                                   const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                   const Geom g, const SelKp* __restrict__ sel, const int* __restrict__ nsel,
                                                   orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc, int capacity) {
-  const int f = blockIdx.y, lane = threadIdx.x & 63;
+  const int f = blockIdx.y + g.frame0, lane = threadIdx.x & 63;
   const int n = nsel[f];
   const int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DESC_G;  // this wave's DESC_G consecutive keypoints
   if (base >= n) return;  // wave-uniform; no barriers below
@@ -474,21 +521,22 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ im
 #define PW_WORDS 13    // 52 bytes per staged row: window columns kx-21 .. kx+21 start at byte (kx-21)&3
 #define PW_PAIRS 22    // row pairs of horizontal sums (rows 0..43, the last one is a dummy)
 #define PW_COLS 40     // 37 blurred columns padded to 10 groups of 4
-#define PW_WAVE_WORDS (PW_ROWS * PW_WORDS + PW_PAIRS * PW_COLS + BL_ROWS_PAD * (PW_COLS / 4))
 #define BL_ROWS_PAD 38
+#define PW_WAVE_WORDS (PW_ROWS * PW_WORDS + PW_PAIRS * PW_COLS)  // the blurred bytes reuse the raw window's space
 
-__global__ __launch_bounds__(256) void k_describe_patch(const uint8_t* __restrict__ img0, long long img0FrameStride,
-                                                        int img0Aligned, const uint8_t* __restrict__ pyr, const Geom g,
-                                                        const SelKp* __restrict__ sel, const int* __restrict__ nsel,
-                                                        orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                        int capacity) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds[4 * PW_WAVE_WORDS];
-  const int f = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = blockIdx.x * 4 + wave;
-  if (i >= nsel[f]) return;  // wave-uniform; only wave-level synchronisation below
-  uint32_t* raw = lds + wave * PW_WAVE_WORDS;        // [43][13] dwords
+__global__ __launch_bounds__(64) void k_describe_patch(const uint8_t* __restrict__ img0, long long img0FrameStride,
+                                                       int img0Aligned, const uint8_t* __restrict__ pyr, const Geom g,
+                                                       const SelKp* __restrict__ sel, const int* __restrict__ nsel,
+                                                       orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
+                                                       int capacity) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[PW_WAVE_WORDS];
+  const int f = blockIdx.y + g.frame0, lane = threadIdx.x;
+  const int i = blockIdx.x;
+  if (i >= nsel[f]) return;  // uniform; the workgroup is one wave
+  uint32_t* raw = lds;                               // [43][13] dwords
   uint32_t* hz2 = raw + PW_ROWS * PW_WORDS;          // [22][40] row-pair packed horizontal sums
-  uint32_t* bl32 = hz2 + PW_PAIRS * PW_COLS;         // [38][10] dwords = blurred bytes, row stride 40
+  uint32_t* bl32 = raw;                              // [38][10] dwords = blurred bytes, row stride 40 (raw is dead by then)
+  static_assert(BL_ROWS_PAD * (PW_COLS / 4) <= PW_ROWS * PW_WORDS, "blurred bytes must fit in the raw window");
   const SelKp k = sel[(long long)f * g.selCap + i];
   const LevelGeom& L = g.L[k.level];
   const uint8_t* img = k.level == 0 ? img0 + (long long)f * img0FrameStride : pyr + L.imgOff + (long long)f * L.frameStride;
@@ -543,53 +591,43 @@ __global__ __launch_bounds__(256) void k_describe_patch(const uint8_t* __restric
   }
   const float angle = fast_atan2_deg((float)m01, (float)m10);
   // ---- horizontal pass: blurred column c (x = kx-18+c) uses window bytes s+c .. s+c+6 of the staged row ----
-  {
+  //      lane = column: consecutive lanes read consecutive (or the same) LDS words -> no bank conflicts
+  if (lane < PW_COLS) {
     const uint32_t K0 = 18u | (34u << 8) | (48u << 16) | (56u << 24), K1 = 48u | (34u << 8) | (18u << 16);
-    for (int it = lane; it < PW_PAIRS * (PW_COLS / 4); it += 64) {
-      const int rp = it / (PW_COLS / 4), g4 = it - rp * (PW_COLS / 4);
-      uint32_t o[2][4];
-#pragma unroll
-      for (int rr = 0; rr < 2; rr++) {
-        const int r = min(2 * rp + rr, PW_ROWS - 1);
-        const uint32_t* pw = &raw[r * PW_WORDS + g4];
-        const uint32_t W0 = pw[0], W1 = pw[1], W2 = pw[2], W3 = g4 + 3 < PW_WORDS ? pw[3] : 0u;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int ofs = s + j;  // 0..6, wave-uniform
-          const uint32_t lo = ofs < 4 ? W0 : W1, mid = ofs < 4 ? W1 : W2, hi = ofs < 4 ? W2 : W3;
-          const uint32_t a = __builtin_amdgcn_alignbyte(mid, lo, ofs & 3), b = __builtin_amdgcn_alignbyte(hi, mid, ofs & 3);
-          o[rr][j] = __builtin_amdgcn_udot4(a, K0, __builtin_amdgcn_udot4(b, K1, 0u, false), false);
-        }
-      }
-      uint4 pk;
-      pk.x = o[0][0] | (o[1][0] << 16);
-      pk.y = o[0][1] | (o[1][1] << 16);
-      pk.z = o[0][2] | (o[1][2] << 16);
-      pk.w = o[0][3] | (o[1][3] << 16);
-      uint32_t* dsth = &hz2[rp * PW_COLS + 4 * g4];
-      dsth[0] = pk.x; dsth[1] = pk.y; dsth[2] = pk.z; dsth[3] = pk.w;
+    const int wi = (s + lane) >> 2, sh8 = (s + lane) & 3;  // first word / byte shift of this column's 7 taps
+    const bool has2 = wi + 2 < PW_WORDS;
+#pragma unroll 2
+    for (int rp = 0; rp < PW_PAIRS; rp++) {
+      const int ra = 2 * rp, rb = min(2 * rp + 1, PW_ROWS - 1);
+      const uint32_t* pa = &raw[ra * PW_WORDS + wi];
+      const uint32_t* pb = &raw[rb * PW_WORDS + wi];
+      const uint32_t a0 = pa[0], a1 = pa[1], a2 = has2 ? pa[2] : 0u;
+      const uint32_t b0 = pb[0], b1 = pb[1], b2 = has2 ? pb[2] : 0u;
+      const uint32_t ha = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(a1, a0, sh8), K0,
+                                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(a2, a1, sh8), K1, 0u, false), false);
+      const uint32_t hb = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b1, b0, sh8), K0,
+                                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b2, b1, sh8), K1, 0u, false), false);
+      hz2[rp * PW_COLS + lane] = ha | (hb << 16);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  // ---- vertical pass + rounding: blurred rows 2q, 2q+1 from row pairs q..q+3 (see k_blur) ----
-  for (int it = lane; it < (BL_ROWS_PAD / 2) * (PW_COLS / 4); it += 64) {
-    const int q = it / (PW_COLS / 4), g4 = it - q * (PW_COLS / 4);
+  // ---- vertical pass + rounding: blurred rows 2q, 2q+1 from row pairs q..q+3 (see k_blur), lane = column with a
+  //      rolling window of row pairs; the blurred bytes overwrite the raw window (no longer needed) ----
+  if (lane < PW_COLS) {
     const uint32_t E0 = 18u | (34u << 16), E1 = 48u | (56u << 16), E2 = 48u | (34u << 16), E3 = 18u;
     const uint32_t O0 = 18u << 16, O1 = 34u | (48u << 16), O2 = 56u | (48u << 16), O3 = 34u | (18u << 16);
-    uint32_t we = 0, wo = 0;
+    uint8_t* bl8 = reinterpret_cast<uint8_t*>(bl32);
+    uint32_t p0 = hz2[0 * PW_COLS + lane], p1 = hz2[1 * PW_COLS + lane], p2 = hz2[2 * PW_COLS + lane];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int c = 4 * g4 + j;
-      const uint32_t p0 = hz2[(q + 0) * PW_COLS + c], p1 = hz2[(q + 1) * PW_COLS + c];
-      const uint32_t p2 = hz2[(q + 2) * PW_COLS + c], p3 = hz2[(q + 3) * PW_COLS + c];
+    for (int q = 0; q < BL_ROWS_PAD / 2; q++) {
+      const uint32_t p3 = hz2[(q + 3) * PW_COLS + lane];
       const uint32_t se = dot2u16(p0, E0, dot2u16(p1, E1, dot2u16(p2, E2, dot2u16(p3, E3, 32768u))));
       const uint32_t so = dot2u16(p0, O0, dot2u16(p1, O1, dot2u16(p2, O2, dot2u16(p3, O3, 32768u))));
-      we |= (se >> 16) << (8 * j);
-      wo |= (so >> 16) << (8 * j);
+      bl8[(2 * q) * PW_COLS + lane] = (uint8_t)(se >> 16);
+      bl8[(2 * q + 1) * PW_COLS + lane] = (uint8_t)(so >> 16);
+      p0 = p1; p1 = p2; p2 = p3;
     }
-    bl32[(2 * q) * (PW_COLS / 4) + g4] = we;
-    bl32[(2 * q + 1) * (PW_COLS / 4) + g4] = wo;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
@@ -648,6 +686,7 @@ struct MatchParams {
   float nnratio;
   int checkOri;
   int onlyPending;
+  int pair0;  // first pair of this launch
   orbx_bounds b;
 };
 
@@ -684,7 +723,7 @@ __global__ __launch_bounds__(64) void k_match_wave(const int* __restrict__ pairF
   __shared__ int hist[HISTO_LENGTH];
 
   const int lane = threadIdx.x;
-  const int pair = blockIdx.x;
+  const int pair = blockIdx.x + mp.pair0;
   const int fa = pairFirst[pair], fb = pairSecond[pair];
   const int n1 = nkp[fa], n2 = nkp[fb];
   const int cap = mp.capacity;
@@ -870,7 +909,7 @@ __global__ __launch_bounds__(MATCH_T) void k_match(const int* __restrict__ pairF
   __shared__ int sNm, sBadDist, sBadRatio, sBadOri, sKeep[3];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int pair = blockIdx.x;
+  const int pair = blockIdx.x + mp.pair0;
   if (mp.onlyPending && nmatchesOut[pair] != MATCH_PENDING) return;  // already done by k_match_wave
   const int fa = pairFirst[pair], fb = pairSecond[pair];
   const int n1 = nkp[fa], n2 = nkp[fb];
@@ -1026,10 +1065,14 @@ __global__ __launch_bounds__(MATCH_T) void k_match(const int* __restrict__ pairF
 // =================================================================================================
 hipError_t launch_resize(hipStream_t st, int nFrames, const uint8_t* src, long long srcFrameStride, int sw, int sh, int sstride,
                          uint8_t* dst, long long dstFrameStride, int dw, int dh, int dstride, const ResizeTab* xtab,
-                         const ResizeTab* ytab) {
+                         const ResizeTab* ytab, int dwordPath) {
   dim3 block(64, 4, 1), grid((dw + 255) / 256, (dh + 3) / 4, nFrames);
-  hipLaunchKernelGGL(k_resize, grid, block, 0, st, src, srcFrameStride, sw, sh, sstride, dst, dstFrameStride, dw, dh, dstride,
-                     xtab, ytab);
+  if (dwordPath)
+    hipLaunchKernelGGL(k_resize_dw, grid, block, 0, st, src, srcFrameStride, sw, sh, sstride, dst, dstFrameStride, dw, dh,
+                       dstride, xtab, ytab);
+  else
+    hipLaunchKernelGGL(k_resize, grid, block, 0, st, src, srcFrameStride, sw, sh, sstride, dst, dstFrameStride, dw, dh, dstride,
+                       xtab, ytab);
   return hipGetLastError();
 }
 
@@ -1051,7 +1094,7 @@ hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const 
                                  int img0Aligned, const uint8_t* pyr, const Geom& g, const SelKp* sel, const int* nsel,
                                  orbx_keypoint* kps, uint8_t* desc, int capacity) {
   if (maxSel <= 0) return hipSuccess;
-  dim3 block(256, 1, 1), grid((maxSel + 3) / 4, nFrames, 1);
+  dim3 block(64, 1, 1), grid(maxSel, nFrames, 1);
   hipLaunchKernelGGL(k_describe_patch, grid, block, 0, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps, desc,
                      capacity);
   return hipGetLastError();
@@ -1068,11 +1111,12 @@ hipError_t launch_describe(hipStream_t st, int nFrames, int maxSel, const uint8_
 
 hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int* dSecond, const orbx_keypoint* kps,
                         const uint8_t* desc, const int* nkp, int capacity, orbx_bounds b, int window, float nnratio, int checkOri,
-                        int* matches12, int* nmatches, int* stats, int* scratch) {
+                        int* matches12, int* nmatches, int* stats, int* scratch, int pair0) {
   if (nPairs <= 0) return hipSuccess;
   MatchParams mp;
   mp.capacity = capacity; mp.window = window; mp.nnratio = nnratio; mp.checkOri = checkOri; mp.b = b;
   mp.onlyPending = 1;
+  mp.pair0 = pair0;
   // small pairs: one wave each, LDS resident; whatever it marks MATCH_PENDING is done by the general kernel
   hipLaunchKernelGGL(k_match_wave, dim3(nPairs), dim3(64), 0, st, dFirst, dSecond, kps, desc, nkp, mp, matches12, nmatches,
                      stats);

@@ -533,7 +533,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   __shared__ int pending[2 * QMAX], childCnt[QMAX];
   __shared__ uint8_t div[NMAX + 4], alone[NMAX];
   __shared__ uint8_t nodeDepth[MCAP + FCAP], nodeAlive[MCAP + FCAP];
-  const int level = blockIdx.x, f = blockIdx.y;
+  const int level = blockIdx.x, f = blockIdx.y + P.frame0;
   const int n = candCount[f * P.nlevels + level];
   int* nOut = &nselLevel[f * P.nlevels + level];
   if (n > NMAX || P.lev[level].quota > QMAX) {  // handled by the global-scratch variant
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
 __global__ __launch_bounds__(OCT_T) void k_octree_global(const uint32_t* __restrict__ cand, const int* __restrict__ candCount,
                                                         const OctLaunch P, SelKp* __restrict__ selStage,
                                                         int* __restrict__ nselLevel, uint8_t* __restrict__ scratch, int all) {
-  const int level = blockIdx.x, f = blockIdx.y;
+  const int level = blockIdx.x, f = blockIdx.y + P.frame0;
   int* nOut = &nselLevel[f * P.nlevels + level];
   if (!all && *nOut != -2) return;
   const int nMax = P.scrNMax[level], qMax = max(P.lev[level].quota, 1);
@@ -602,7 +602,7 @@ size_t octScratchBytes(int nMax, int qMax) {
 __global__ __launch_bounds__(256) void k_sel_compact(const SelKp* __restrict__ selStage, const int* __restrict__ nselLevel,
                                                      const OctLaunch P, SelKp* __restrict__ sel, int* __restrict__ nsel,
                                                      int selCap, int* __restrict__ err) {
-  const int f = blockIdx.x;
+  const int f = blockIdx.x + P.frame0;
   __shared__ int off[ORBX_MAX_LEVELS + 1];
   if (threadIdx.x == 0) {
     int acc = 0;

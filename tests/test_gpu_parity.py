@@ -339,6 +339,42 @@ def test_device_octree_level_geometries(orbx, ext640, oracle, shape):
             assert np.array_equal(got, exp), (dens, variant)
 
 
+def test_fused_two_stream_batch(orbx, oracle):
+    """orbx_extract_match_batch_device (half-batches on two streams, matching fused behind extraction) gives exactly
+    the results of the separate calls and of the oracle, incl. pairs that straddle the halves or are out of order."""
+    import torch
+    from orb_slam_tracking_amd import synth
+    B, cap, w, h = 40, 1000, 640, 480
+    frames = synth.synth_frames(B, w, h, 3000)
+    oe = oracle.Extractor(*CANON)
+    ora = [oe(f) for f in frames]
+    e = orbx.ORBextractor(*CANON, max_width=w, max_height=h, max_batch=B)
+    d_img = torch.from_numpy(frames).cuda()
+    for first, second in ((np.arange(0, B, 2), np.arange(1, B, 2)),                       # consecutive pairs
+                          (np.array([0, 2, 19, 21, 38, 5]), np.array([1, 3, 20, 22, 39, 30]))):  # straddling / unordered
+        d_k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+        d_d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+        d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+        P = len(first)
+        d_m = torch.zeros(P * cap, dtype=torch.int32, device="cuda")
+        d_nm = torch.zeros(P, dtype=torch.int32, device="cuda")
+        d_st = torch.zeros(P * 3, dtype=torch.int32, device="cuda")
+        e.extract_match_batch_device(d_img, B, w, h, w, w * h, d_k, d_d, d_n, first, second, (0, w, 0, h), d_m, d_nm, d_st, 100,
+                                     0.9, True, cap)
+        n = d_n.cpu().numpy()
+        kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, cap)
+        dd = d_d.cpu().numpy().reshape(B, cap, 32)
+        for f in range(B):
+            assert n[f] == len(ora[f][1])
+            _same(kk[f, :n[f]], dd[f, :n[f]], ora[f][1], ora[f][2])
+        mm, nm, st = d_m.cpu().numpy().reshape(P, cap), d_nm.cpu().numpy(), d_st.cpu().numpy().reshape(-1, 3)
+        for p in range(P):
+            a, b = ora[int(first[p])], ora[int(second[p])]
+            onm, om12, ost = oracle.match_init(a[1], a[2], b[1], b[2], (0, w, 0, h), 100, 0.9, True)
+            assert nm[p] == onm and np.array_equal(mm[p, :len(om12)], om12) and st[p].tolist() == ost.tolist()
+    e.close()
+
+
 def test_cpp_shim_equals_oracle(orbx, oracle, tmp_path):
     """The reference's demo call sequence through the C++ drop-in classes (include/orbx_shim.hpp)."""
     import subprocess
