@@ -27,6 +27,34 @@ namespace orbx {
 #define OCT_T 256
 #define OCT_DEPTH 16
 
+// Diagnostic build only (-DORBX_OCT_STAMPS): s_memtime stamps of the selection kernel's phases, per workgroup, into a
+// buffer nothing else reads (cdna_hip_programming.md section 7).  The production build contains no stamp.
+#ifdef ORBX_OCT_STAMPS
+#define OCT_NSTAMP 16
+__device__ unsigned long long g_octStamps[4096 * OCT_NSTAMP];
+#define OCT_STAMP(k)                                                                                         \
+  do {                                                                                                       \
+    __syncthreads();                                                                                         \
+    if (threadIdx.x == 0) {                                                                                  \
+      const int b_ = (blockIdx.y * gridDim.x + blockIdx.x) & 4095;                                           \
+      g_octStamps[b_ * OCT_NSTAMP + (k)] = __builtin_amdgcn_s_memtime();                                     \
+    }                                                                                                        \
+  } while (0)
+#define OCT_STAMP_ACC(k, t0)                                                                                 \
+  do {                                                                                                       \
+    __syncthreads();                                                                                         \
+    if (threadIdx.x == 0) {                                                                                  \
+      const int b_ = (blockIdx.y * gridDim.x + blockIdx.x) & 4095;                                           \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                          \
+      g_octStamps[b_ * OCT_NSTAMP + (k)] += now_ - (t0);                                                     \
+      (t0) = now_;                                                                                           \
+    }                                                                                                        \
+  } while (0)
+#else
+#define OCT_STAMP(k) do {} while (0)
+#define OCT_STAMP_ACC(k, t0) do {} while (0)
+#endif
+
 typedef unsigned long long u64;
 
 struct OctScratch {
@@ -43,6 +71,9 @@ struct OctScratch {
   int* pending;       // [2 * qCap]  two buffers
   int* childCnt;      // [qCap]      per sorted entry: children | multi-key children << 8
   const uint32_t* cand;  // packed candidates (LDS copy or global)
+  uint32_t* candLds;     // if set: the LDS copy shares its space with hiOf and is re-read from candSrc before the emit step
+  const uint32_t* candSrc;
+  u64* xchg;          // LDS exchange buffer for the register sort when keys/nodes live in global memory, else nullptr
 };
 
 __device__ __forceinline__ int divDepth(u64 a, u64 b) {  // first depth at which two path codes differ
@@ -52,7 +83,8 @@ __device__ __forceinline__ int divDepth(u64 a, u64 b) {  // first depth at which
   return hb >= 2 * OCT_DEPTH ? 0 : OCT_DEPTH - hb / 2;
 }
 
-__device__ __forceinline__ void bitonicSort(u64* a, int nPow2, int tid) {
+// bitonic sort in memory, one barrier per stage: only for arrays too large for the register version below
+__device__ __forceinline__ void bitonicSortMem(u64* a, int nPow2, int tid) {
   for (int k = 2; k <= nPow2; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int i = tid; i < nPow2; i += OCT_T) {
@@ -65,6 +97,97 @@ __device__ __forceinline__ void bitonicSort(u64* a, int nPow2, int tid) {
       }
       __syncthreads();
     }
+}
+
+__device__ __forceinline__ u64 shflXor64(u64 v, int laneMask) {
+  const uint32_t lo = __shfl_xor((uint32_t)v, laneMask), hi = __shfl_xor((uint32_t)(v >> 32), laneMask);
+  return ((u64)hi << 32) | lo;
+}
+
+// Bitonic sort of 256*E keys held E per thread (thread t owns elements t*E .. t*E+E-1).  Compare-exchange partners at
+// distance < E are registers of the same thread, at distance < 64*E lanes of the same wave (shuffles), and only the
+// last stages (distance >= 64*E, three of them) go through memory with a barrier.
+template <int E>
+__device__ void bitonicSortRegs(u64* a, int tid) {
+  constexpr int NTOT = OCT_T * E;
+  u64 v[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) v[e] = a[tid * E + e];
+  for (int k = 2; k <= NTOT; k <<= 1) {
+    for (int j = k >> 1; j >= E; j >>= 1) {
+      if (j >= 64 * E) {  // partner in another wave
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; e++) a[tid * E + e] = v[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          const int i = tid * E + e;
+          const u64 o = a[i ^ j];
+          const bool lower = (i & j) == 0, asc = (i & k) == 0;
+          const bool keepMin = lower == asc;
+          v[e] = keepMin ? (o < v[e] ? o : v[e]) : (o > v[e] ? o : v[e]);
+        }
+      } else {  // partner lane in the same wave
+        const int lm = j / E;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          const int i = tid * E + e;
+          const u64 o = shflXor64(v[e], lm);
+          const bool lower = (i & j) == 0, asc = (i & k) == 0;
+          const bool keepMin = lower == asc;
+          v[e] = keepMin ? (o < v[e] ? o : v[e]) : (o > v[e] ? o : v[e]);
+        }
+      }
+    }
+    // partner register of the same thread: distances E/2 .. 1 (compile-time, so v[] stays in registers)
+#pragma unroll
+    for (int jj = E / 2; jj > 0; jj >>= 1) {
+      if (jj < k) {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          const int pe = e ^ jj;
+          if (pe > e) {
+            const bool asc = ((tid * E + e) & k) == 0;
+            const u64 x = v[e], y = v[pe];
+            const bool sw = (x > y) == asc;
+            v[e] = sw ? y : x;
+            v[pe] = sw ? x : y;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < E; e++) a[tid * E + e] = v[e];
+  __syncthreads();
+}
+
+// sorts a[0 .. nPow2) ascending; entries beyond the real data must be padded with ~0 up to max(nPow2, 256).
+// `xchg`: LDS buffer of OCT_SORT_LDS keys used when `a` itself is not in LDS (the register sort exchanges its last
+// stages through LDS only); arrays larger than that are sorted in place, one barrier per stage.
+#define OCT_SORT_LDS 2048
+__device__ void bitonicSort(u64* a, int nPow2, int tid, u64* xchg) {
+  if (nPow2 > OCT_SORT_LDS) {
+    bitonicSortMem(a, nPow2, tid);
+    return;
+  }
+  const int np = nPow2 < 256 ? 256 : nPow2;
+  u64* s = a;
+  if (xchg) {
+    for (int i = tid; i < np; i += OCT_T) xchg[i] = a[i];
+    __syncthreads();
+    s = xchg;
+  }
+  if (np == 256) bitonicSortRegs<1>(s, tid);
+  else if (np == 512) bitonicSortRegs<2>(s, tid);
+  else if (np == 1024) bitonicSortRegs<4>(s, tid);
+  else bitonicSortRegs<8>(s, tid);
+  if (xchg) {
+    for (int i = tid; i < np; i += OCT_T) a[i] = xchg[i];
+    __syncthreads();
+  }
 }
 
 // exclusive prefix sum of one int per thread over the workgroup; *total = sum.  `ws` = 4 ints of LDS.
@@ -94,35 +217,43 @@ __device__ __forceinline__ int blockScanExcl(int v, int tid, int* ws, int* total
 //      keys; the comparator (compareNodes: count, then UL.x) is "a >> 20 < b >> 20" -----------------------------------
 #define SLESS(a, b) (((a) >> 20) < ((b) >> 20))
 
-__device__ void stdAdjustHeap(u64* p, int first, int holeIndex, int len, u64 value) {
+// key array accessor for the replay (LDS or global memory)
+struct MemKeys {
+  u64* p;
+  __device__ __forceinline__ u64 get(int i) const { return p[i]; }
+  __device__ __forceinline__ void set(int i, u64 v) { p[i] = v; }
+};
+template <class A>
+__device__ void stdAdjustHeap(A& p, int first, int holeIndex, int len, u64 value) {
   const int topIndex = holeIndex;
   int secondChild = holeIndex;
   while (secondChild < (len - 1) / 2) {
     secondChild = 2 * (secondChild + 1);
-    if (SLESS(p[first + secondChild], p[first + (secondChild - 1)])) secondChild--;
-    p[first + holeIndex] = p[first + secondChild];
+    if (SLESS(p.get(first + secondChild), p.get(first + (secondChild - 1)))) secondChild--;
+    p.set(first + holeIndex, p.get(first + secondChild));
     holeIndex = secondChild;
   }
   if ((len & 1) == 0 && secondChild == (len - 2) / 2) {
     secondChild = 2 * (secondChild + 1);
-    p[first + holeIndex] = p[first + (secondChild - 1)];
+    p.set(first + holeIndex, p.get(first + (secondChild - 1)));
     holeIndex = secondChild - 1;
   }
   int parent = (holeIndex - 1) / 2;  // __push_heap
-  while (holeIndex > topIndex && SLESS(p[first + parent], value)) {
-    p[first + holeIndex] = p[first + parent];
+  while (holeIndex > topIndex && SLESS(p.get(first + parent), value)) {
+    p.set(first + holeIndex, p.get(first + parent));
     holeIndex = parent;
     parent = (holeIndex - 1) / 2;
   }
-  p[first + holeIndex] = value;
+  p.set(first + holeIndex, value);
 }
 
-__device__ void stdHeapSortRange(u64* p, int first, int last) {  // __partial_sort(first, last, last)
+template <class A>
+__device__ void stdHeapSortRange(A& p, int first, int last) {  // __partial_sort(first, last, last)
   const int len = last - first;
   if (len >= 2) {  // __make_heap
     int parent = (len - 2) / 2;
     for (;;) {
-      stdAdjustHeap(p, first, parent, len, p[first + parent]);
+      stdAdjustHeap(p, first, parent, len, p.get(first + parent));
       if (parent == 0) break;
       parent--;
     }
@@ -130,15 +261,15 @@ __device__ void stdHeapSortRange(u64* p, int first, int last) {  // __partial_so
   int l = last;  // __sort_heap
   while (l - first > 1) {
     --l;
-    const u64 v = p[l];  // __pop_heap(first, l, l)
-    p[l] = p[first];
+    const u64 v = p.get(l);  // __pop_heap(first, l, l)
+    p.set(l, p.get(first));
     stdAdjustHeap(p, first, 0, l - first, v);
   }
 }
 
-__device__ void stdIntrosortLoop(u64* p, int n) {
+template <class A>
+__device__ void stdIntrosortLoop(A& p, int n, u64* stack /* LDS, >= 40 entries: at most 2*log2(n) <= 38 pending ranges */) {
   if (n <= 16) return;
-  int stackF[64], stackL[64], stackD[64];
   int sp = 0, first = 0, last = n;
   int depth = 2 * (31 - __builtin_clz((unsigned)n));
   for (;;) {
@@ -148,34 +279,43 @@ __device__ void stdIntrosortLoop(u64* p, int n) {
       const int mid = first + (last - first) / 2;
       {  // __move_median_to_first(first, first + 1, mid, last - 1)
         const int ia = first + 1, ib = mid, ic = last - 1;
-        const u64 a = p[ia], b = p[ib], c = p[ic], f = p[first];
+        const u64 a = p.get(ia), b = p.get(ib), c = p.get(ic), f = p.get(first);
         int sel;
         if (SLESS(a, b)) sel = SLESS(b, c) ? ib : (SLESS(a, c) ? ic : ia);
         else sel = SLESS(a, c) ? ia : (SLESS(b, c) ? ic : ib);
-        p[first] = p[sel];
-        p[sel] = f;
+        p.set(first, p.get(sel));
+        p.set(sel, f);
       }
-      const u64 pivot = p[first];
+      const u64 pivot = p.get(first);
       int lo = first + 1, hi = last;
       for (;;) {  // __unguarded_partition(first + 1, last, first)
-        u64 vlo = p[lo];
-        while (SLESS(vlo, pivot)) vlo = p[++lo];
+        u64 vlo = p.get(lo);
+        while (SLESS(vlo, pivot)) vlo = p.get(++lo);
         --hi;
-        u64 vhi = p[hi];
-        while (SLESS(pivot, vhi)) vhi = p[--hi];
+        u64 vhi = p.get(hi);
+        while (SLESS(pivot, vhi)) vhi = p.get(--hi);
         if (!(lo < hi)) break;
-        p[lo] = vhi;
-        p[hi] = vlo;
+        p.set(lo, vhi);
+        p.set(hi, vlo);
         ++lo;
       }
       // the library recurses on [cut, last) and loops on [first, cut): disjoint ranges, same depth budget
-      stackF[sp] = first; stackL[sp] = lo; stackD[sp] = depth; sp++;
+      stack[sp++] = (u64)first | ((u64)lo << 20) | ((u64)depth << 40);  // private arrays would live in (slow) scratch memory
       first = lo;
     }
     if (sp == 0) break;
-    --sp;
-    first = stackF[sp]; last = stackL[sp]; depth = stackD[sp];
+    const u64 top = stack[--sp];
+    first = (int)(top & 0xfffff); last = (int)((top >> 20) & 0xfffff); depth = (int)(top >> 40);
   }
+}
+
+// partition phase of std::sort on p[0..n), replayed by one lane (a register-resident variant read through v_readlane
+// was measured slower: a lone wave spends ~100 cycles per serial step either way).  Call with the whole workgroup.
+__device__ void stdSortPartitionPhase(u64* p, int n, int tid) {
+  __shared__ u64 sortStack[40];
+  if (n <= 16 || tid != 0) return;
+  MemKeys A{p};
+  stdIntrosortLoop(A, n, sortStack);
 }
 
 // reference candidate order (cell row, cell col, y, x) of a packed candidate (cpp:1078-1137; cv::FAST is row-major)
@@ -207,6 +347,8 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
   }
   int nPad = 1;
   while (nPad < n) nPad <<= 1;
+  if (nPad < 256) nPad = 256;  // the register sort works on at least 256 (padded) keys
+  OCT_STAMP(0);
 
   // ---- 1. path codes -----------------------------------------------------------------------------------------
   for (int i = tid; i < nPad; i += OCT_T) {
@@ -233,7 +375,9 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
   }
   if (tid < OCT_DEPTH + 2) { cntDiv[tid] = 0; cntAlone[tid] = 0; }
   __syncthreads();
-  bitonicSort(S.keys, nPad, tid);
+  OCT_STAMP(1);
+  bitonicSort(S.keys, nPad, tid, S.xchg);
+  OCT_STAMP(2);
 
   // ---- 2. divergence depths, S_d (distinct depth-d prefixes), singles_d -----------------------------------------
   for (int i = tid; i <= n; i += OCT_T) {
@@ -252,6 +396,7 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
     atomicAdd(&cntAlone[a], 1);
   }
   __syncthreads();
+  OCT_STAMP(3);
   // ---- 3. replay the pass loop on sizes only (cpp:781-895) ------------------------------------------------------
   if (tid == 0) {
     int Sd[OCT_DEPTH + 2], sg[OCT_DEPTH + 2];
@@ -284,6 +429,7 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
     if (tid == 0) *nOut = -2;
     return;
   }
+  OCT_STAMP(4);
   // ---- 4. node list in std::list order ---------------------------------------------------------------------------
   // node starts: a leaf key (alone < k) or the first key of a depth-k group
   {
@@ -314,6 +460,7 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
   }
   int mPad = 1;
   while (mPad < M) mPad <<= 1;
+  if (mPad < 256) mPad = 256;
   for (int m = tid; m < M; m += OCT_T) {  // ends of the nodes, from the position-ordered list before it is re-sorted
     const int lo = (int)(S.nodes[m] & 0x7ffff);
     const int hi = (m + 1 < M) ? (int)(S.nodes[m + 1] & 0x7ffff) : n;
@@ -322,7 +469,9 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
   __syncthreads();
   for (int m = M + tid; m < mPad; m += OCT_T) S.nodes[m] = ~0ull;
   __syncthreads();
-  bitonicSort(S.nodes, mPad, tid);
+  OCT_STAMP(5);
+  bitonicSort(S.nodes, mPad, tid, S.xchg);
+  OCT_STAMP(6);
   for (int m = tid; m < M; m += OCT_T) {
     const u64 v = S.nodes[m];
     const int lo = (int)(v & 0x7ffff);
@@ -333,6 +482,11 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
   }
   __syncthreads();
 
+  OCT_STAMP(7);
+#ifdef ORBX_OCT_STAMPS
+  unsigned long long tAcc = __builtin_amdgcn_s_memtime();
+  if (tid == 0) for (int k_ = 8; k_ < 14; k_++) g_octStamps[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * OCT_NSTAMP + k_] = 0;
+#endif
   // ---- 5. partial pass(es), cpp:897-965 ---------------------------------------------------------------------------
   if (sPhase2) {
     int* pendA = S.pending;
@@ -381,9 +535,11 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
         sizedA[j] = ((u64)(S.nodeHi[nd] - lo) << 40) | ((u64)(ulx & 0xfffff) << 20) | (u64)nd;
       }
       __syncthreads();
+      OCT_STAMP_ACC(8, tAcc);
       // (b) std::sort (cpp:912): partition phase on one lane, final insertion sort as a parallel stable rank sort
-      if (tid == 0) stdIntrosortLoop(sizedA, nPend);
+      stdSortPartitionPhase(sizedA, nPend, tid);
       __syncthreads();
+      OCT_STAMP_ACC(9, tAcc);
       for (int j = tid; j < nPend; j += OCT_T) {
         const u64 v = sizedA[j];
         const u64 kv = v >> 20;
@@ -395,6 +551,7 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
         sizedB[rank] = v;
       }
       __syncthreads();
+      OCT_STAMP_ACC(10, tAcc);
       // (c) children of every pending node (in sorted order)
       for (int j = tid; j < nPend; j += OCT_T) {
         const int nd = (int)(sizedB[j] & 0xfffff);
@@ -414,20 +571,29 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
         S.childCnt[j] = nch | (nmulti << 8);
       }
       __syncthreads();
+      OCT_STAMP_ACC(11, tAcc);
       // (d) cut point: nodes are split from the back of the sorted array until the list holds N nodes
-      if (tid == 0) {
+      {
+        // growth of the list when the last t+1 sorted nodes are split: inclusive prefix over t = nPend-1-j
         const int prevSize = sSize;
-        int size = prevSize, j = nPend - 1;
-        for (; j >= 0; j--) {
-          size += (S.childCnt[j] & 0xff) - 1;
-          if (size >= N) break;
+        const int chunk = (nPend + OCT_T - 1) / OCT_T;
+        const int b = min(tid * chunk, nPend), e = min(b + chunk, nPend);
+        int c = 0;
+        for (int t = b; t < e; t++) c += (S.childCnt[nPend - 1 - t] & 0xff) - 1;
+        int totalGrowth;
+        int acc = blockScanExcl(c, tid, ws, &totalGrowth);
+        if (tid == 0) { sCut = 0; sSize = prevSize + totalGrowth; sFinish = (totalGrowth == 0 || prevSize + totalGrowth >= N) ? 1 : 0; }
+        __syncthreads();
+        // growth is >= 0 per split, so the first t whose inclusive sum reaches N - prevSize is unique: that thread reports
+        for (int t = b; t < e; t++) {
+          const int before = acc;
+          acc += (S.childCnt[nPend - 1 - t] & 0xff) - 1;
+          if (prevSize + before < N && prevSize + acc >= N) { sCut = nPend - 1 - t; sSize = prevSize + acc; sFinish = 1; }
         }
-        sCut = max(j, 0);
-        sSize = size;
-        sFinish = (size >= N || size == prevSize) ? 1 : 0;
       }
       __syncthreads();
       const int cut = sCut, finish = sFinish;
+      OCT_STAMP_ACC(12, tAcc);
       // (e) create the children: processing order t = nPend-1-j; children are push_front'ed in quadrant order
       {
         const int nProc = nPend - cut;
@@ -470,10 +636,16 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
         nPend = totM;
       }
       __syncthreads();
+      OCT_STAMP_ACC(13, tAcc);
       if (finish) break;
       { int* t = pendA; pendA = pendB; pendB = t; }
     }
     if (tid == 0) sFront = nFront;
+    __syncthreads();
+  }
+  OCT_STAMP(14);
+  if (S.candLds) {  // hiOf (dead since step 4) shared the candidate cache's space: fetch the candidates again
+    for (int i = tid; i < n; i += OCT_T) S.candLds[i] = S.candSrc[i];
     __syncthreads();
   }
   // ---- 6. output positions: reverse(front alive) ++ list alive; keep the first `quota` ------------------------------
@@ -513,6 +685,7 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
     }
     if (tid == 0) *nOut = min(alive, N);
   }
+  OCT_STAMP(15);
 }
 
 // ---- kernels ---------------------------------------------------------------------------------------------------------
@@ -522,17 +695,22 @@ template <int NMAX, int QMAX>
 __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict__ cand, const int* __restrict__ candCount,
                                                      const OctLaunch P, SelKp* __restrict__ selStage,
                                                      int* __restrict__ nselLevel) {
-  constexpr int MCAP = 4 * QMAX, FCAP = 4 * QMAX;
+  constexpr int MCAP = 4 * QMAX, FCAP = 2 * QMAX;
   static_assert((NMAX & (NMAX - 1)) == 0 && (MCAP & (MCAP - 1)) == 0, "sort buffers must be powers of two");
+  // LDS budget (NMAX 2048, QMAX 256): 16 + 8 + 8 + 12 + 4 + 3 KB = 51 KB -> three workgroups per CU.
+  //   nodes[] is dead once the node records exist, so the partial pass's buffers (sized, pending, childCnt) live in it;
+  //   hiOf[] is dead after step 4 and shares its space with the candidate cache (reloaded before the emit step).
   __shared__ u64 keys[NMAX];
   __shared__ u64 nodes[MCAP];
-  __shared__ u64 sized[2 * QMAX];
   __shared__ uint32_t candL[NMAX];
-  __shared__ uint32_t hiOf[NMAX];
   __shared__ int nodeLo[MCAP + FCAP], nodeHi[MCAP + FCAP];
-  __shared__ int pending[2 * QMAX], childCnt[QMAX];
   __shared__ uint8_t div[NMAX + 4], alone[NMAX];
   __shared__ uint8_t nodeDepth[MCAP + FCAP], nodeAlive[MCAP + FCAP];
+  static_assert(2 * QMAX * 8 + 2 * QMAX * 4 + QMAX * 4 <= MCAP * 8, "partial-pass buffers must fit in nodes[]");
+  u64* sized = nodes;                                             // [2 * QMAX]
+  int* pending = reinterpret_cast<int*>(nodes + 2 * QMAX);        // [2 * QMAX]
+  int* childCnt = pending + 2 * QMAX;                             // [QMAX]
+  uint32_t* hiOf = candL;
   const int level = blockIdx.x, f = blockIdx.y + P.frame0;
   const int n = candCount[f * P.nlevels + level];
   int* nOut = &nselLevel[f * P.nlevels + level];
@@ -543,7 +721,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   const uint32_t* src = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
   for (int i = threadIdx.x; i < n; i += OCT_T) candL[i] = src[i];
   __syncthreads();
-  OctScratch S{keys, nodes, div, alone, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, childCnt, candL};
+  OctScratch S{keys, nodes, div, alone, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, childCnt, candL, candL, src, nullptr};
   octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, MCAP, FCAP, QMAX);
 }
 
@@ -552,6 +730,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
 __global__ __launch_bounds__(OCT_T) void k_octree_global(const uint32_t* __restrict__ cand, const int* __restrict__ candCount,
                                                         const OctLaunch P, SelKp* __restrict__ selStage,
                                                         int* __restrict__ nselLevel, uint8_t* __restrict__ scratch, int all) {
+  __shared__ u64 xchg[OCT_SORT_LDS];
   const int level = blockIdx.x, f = blockIdx.y + P.frame0;
   int* nOut = &nselLevel[f * P.nlevels + level];
   if (!all && *nOut != -2) return;
@@ -561,10 +740,10 @@ __global__ __launch_bounds__(OCT_T) void k_octree_global(const uint32_t* __restr
     if (threadIdx.x == 0) *nOut = -1;
     return;
   }
-  size_t nPad = 1;
+  size_t nPad = 256;
   while ((int)nPad < nMax) nPad <<= 1;
   const int mCap = 4 * qMax, fCap = 16 * qMax;
-  size_t mPad = 1;
+  size_t mPad = 256;
   while ((int)mPad < mCap) mPad <<= 1;
   uint8_t* p = scratch + P.scrOff[level] + (int64_t)f * P.scrStride[level];
   OctScratch S;
@@ -581,17 +760,20 @@ __global__ __launch_bounds__(OCT_T) void k_octree_global(const uint32_t* __restr
   S.nodeDepth = p; p += (size_t)(mCap + fCap + 8);
   S.nodeAlive = p;
   S.cand = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
+  S.candLds = nullptr;
+  S.candSrc = nullptr;
+  S.xchg = xchg;
   octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, mCap, fCap, qMax);
   __syncthreads();
   if (threadIdx.x == 0 && *nOut == -2) *nOut = -1;  // even the large scratch was too small: hard error
 }
 
 size_t octScratchBytes(int nMax, int qMax) {
-  size_t nPad = 1;
+  size_t nPad = 256;
   while ((int)nPad < nMax) nPad <<= 1;
   qMax = qMax < 1 ? 1 : qMax;
   const size_t mCap = 4 * (size_t)qMax, fCap = 16 * (size_t)qMax;
-  size_t mPad = 1;
+  size_t mPad = 256;
   while (mPad < mCap) mPad <<= 1;
   size_t b = nPad * 8 + mPad * 8 + (size_t)2 * qMax * 8 + nPad * 4 + (mCap + fCap) * 8 + (size_t)3 * qMax * 4 + 2 * (nPad + 8) +
              2 * (mCap + fCap + 8);
@@ -640,6 +822,12 @@ hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage
   return hipGetLastError();
 }
 
+#ifdef ORBX_OCT_STAMPS
+extern "C" int orbx_diag_oct_stamps(unsigned long long* out, int nBlocks) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_octStamps), sizeof(unsigned long long) * OCT_NSTAMP * nBlocks);
+}
+#endif
+
 // ---- test hook: the std::sort replay alone (partition phase on one lane + parallel stable rank sort) ---------------
 __global__ __launch_bounds__(OCT_T) void k_debug_sort(int* triples, int n, u64* a, u64* b) {
   const int tid = threadIdx.x;
@@ -647,7 +835,7 @@ __global__ __launch_bounds__(OCT_T) void k_debug_sort(int* triples, int n, u64* 
     a[j] = ((u64)(uint32_t)triples[3 * j] << 40) | ((u64)((uint32_t)triples[3 * j + 1] & 0xfffff) << 20) |
            (u64)((uint32_t)triples[3 * j + 2] & 0xfffff);
   __syncthreads();
-  if (tid == 0) stdIntrosortLoop(a, n);
+  stdSortPartitionPhase(a, n, tid);
   __syncthreads();
   for (int j = tid; j < n; j += OCT_T) {
     const u64 v = a[j], kv = v >> 20;
