@@ -475,7 +475,7 @@ int issueMatch(orbx_ctx* ctx, int si, hipStream_t st, int pair0, int n, const Ma
   StageTimer tm(ctx, ORBX_STAGE_MATCH, si, st);
   HIPCHK(launch_match(st, n, ctx->dPairs, ctx->dPairs + m.nPairs, dKps, dDesc, dN, capacity, m.b, m.window, m.nnratio, m.checkOri,
                       m.dMatches12, m.dNmatches, m.dStats, ctx->dMatchScratch, pair0));
-  tm.stop(2);  // k_match_wave + k_match (pending pairs only)
+  tm.stop(3);  // k_match_jacobi + k_match_wave + k_match (the latter two for pending pairs only)
   return ORBX_OK;
 }
 

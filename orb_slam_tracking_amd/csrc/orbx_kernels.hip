@@ -697,6 +697,247 @@ __device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const 
 }
 
 // -------------------------------------------------------------------------------------------------
+// k_match_jacobi: one workgroup per frame pair, ONE THREAD PER QUERY.
+// The reference's query loop is sequential only through vMatchedDistance: query q sees, for every train t, the smallest
+// distance with which an EARLIER query claimed t (each accepted match overwrites it with a smaller value,
+// ORBmatcher.cpp:67,103).  So the outcome of q is a function of the outcomes of the queries < q, and the sequential
+// result is the unique fixpoint of "evaluate all queries in parallel against the claims of the previous sweep":
+// after sweep i the first i queries are final, and in practice a handful of sweeps suffice (the loop stops when a
+// sweep changes nothing).  Claims are kept per train (up to MJ_K; more, or no convergence within MJ_SWEEPS, hands
+// the pair to the sequential kernels).  Everything else (vnMatches21 stealing, nmatches, rotation histogram with its
+// double-decrement quirk) follows from the final outcomes: a train belongs to its LAST claimant.
+// All threads walk the trains together, so train data are LDS broadcasts.
+// -------------------------------------------------------------------------------------------------
+#define MJ_CAP 256
+#define MJ_K 4
+#define MJ_SWEEPS 64
+#define MJ_CMAX 64   // trains inside one query's window
+
+__global__ __launch_bounds__(MJ_CAP) void k_match_jacobi(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
+                                                         const orbx_keypoint* __restrict__ kps,
+                                                         const uint8_t* __restrict__ desc, const int* __restrict__ nkp,
+                                                         const MatchParams mp, int* __restrict__ matches12,
+                                                         int* __restrict__ nmatchesOut, int* __restrict__ statsOut) {
+  __shared__ float tX[MJ_CAP], tY[MJ_CAP], tAng[MJ_CAP];
+  __shared__ uint32_t tDesc[8][MJ_CAP];
+  __shared__ uint16_t tIdx[MJ_CAP];
+  __shared__ uint8_t tCx[MJ_CAP], tCy[MJ_CAP];
+  __shared__ int clCount[MJ_CAP], lastQ[MJ_CAP];
+  __shared__ uint16_t clQ[MJ_CAP][MJ_K], clD[MJ_CAP][MJ_K];
+  __shared__ uint32_t candList[MJ_CMAX * MJ_CAP];  // [k][query]: dist << 8 | train slot
+  __shared__ uint32_t tOrd[MJ_CAP];                // cell << 20 | F2 index: the reference's candidate order
+  __shared__ int hist[HISTO_LENGTH];
+  __shared__ int sNT, sBase, sChanged, sOverflow, sNm, sBadDist, sBadRatio, sBadOri, sKeep[3];
+  __shared__ int wcnt[MJ_CAP / 64];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int pair = blockIdx.x + mp.pair0;
+  const int fa = pairFirst[pair], fb = pairSecond[pair];
+  const int n1 = nkp[fa], n2 = nkp[fb];
+  const int cap = mp.capacity;
+  const orbx_keypoint* k1 = kps + (long long)fa * cap;
+  const orbx_keypoint* k2 = kps + (long long)fb * cap;
+  const uint32_t* d1 = reinterpret_cast<const uint32_t*>(desc + (long long)fa * cap * 32);
+  const uint32_t* d2 = reinterpret_cast<const uint32_t*>(desc + (long long)fb * cap * 32);
+  int* m12 = matches12 + (long long)pair * cap;
+
+  const float wInv = (float)ORBX_GRID_COLS / (float)(mp.b.max_x - mp.b.min_x);  // Frame.cpp:46-47
+  const float hInv = (float)ORBX_GRID_ROWS / (float)(mp.b.max_y - mp.b.min_y);
+  const float fminX = (float)mp.b.min_x, fminY = (float)mp.b.min_y;
+  if (t == 0) { sNT = 0; sBase = 0; sOverflow = n2 > 65535 ? 1 : 0; sNm = 0; sBadDist = 0; sBadRatio = 0; sBadOri = 0; }
+  if (t < HISTO_LENGTH) hist[t] = 0;
+  __syncthreads();
+  // ---- stage the grid-eligible octave-0 trains of F2 (slot order is irrelevant: ties are broken by cell and index) ----
+  for (int j0 = 0; j0 < n2; j0 += MJ_CAP) {
+    const int j = j0 + t;
+    if (j < n2) {
+      const orbx_keypoint kp = k2[j];
+      // Frame::PosInGrid (Frame.cpp:89-99) + the octave filter of GetFeaturesInArea (Frame.cpp:179,191)
+      const int px = (int)roundf((kp.x - fminX) * wInv), py = (int)roundf((kp.y - fminY) * hInv);
+      if (kp.octave == 0 && px >= 0 && px < ORBX_GRID_COLS && py >= 0 && py < ORBX_GRID_ROWS) {
+        const int slot = atomicAdd(&sNT, 1);
+        if (slot < MJ_CAP) {
+          tX[slot] = kp.x; tY[slot] = kp.y; tAng[slot] = kp.angle;
+          tIdx[slot] = (uint16_t)j; tCx[slot] = (uint8_t)px; tCy[slot] = (uint8_t)py;
+#pragma unroll
+          for (int w = 0; w < 8; w++) tDesc[w][slot] = d2[(long long)j * 8 + w];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- my query: the q-th octave-0 keypoint of F1 in index order goes to thread q ----
+  float qx = 0, qy = 0, qang = 0;
+  int qi = -1;
+  uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i0 = 0; i0 < n1; i0 += MJ_CAP) {
+    const int i = i0 + t;
+    bool ok = false;
+    orbx_keypoint kp;
+    if (i < n1) {
+      kp = k1[i];
+      ok = !(kp.octave > 0);  // ORBmatcher.cpp:38-39
+      m12[i] = -1;
+    }
+    const unsigned long long bm = __ballot(ok);
+    if (lane == 0) wcnt[wave] = __popcll(bm);
+    __syncthreads();
+    int before = sBase;
+    for (int w2 = 0; w2 < wave; w2++) before += wcnt[w2];
+    const int pos = before + __popcll(bm & ((1ull << lane) - 1ull));
+    if (ok && pos < MJ_CAP) clCount[pos] = i;  // clCount is free until the sweeps start: F1 index of query `pos`
+    __syncthreads();
+    if (t == 0) {
+      int tot = sBase;
+      for (int w2 = 0; w2 < MJ_CAP / 64; w2++) tot += wcnt[w2];
+      sBase = tot;
+    }
+    __syncthreads();
+  }
+  const int nQ = sBase, nT = sNT;
+  if (nQ > MJ_CAP || nT > MJ_CAP || sOverflow) {  // block-uniform: leave the pair to the sequential kernels
+    if (t == 0) nmatchesOut[pair] = MATCH_PENDING;
+    return;
+  }
+  if (t < nQ) {
+    qi = clCount[t];
+    const orbx_keypoint kp = k1[qi];
+    qx = kp.x; qy = kp.y; qang = kp.angle;
+#pragma unroll
+    for (int w = 0; w < 8; w++) qd[w] = d1[(long long)qi * 8 + w];
+  }
+  __syncthreads();
+  if (t < MJ_CAP) clCount[t] = 0;
+  __syncthreads();
+  // cell window of my query, Frame.cpp:167-177
+  const float r = (float)mp.window;
+  const int minCX = max(0, (int)floorf((qx - fminX - r) * wInv));
+  const int maxCX = min(ORBX_GRID_COLS - 1, (int)ceilf((qx - fminX + r) * wInv));
+  const int minCY = max(0, (int)floorf((qy - fminY - r) * hInv));
+  const int maxCY = min(ORBX_GRID_ROWS - 1, (int)ceilf((qy - fminY + r) * hInv));
+  const bool hasWindow = t < nQ && !(minCX >= ORBX_GRID_COLS || maxCX < 0 || minCY >= ORBX_GRID_ROWS || maxCY < 0);
+
+  // ---- candidate list of my query, built once: every train inside the window, with its Hamming distance ----
+  int nCand = 0;
+  if (hasWindow) {
+    for (int e = 0; e < nT; e++) {
+      const int cx = tCx[e], cy = tCy[e];
+      if (cx < minCX || cx > maxCX || cy < minCY || cy > maxCY) continue;
+      const float dx = tX[e] - qx, dy = tY[e] - qy;
+      if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
+      int dist = 0;
+#pragma unroll
+      for (int w = 0; w < 8; w++) dist += __popc(qd[w] ^ tDesc[w][e]);
+      if (nCand < MJ_CMAX) candList[nCand * MJ_CAP + t] = ((uint32_t)dist << 8) | (uint32_t)e;
+      nCand++;
+    }
+    if (nCand > MJ_CMAX) sOverflow = 1;
+  }
+  if (t < nT) tOrd[t] = ((uint32_t)(tCx[t] * ORBX_GRID_ROWS + tCy[t]) << 20) | (uint32_t)tIdx[t];
+  __syncthreads();
+  if (sOverflow) {  // a window with more than MJ_CMAX trains: leave the pair to the sequential kernels
+    if (t == 0) nmatchesOut[pair] = MATCH_PENDING;
+    return;
+  }
+  // outcome of my query: 0 = no candidate in the window, 1 = invalid by distance, 2 = invalid by ratio, 3 = accepted
+  int outcome = 0, bestT = -1, bestD = 0;
+  bool converged = false;
+  for (int sweep = 0; sweep < MJ_SWEEPS; sweep++) {
+    int nOutcome = 0, nBestT = -1, nBestD = 0;
+    if (nCand > 0) {
+      unsigned long long best = MATCH_NONE;  // dist << 32 | cell << 20 | train index
+      int second = INF_DIST, bt = -1;
+      for (int k = 0; k < nCand; k++) {
+        const uint32_t ce = candList[k * MJ_CAP + t];
+        const int e = ce & 255, dist = (int)(ce >> 8);
+        // vMatchedDistance[e] as query t sees it: smallest distance of an earlier accepted query that chose e
+        int md = INF_DIST;
+        const int nc = min(clCount[e], MJ_K);
+        for (int c = 0; c < nc; c++)
+          if ((int)clQ[e][c] < t) md = min(md, (int)clD[e][c]);
+        if (md <= dist) continue;  // ORBmatcher.cpp:67
+        const unsigned long long key = ((unsigned long long)dist << 32) | tOrd[e];
+        if (key < best) {
+          second = min(second, (int)(best >> 32));
+          best = key;
+          bt = e;
+        } else {
+          second = min(second, dist);
+        }
+      }
+      const int bd = (int)(best >> 32);
+      if (best == MATCH_NONE || bd > TH_LOW) nOutcome = 1;
+      else if ((float)bd > mp.nnratio * (float)second) nOutcome = 2;
+      else { nOutcome = 3; nBestT = bt; nBestD = bd; }
+    }
+    const bool changed = nOutcome != outcome || nBestT != bestT || nBestD != bestD;
+    outcome = nOutcome; bestT = nBestT; bestD = nBestD;
+    if (t == 0) sChanged = 0;
+    __syncthreads();
+    if (changed) sChanged = 1;
+    if (t < MJ_CAP) clCount[t] = 0;
+    __syncthreads();
+    if (!sChanged) { converged = true; break; }
+    if (outcome == 3) {
+      const int slot = atomicAdd(&clCount[bestT], 1);
+      if (slot < MJ_K) { clQ[bestT][slot] = (uint16_t)t; clD[bestT][slot] = (uint16_t)bestD; }
+      else sOverflow = 1;
+    }
+    __syncthreads();
+    if (sOverflow) break;
+  }
+  if (!converged) {  // block-uniform (sChanged / sOverflow are read after barriers)
+    if (t == 0) nmatchesOut[pair] = MATCH_PENDING;
+    return;
+  }
+  // ---- final bookkeeping from the converged outcomes ----
+  if (t < MJ_CAP) lastQ[t] = -1;
+  __syncthreads();
+  if (outcome == 3) atomicMax(&lastQ[bestT], t);
+  if (outcome == 1) atomicAdd(&sBadDist, 1);
+  if (outcome == 2) atomicAdd(&sBadRatio, 1);
+  int bin = -1;
+  if (outcome == 3 && mp.checkOri) {
+    float rot = qang - tAng[bestT];
+    if (rot < 0.0f) rot += 360.0f;
+    bin = (int)roundf(rot * (HISTO_LENGTH / 360.0f));
+    if (bin == HISTO_LENGTH) bin = 0;
+    if (bin < 0 || bin >= HISTO_LENGTH) bin = -1;
+    if (bin >= 0) atomicAdd(&hist[bin], 1);
+  }
+  __syncthreads();
+  // nmatches before pruning = trains that ended up with a claimant (every steal took one match away again)
+  if (t < nT && lastQ[t] >= 0) atomicAdd(&sNm, 1);
+  if (outcome == 3 && lastQ[bestT] == t) m12[qi] = (int)tIdx[bestT];
+  if (mp.checkOri) {
+    if (t == 0) {  // ComputeThreeMaxima, ORBmatcher.cpp:152-183
+      int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+      for (int i = 0; i < HISTO_LENGTH; i++) {
+        const int s = hist[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+      }
+      if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+      else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+      sKeep[0] = ind1; sKeep[1] = ind2; sKeep[2] = ind3;
+    }
+    __syncthreads();
+    // every accepted query sits in rotHist, also one whose match was stolen later (double decrement, :130-138)
+    if (bin >= 0 && bin != sKeep[0] && bin != sKeep[1] && bin != sKeep[2]) {
+      m12[qi] = -1;
+      atomicSub(&sNm, 1);
+      atomicAdd(&sBadOri, 1);
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    nmatchesOut[pair] = sNm;
+    if (statsOut) { statsOut[pair * 3] = sBadDist; statsOut[pair * 3 + 1] = sBadRatio; statsOut[pair * 3 + 2] = sBadOri; }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
 // k_match_wave: one WAVE per frame pair, everything the sequential query loop touches lives in LDS:
 // the octave-0 queries of F1 and the grid-eligible octave-0 trains of F2 (position, cell, angle, descriptor words
 // stored word-major so that lane e reading word w is bank-conflict free), vMatchedDistance, vnMatches21 and the
@@ -724,6 +965,7 @@ __global__ __launch_bounds__(64) void k_match_wave(const int* __restrict__ pairF
 
   const int lane = threadIdx.x;
   const int pair = blockIdx.x + mp.pair0;
+  if (nmatchesOut[pair] != MATCH_PENDING) return;  // already done by k_match_jacobi
   const int fa = pairFirst[pair], fb = pairSecond[pair];
   const int n1 = nkp[fa], n2 = nkp[fb];
   const int cap = mp.capacity;
@@ -1117,7 +1359,10 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
   mp.capacity = capacity; mp.window = window; mp.nnratio = nnratio; mp.checkOri = checkOri; mp.b = b;
   mp.onlyPending = 1;
   mp.pair0 = pair0;
-  // small pairs: one wave each, LDS resident; whatever it marks MATCH_PENDING is done by the general kernel
+  // small pairs (<= 256 octave-0 queries and eligible trains): parallel fixpoint sweeps, one thread per query;
+  // what it marks MATCH_PENDING goes to the sequential one-wave kernel (<= 512), and the rest to the general kernel
+  hipLaunchKernelGGL(k_match_jacobi, dim3(nPairs), dim3(MJ_CAP), 0, st, dFirst, dSecond, kps, desc, nkp, mp, matches12, nmatches,
+                     stats);
   hipLaunchKernelGGL(k_match_wave, dim3(nPairs), dim3(64), 0, st, dFirst, dSecond, kps, desc, nkp, mp, matches12, nmatches,
                      stats);
   hipLaunchKernelGGL(k_match, dim3(nPairs), dim3(MATCH_T), 0, st, dFirst, dSecond, kps, desc, nkp, mp, matches12, nmatches,
