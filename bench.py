@@ -39,8 +39,7 @@ def algorithmic_bytes(w, h, n_kp):
     return {
         "pyramid": (sp - P[-1]) + (sp - P[0]),          # level reads + level writes, 7 launches
         "fast": sp,                                      # every level pixel read once
-        "blur": 2 * sp,                                  # blur read + blur write
-        "describe": n_kp * (749 + 512) + n_kp * 60,      # disc + samples, keypoint + descriptor out
+        "describe": 2 * sp + n_kp * (749 + 512) + n_kp * 60,  # blur read+write of the model, disc + samples, outputs
         "total": 5 * sp - P[0] - P[-1] + 1321 * n_kp,
     }
 
@@ -138,8 +137,8 @@ def main():
         nm_mean = float(d_nm.float().mean().item())
         ab = algorithmic_bytes(W, H, n_kp)
         # dominant kernel = stage with the largest device time per step; all three are HBM-streaming / gather bound
-        dev_ms = {s: prof[s][0] / args.steps for s in ("pyramid", "fast", "blur", "describe", "match")}
-        kern = max(("pyramid", "fast", "blur", "describe"), key=lambda s: dev_ms[s])
+        dev_ms = {s: prof[s][0] / args.steps for s in ("pyramid", "fast", "describe", "match")}
+        kern = max(("pyramid", "fast", "describe"), key=lambda s: dev_ms[s])
         launches = max(prof[kern][1], 1)
         avg_launch_ms = prof[kern][0] / launches
         bytes_per_launch = ab[kern] * B * args.steps / launches
@@ -157,8 +156,8 @@ def main():
                                    % (B, B // 2),
                        "frames_per_gpu": B, "pairs_per_gpu": B // 2, "mean_keypoints": n_kp, "mean_nmatches": nm_mean,
                        "parallelism": "frames sharded per GPU (%d ranks), RCCL all_gather of keypoint counts" % world},
-            "roofline": {"bound": "hbm", "kernel": {"pyramid": "k_resize", "fast": "k_fast", "blur": "k_blur",
-                                                   "describe": "k_describe"}[kern],
+            "roofline": {"bound": "hbm", "kernel": {"pyramid": "k_resize_dw", "fast": "k_fast",
+                                                   "describe": "k_describe_patch"}[kern],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "whole_path_GBs": ab["total"] * B * world * args.steps / dt / 1e9},

@@ -95,8 +95,8 @@ int orbx_extract_batch(orbx_ctx* ctx, int n_frames, const uint8_t* imgs, int wid
 
 /* Same, but the frames are already resident in device memory (HBM) and results stay there:
  * d_kps / d_desc32 / d_n_out are device pointers (d_n_out: int32[n_frames]).  Nothing is copied
- * to the host except what the host-side selection stage needs.  The call returns after the work
- * has been issued and completed on the ctx stream (it synchronises internally between stages). */
+ * to the host except two error flags and the per-frame counts; there is no host round trip between
+ * the stages.  The call returns after the work has completed on the ctx stream. */
 int orbx_extract_batch_device(orbx_ctx* ctx, int n_frames, const uint8_t* d_imgs, int width, int height,
                               int stride, size_t frame_stride_bytes, orbx_keypoint* d_kps, uint8_t* d_desc32,
                               int capacity, int32_t* d_n_out);
@@ -145,8 +145,7 @@ int orbx_extract_match_batch_device(orbx_ctx* ctx, int n_frames, const uint8_t* 
 #define ORBX_STAGE_SELECT 2 /* quadtree selection incl. its transfers */
 #define ORBX_STAGE_DESCRIBE 3
 #define ORBX_STAGE_MATCH 4
-#define ORBX_STAGE_BLUR 5 /* whole-level Gaussian blur (runs between FAST/selection and DESCRIBE) */
-#define ORBX_STAGE_COUNT 6
+#define ORBX_STAGE_COUNT 5
 /* enable: record hipEvents around every stage; accumulated device ms and launch counts since the
  * last reset are returned by orbx_profile_get (arrays of ORBX_STAGE_COUNT). */
 int orbx_profile_enable(orbx_ctx* ctx, int on);

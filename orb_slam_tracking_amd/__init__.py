@@ -28,7 +28,7 @@ assert KEYPOINT_DTYPE.itemsize == 28
 
 E_EMPTY, E_BADARG, E_TOOSMALL, E_HIP, E_CAPACITY = -1, -2, -3, -4, -5
 _ERRNAMES = {-1: "ORBX_E_EMPTY", -2: "ORBX_E_BADARG", -3: "ORBX_E_TOOSMALL", -4: "ORBX_E_HIP", -5: "ORBX_E_CAPACITY"}
-STAGES = ("pyramid", "fast", "select", "describe", "match", "blur")
+STAGES = ("pyramid", "fast", "select", "describe", "match")
 
 
 class OrbxError(RuntimeError):

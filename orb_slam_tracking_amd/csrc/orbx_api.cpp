@@ -25,11 +25,6 @@ hipError_t launch_resize(hipStream_t st, int nFrames, const uint8_t* src, long l
                          const ResizeTab* ytab, int dwordPath);
 hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, int img0Aligned,
                        const uint8_t* pyr, const Geom& g, uint32_t* cand, int* candCount, int* overflow);
-hipError_t launch_blur(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, int img0Aligned,
-                       const uint8_t* pyr, const Geom& g, uint8_t* blur);
-hipError_t launch_describe(hipStream_t st, int nFrames, int maxSel, const uint8_t* img0, long long img0FrameStride,
-                           const uint8_t* pyr, const uint8_t* blur, const Geom& g, const SelKp* sel, const int* nsel,
-                           orbx_keypoint* kps, uint8_t* desc, int capacity);
 hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const uint8_t* img0, long long img0FrameStride,
                                  int img0Aligned, const uint8_t* pyr, const Geom& g, const SelKp* sel, const int* nsel,
                                  orbx_keypoint* kps, uint8_t* desc, int capacity);
@@ -72,8 +67,6 @@ struct orbx_ctx {
   // device buffers
   uint8_t* dPyr = nullptr;
   size_t pyrBytes = 0;
-  uint8_t* dBlur = nullptr;  // blurred copy of every level (incl. level 0)
-  size_t blurBytes = 0;
   uint32_t* dCand = nullptr;
   size_t candEntries = 0;
   int* dCandCount = nullptr;
@@ -190,8 +183,8 @@ int buildGeometry(orbx_ctx* c, int w, int h, int stride0, Geom* out, std::vector
   g.iniTh = std::min(std::max(c->p.ini_th_fast, 0), 255);
   g.minTh = std::min(std::max(c->p.min_th_fast, 0), 255);
   g.selCap = c->selCap;
-  int cellBase = 0, blurTiles = 0;
-  int64_t pyrOff = 0, candOff = 0, blurOff = 0;
+  int cellBase = 0;
+  int64_t pyrOff = 0, candOff = 0;
   int tabOff = 0;
   if (tab) tab->clear();
   int pw = 0, ph = 0;
@@ -230,13 +223,6 @@ int buildGeometry(orbx_ctx* c, int w, int h, int stride0, Geom* out, std::vector
     L.quota = c->quota[l];
     L.scale = c->scale[l];
     L.patchSize = (int)(31 * c->scale[l]);  // cpp:1165
-    L.blurStride = alignUp(L.w, 64);
-    L.blurFrameStride = (int64_t)L.blurStride * L.h;
-    L.blurOff = blurOff;
-    blurOff += L.blurFrameStride * c->maxB;
-    L.blurTilesX = (L.w + 127) / 128;
-    L.blurTileBase = blurTiles;
-    blurTiles += L.blurTilesX * ((L.h + 31) / 32);
     if (l == 0) {
       L.stride = stride0;
       L.imgOff = 0;
@@ -283,13 +269,12 @@ int buildGeometry(orbx_ctx* c, int w, int h, int stride0, Geom* out, std::vector
     ph = L.h;
   }
   g.nCellsTotal = cellBase;
-  g.nBlurTiles = blurTiles;
   *out = g;
   return ORBX_OK;
 }
 
 struct Sizes {
-  size_t pyrBytes, candEntries, tabEntries, blurBytes;
+  size_t pyrBytes, candEntries, tabEntries;
 };
 Sizes sizesOf(const orbx_ctx* c, const Geom& g, size_t tabEntries) {
   Sizes s{};
@@ -297,7 +282,6 @@ Sizes sizesOf(const orbx_ctx* c, const Geom& g, size_t tabEntries) {
   s.pyrBytes = g.nlevels > 1 ? (size_t)(last.imgOff + last.frameStride * c->maxB) : 0;
   s.candEntries = (size_t)(last.candOff + (int64_t)last.candCap * c->maxB);
   s.tabEntries = tabEntries;
-  s.blurBytes = (size_t)(last.blurOff + last.blurFrameStride * c->maxB);
   return s;
 }
 
@@ -344,7 +328,7 @@ int ensureGeometry(orbx_ctx* ctx, int w, int h, int stride0) {
   OctLaunch oct;
   const size_t octBytes = buildOctLaunch(ctx, g, &oct);
   if (s.pyrBytes > ctx->pyrBytes || s.candEntries > ctx->candEntries || s.tabEntries > ctx->tabEntries ||
-      s.blurBytes > ctx->blurBytes || octBytes > ctx->octScratchBytes) {
+      octBytes > ctx->octScratchBytes) {
     ctx->err = "internal: geometry exceeds the buffers sized at orbx_create";
     return ORBX_E_BADARG;
   }
@@ -434,18 +418,7 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
     HIPCHK(launch_sel_compact(st, n, ctx->dSelStage, ctx->dNselLevel, oct, ctx->dSel, ctx->dNsel, g.selCap, ctx->dOverflow + 1));
     tm.stop(ctx->maxQuota <= 256 ? 3 : 2);
   }
-  static const bool useLevelBlur = getenv("ORBX_LEVEL_BLUR") != nullptr;  // A/B switch between the two describe designs
-  if (useLevelBlur) {
-    {
-      StageTimer tm(ctx, ORBX_STAGE_BLUR, si, st);
-      HIPCHK(launch_blur(st, n, a.dImg0, a.frameStride0, a.aligned0, ctx->dPyr, g, ctx->dBlur));
-      tm.stop(1);
-    }
-    StageTimer tm(ctx, ORBX_STAGE_DESCRIBE, si, st);
-    HIPCHK(launch_describe(st, n, g.selCap, a.dImg0, a.frameStride0, ctx->dPyr, ctx->dBlur, g, ctx->dSel, ctx->dNsel, a.dKps,
-                           a.dDesc, a.capacity));
-    tm.stop(1);
-  } else {
+  {
     StageTimer tm(ctx, ORBX_STAGE_DESCRIBE, si, st);
     HIPCHK(launch_describe_patch(st, n, g.selCap, a.dImg0, a.frameStride0, a.aligned0, ctx->dPyr, g, ctx->dSel, ctx->dNsel,
                                  a.dKps, a.dDesc, a.capacity));
@@ -591,7 +564,6 @@ int orbx_create(const orbx_params* params, int device_id, int max_width, int max
   Sizes s = sizesOf(ctx, g, tab.size());
   // row strides grow by at most 63 bytes and tables by a few entries for smaller frames: keep headroom
   ctx->pyrBytes = s.pyrBytes + (size_t)64 * max_height * ctx->p.nlevels * max_batch + 4096;
-  ctx->blurBytes = s.blurBytes + (size_t)64 * max_height * ctx->p.nlevels * max_batch + 4096;
   ctx->candEntries = s.candEntries + 1024;
   ctx->tabEntries = s.tabEntries + 64 * ctx->p.nlevels;
   const size_t B = (size_t)max_batch, nl = (size_t)ctx->p.nlevels;
@@ -602,7 +574,6 @@ int orbx_create(const orbx_params* params, int device_id, int max_width, int max
 #define ALLOCH(ptr, bytes)                                                     \
   if (hipHostMalloc((void**)&(ptr), std::max<size_t>((bytes), 16), hipHostMallocDefault) != hipSuccess) return fail(ORBX_E_HIP)
   ALLOC(ctx->dPyr, ctx->pyrBytes);
-  ALLOC(ctx->dBlur, ctx->blurBytes);
   ALLOC(ctx->dCand, ctx->candEntries * 4);
   ALLOC(ctx->dCandCount, (B * nl + 2) * sizeof(int));
   ctx->dOverflow = ctx->dCandCount + B * nl;  // [0] candidate overflow, [1] selection error
@@ -640,7 +611,7 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->st) (void)hipStreamSynchronize(ctx->st);
-  void* dev[] = {ctx->dPyr, ctx->dBlur, ctx->dCand, ctx->dCandCount, ctx->dTab, ctx->dSel, ctx->dNsel, ctx->dSelStage, ctx->dNselLevel,
+  void* dev[] = {ctx->dPyr, ctx->dCand, ctx->dCandCount, ctx->dTab, ctx->dSel, ctx->dNsel, ctx->dSelStage, ctx->dNselLevel,
                  ctx->dOctScratch, ctx->dIn, ctx->dKps, ctx->dDesc, ctx->dMatchScratch, ctx->dPairs, ctx->dMk, ctx->dMd,
                  ctx->dMi};
   for (void* p : dev)

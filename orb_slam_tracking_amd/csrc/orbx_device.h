@@ -26,11 +26,6 @@ struct LevelGeom {
   int64_t imgOff;             // byte offset of frame 0's image inside the pyramid buffer (levels >= 1)
   int64_t frameStride;        // bytes between consecutive frames of this level
   int64_t candOff;            // entry offset of frame 0's candidate list (frame stride = candCap)
-  int64_t blurOff;            // byte offset of frame 0's blurred level (all levels incl. 0) in the blur buffer
-  int64_t blurFrameStride;    // bytes between consecutive frames of this blurred level
-  int32_t blurStride;         // row stride of the blurred level (multiple of 64)
-  int32_t blurTileBase;       // index of this level's first 128x32 blur tile in the flattened tile list
-  int32_t blurTilesX;
   int32_t resizeSpanOk;       // 1 if the taps of any 4 consecutive outputs span <= 8 source pixels (k_resize_dw usable)
 };
 
@@ -39,9 +34,7 @@ struct Geom {
   int32_t nCellsTotal;
   int32_t iniTh, minTh;
   int32_t selCap;             // per-frame capacity of the selected-keypoint list (== output capacity)
-  int32_t nBlurTiles;
   int32_t frame0;             // first frame of this launch (a batch may be issued as several sub-batches / streams)
-  int32_t pad_;
   LevelGeom L[ORBX_MAX_LEVELS];
 };
 

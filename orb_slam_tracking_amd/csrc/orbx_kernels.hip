@@ -3,10 +3,9 @@
 //   k_resize    pyramid level l from level l-1      (ORBextractor::ComputePyramid, cpp:1660-1713 -> cv::resize)
 //   k_fast      per-cell FAST-9-16 + in-cell NMS + threshold fallback
 //                                                    (ComputeKeyPointsOctTree cell loops, cpp:1078-1141 -> cv::FAST)
-//   k_blur      7x7 Gaussian of every level, separable fixed point, LDS tiles  (GaussianBlur cpp:1598-1606)
-//   k_describe  IC-angle + steered BRIEF, one wave per keypoint
-//                                                    (IC_Angle cpp:103-159, computeOrbDescriptor cpp:169-228,
-//                                                     assembly cpp:1557-1652)
+//   k_describe_patch  IC-angle + 7x7 Gaussian (patch-local, v_dot4/v_dot2 fixed point) + steered BRIEF, one wave per
+//               keypoint                              (IC_Angle cpp:103-159, GaussianBlur cpp:1598-1606,
+//                                                     computeOrbDescriptor cpp:169-228, assembly cpp:1557-1652)
 //   k_match     SearchForInitialization, one workgroup per frame pair
 //                                                    (ORBmatcher.cpp:11-183, Frame.cpp:89-99,163-206, FORB.cpp:77-101)
 //
@@ -272,7 +271,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img0, 
 }
 
 // =================================================================================================
-// K4+K5+K6  whole-level Gaussian blur, then orientation + steered BRIEF per keypoint.
+// K4+K5+K6  orientation + patch-local Gaussian + steered BRIEF per keypoint.
 // =================================================================================================
 __device__ const int8_t d_pattern[256 * 4] = {
 #include "orbx_pattern_data.inc"
@@ -308,207 +307,9 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   return a;
 }
 
-// -------------------------------------------------------------------------------------------------
-// K5  cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) of every pyramid level (cpp:1598-1606), bit-exact fixed point:
-// Q8 taps [18,34,48,56,48,34,18], horizontal sums exact in u16, vertical in u32, (sum + 2^15) >> 16.
-// One workgroup = one 128x32 output tile; input tile (+3 halo, reflected at the level's own edges) and the horizontal
-// sums live in LDS; each thread produces 4 adjacent pixels per step (dword LDS reads, one u32 store).
-// -------------------------------------------------------------------------------------------------
-#define BLUR_W 128
-#define BLUR_H 32
-#define BLUR_IN_WORDS 36  // 34 dwords used per input row: columns x0-4 .. x0+131
-#define BLUR_ROWS (BLUR_H + 6)
-
 typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t dot2u16(uint32_t a, uint32_t b, uint32_t c) {  // v_dot2_u32_u16
   return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, b), c, false);
-}
-
-__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ img0, long long img0FrameStride, int img0Aligned,
-                                              const uint8_t* __restrict__ pyr, const Geom g, uint8_t* __restrict__ blur) {
-  // in32[r][d]: input bytes of row y0-3+r, columns x0-4+4d .. +3;  hz2[rp][c]: horizontal sums (exact, < 2^16) of rows
-  // 2rp (low half) and 2rp+1 (high half) at column x0+c
-  __shared__ __attribute__((aligned(16))) uint32_t in32[BLUR_ROWS * BLUR_IN_WORDS];
-  __shared__ __attribute__((aligned(16))) uint32_t hz2[(BLUR_ROWS / 2) * BLUR_W];
-  const int t = threadIdx.x, f = blockIdx.y + g.frame0;
-  int level = 0;
-  const int tid = blockIdx.x;
-  while (level + 1 < g.nlevels && tid >= g.L[level + 1].blurTileBase) level++;
-  const LevelGeom& L = g.L[level];
-  const int local = tid - L.blurTileBase;
-  const int ty = local / L.blurTilesX, tx = local - ty * L.blurTilesX;
-  const int x0 = tx * BLUR_W, y0 = ty * BLUR_H;
-  const uint8_t* img = level == 0 ? img0 + (long long)f * img0FrameStride : pyr + L.imgOff + (long long)f * L.frameStride;
-  const int w = L.w, h = L.h, stride = L.stride;
-  const bool aligned = level > 0 || img0Aligned != 0;
-  // ---- input tile: aligned dwords where the whole word lies inside the row, else bytes with REFLECT_101
-  //      (clamped afterwards: columns/rows beyond the level only feed outputs that are never stored) ----
-  for (int idx = t; idx < BLUR_ROWS * 34; idx += 256) {
-    const int r = idx / 34, d = idx - r * 34;
-    int yy = y0 - 3 + r;
-    yy = yy < 0 ? -yy : yy; yy = yy >= h ? 2 * h - 2 - yy : yy; yy = min(max(yy, 0), h - 1);
-    const uint8_t* row = img + (long long)yy * stride;
-    const int xs = x0 - 4 + 4 * d;
-    uint32_t word;
-    if (aligned && xs >= 0 && xs + 4 <= w) {
-      word = *reinterpret_cast<const uint32_t*>(row + xs);
-    } else {
-      word = 0;
-#pragma unroll
-      for (int b = 0; b < 4; b++) {
-        int xx = xs + b;
-        xx = xx < 0 ? -xx : xx; xx = xx >= w ? 2 * w - 2 - xx : xx; xx = min(max(xx, 0), w - 1);
-        word |= (uint32_t)row[xx] << (8 * b);
-      }
-    }
-    in32[r * BLUR_IN_WORDS + d] = word;
-  }
-  __syncthreads();
-  // ---- horizontal pass with v_dot4_u32_u8: output column c (x0+c) uses input bytes c+1 .. c+7 of the row.
-  //      One step = 4 columns x 2 rows (one row pair) -> one 16-byte LDS store ----
-  {
-    const uint32_t K0 = 18u | (34u << 8) | (48u << 16) | (56u << 24), K1 = 48u | (34u << 8) | (18u << 16);
-    for (int it = t; it < (BLUR_ROWS / 2) * (BLUR_W / 4); it += 256) {
-      const int rp = it >> 5, g4 = it & 31;
-      uint32_t o[2][4];
-#pragma unroll
-      for (int rr = 0; rr < 2; rr++) {
-        const uint32_t* pw = &in32[(2 * rp + rr) * BLUR_IN_WORDS + g4];  // only 4-byte aligned
-        uint4 W;
-        W.x = pw[0]; W.y = pw[1]; W.z = pw[2]; W.w = 0;
-        // bytes 1..7 / 2..8 / 3..9 / 4..10 of the 16 loaded bytes
-        const uint32_t a1 = __builtin_amdgcn_alignbyte(W.y, W.x, 1), b1 = __builtin_amdgcn_alignbyte(W.z, W.y, 1);
-        const uint32_t a2 = __builtin_amdgcn_alignbyte(W.y, W.x, 2), b2 = __builtin_amdgcn_alignbyte(W.z, W.y, 2);
-        const uint32_t a3 = __builtin_amdgcn_alignbyte(W.y, W.x, 3), b3 = __builtin_amdgcn_alignbyte(W.z, W.y, 3);
-        o[rr][0] = __builtin_amdgcn_udot4(a1, K0, __builtin_amdgcn_udot4(b1, K1, 0u, false), false);
-        o[rr][1] = __builtin_amdgcn_udot4(a2, K0, __builtin_amdgcn_udot4(b2, K1, 0u, false), false);
-        o[rr][2] = __builtin_amdgcn_udot4(a3, K0, __builtin_amdgcn_udot4(b3, K1, 0u, false), false);
-        o[rr][3] = __builtin_amdgcn_udot4(W.y, K0, __builtin_amdgcn_udot4(W.z, K1, 0u, false), false);
-      }
-      uint4 pk;
-      pk.x = o[0][0] | (o[1][0] << 16);
-      pk.y = o[0][1] | (o[1][1] << 16);
-      pk.z = o[0][2] | (o[1][2] << 16);
-      pk.w = o[0][3] | (o[1][3] << 16);
-      *reinterpret_cast<uint4*>(&hz2[rp * BLUR_W + 4 * g4]) = pk;
-    }
-  }
-  __syncthreads();
-  // ---- vertical pass with v_dot2_u32_u16 + rounding.  One step = 4 columns x 2 output rows (2q, 2q+1), which use the
-  //      same four row pairs q..q+3:  even row taps (18,34)(48,56)(48,34)(18,0), odd row taps (0,18)(34,48)(56,48)(34,18)
-  uint8_t* dst = blur + L.blurOff + (long long)f * L.blurFrameStride;
-  for (int it = t; it < (BLUR_H / 2) * (BLUR_W / 4); it += 256) {
-    const int q = it >> 5, c4 = (it & 31) * 4;
-    const int y = y0 + 2 * q, x = x0 + c4;
-    if (y >= h || x >= w) continue;
-    const uint4 P0 = *reinterpret_cast<const uint4*>(&hz2[(q + 0) * BLUR_W + c4]);
-    const uint4 P1 = *reinterpret_cast<const uint4*>(&hz2[(q + 1) * BLUR_W + c4]);
-    const uint4 P2 = *reinterpret_cast<const uint4*>(&hz2[(q + 2) * BLUR_W + c4]);
-    const uint4 P3 = *reinterpret_cast<const uint4*>(&hz2[(q + 3) * BLUR_W + c4]);
-    const uint32_t E0 = 18u | (34u << 16), E1 = 48u | (56u << 16), E2 = 48u | (34u << 16), E3 = 18u;
-    const uint32_t O0 = 18u << 16, O1 = 34u | (48u << 16), O2 = 56u | (48u << 16), O3 = 34u | (18u << 16);
-    const uint32_t p0[4] = {P0.x, P0.y, P0.z, P0.w}, p1[4] = {P1.x, P1.y, P1.z, P1.w};
-    const uint32_t p2[4] = {P2.x, P2.y, P2.z, P2.w}, p3[4] = {P3.x, P3.y, P3.z, P3.w};
-    uint32_t we = 0, wo = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const uint32_t se = dot2u16(p0[j], E0, dot2u16(p1[j], E1, dot2u16(p2[j], E2, dot2u16(p3[j], E3, 32768u))));
-      const uint32_t so = dot2u16(p0[j], O0, dot2u16(p1[j], O1, dot2u16(p2[j], O2, dot2u16(p3[j], O3, 32768u))));
-      we |= (se >> 16) << (8 * j);  // <= 255: the taps sum to 256 in each direction
-      wo |= (so >> 16) << (8 * j);
-    }
-    // rows of the blurred level are padded to a multiple of 64 bytes: a full word may be stored at the right edge
-    *reinterpret_cast<uint32_t*>(dst + (long long)y * L.blurStride + x) = we;
-    if (y + 1 < h) *reinterpret_cast<uint32_t*>(dst + (long long)(y + 1) * L.blurStride + x) = wo;
-  }
-}
-
-// -------------------------------------------------------------------------------------------------
-// K4+K6  IC_Angle (cpp:103-159) on the un-blurred level + steered BRIEF (cpp:169-228) on the blurred level.
-// One wave handles DESC_G consecutive keypoints, no LDS: the 749 disc pixels and the 512 sample points of a keypoint
-// are gathered straight from L2/HBM (all within a 37x37 window).  The f64 cos/sin (the expensive, per-keypoint scalar
-// part) is evaluated once per wave with lane j working for keypoint j instead of 64 redundant copies per keypoint.
-// -------------------------------------------------------------------------------------------------
-#define DESC_G 16
-__global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ img0, long long img0FrameStride,
-                                                  const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
-                                                  const Geom g, const SelKp* __restrict__ sel, const int* __restrict__ nsel,
-                                                  orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc, int capacity) {
-  const int f = blockIdx.y + g.frame0, lane = threadIdx.x & 63;
-  const int n = nsel[f];
-  const int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DESC_G;  // this wave's DESC_G consecutive keypoints
-  if (base >= n) return;  // wave-uniform; no barriers below
-  const SelKp* ksel = sel + (long long)f * g.selCap;
-  const uint8_t* frame0 = img0 + (long long)f * img0FrameStride;
-  // ---- IC_Angle: m10 = sum u*I, m01 = sum v*I over the 749-pixel disc (keypoints are >= 19 px inside the level).
-  //      Lane j keeps the moments of the wave's j-th keypoint ----
-  int myM10 = 0, myM01 = 0;
-  const int u = (lane & 31) - 15;  // lanes 31 and 63 idle
-  const int au = u < 0 ? -u : u;
-  for (int j = 0; j < DESC_G && base + j < n; j++) {
-    const SelKp k = ksel[base + j];
-    const LevelGeom& L = g.L[k.level];
-    const uint8_t* img = k.level == 0 ? frame0 : pyr + L.imgOff + (long long)f * L.frameStride;
-    const uint8_t* c = img + (long long)k.y * L.stride + k.x + u;
-    int m10 = 0, m01 = 0;
-#pragma unroll 8
-    for (int it = 0; it < 16; it++) {
-      const int v = -15 + 2 * it + (lane >> 5);
-      const int av = v < 0 ? -v : v;
-      if (av <= 15 && au <= 15 && au <= c_umax[av & 15]) {
-        const int I = c[(long long)v * L.stride];
-        m10 += u * I;
-        m01 += v * I;
-      }
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      m10 += __shfl_xor(m10, o);
-      m01 += __shfl_xor(m01, o);
-    }
-    if (lane == j) { myM10 = m10; myM01 = m01; }
-  }
-  // one evaluation for all DESC_G keypoints: lane j -> angle, cos, sin of keypoint j.
-  // cos/sin of the f32 argument are evaluated in f64 and rounded to f32 (the oracle does the same).
-  const float myAngle = fast_atan2_deg((float)myM01, (float)myM10);
-  const float factorPI = (float)(3.14159265358979323846 / 180.f);
-  double sd, cd;
-  sincos((double)(myAngle * factorPI), &sd, &cd);
-  const float myCs = (float)cd, mySn = (float)sd;
-  // ---- steered BRIEF (cpp:169-228): lane i produces descriptor bits i, i+64, i+128, i+192 ----
-  char4 pt[4];
-#pragma unroll
-  for (int w = 0; w < 4; w++) pt[w] = reinterpret_cast<const char4*>(d_pattern)[w * 64 + lane];
-  for (int j = 0; j < DESC_G && base + j < n; j++) {
-    const SelKp k = ksel[base + j];
-    const LevelGeom& L = g.L[k.level];
-    const float angle = __shfl(myAngle, j), cs = __shfl(myCs, j), sn = __shfl(mySn, j);
-    const uint8_t* center = blur + L.blurOff + (long long)f * L.blurFrameStride + (long long)k.y * L.blurStride + k.x;
-    unsigned long long words[4];
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-      const float x0 = (float)pt[w].x, y0 = (float)pt[w].y, x1 = (float)pt[w].z, y1 = (float)pt[w].w;
-      const int r0 = __float2int_rn(x0 * sn + y0 * cs), c0 = __float2int_rn(x0 * cs - y0 * sn);
-      const int r1 = __float2int_rn(x1 * sn + y1 * cs), c1 = __float2int_rn(x1 * cs - y1 * sn);
-      const int t0 = center[r0 * L.blurStride + c0];
-      const int t1 = center[r1 * L.blurStride + c1];
-      words[w] = __ballot(t0 < t1);
-    }
-    const long long o = (long long)f * capacity + base + j;
-    if (lane < 4) reinterpret_cast<unsigned long long*>(desc + o * 32)[lane] = words[lane];
-    if (lane == 0) {
-      orbx_keypoint kp;
-      // cpp:1631-1634: pt *= scale for level != 0 (scale[0] == 1 exactly)
-      kp.x = k.level ? (float)k.x * L.scale : (float)k.x;
-      kp.y = k.level ? (float)k.y * L.scale : (float)k.y;
-      kp.size = (float)L.patchSize;
-      kp.angle = angle;
-      kp.response = (float)k.response;
-      kp.octave = k.level;
-      kp.class_id = -1;
-      kps[o] = kp;
-    }
-  }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -612,7 +413,8 @@ __global__ __launch_bounds__(64) void k_describe_patch(const uint8_t* __restrict
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  // ---- vertical pass + rounding: blurred rows 2q, 2q+1 from row pairs q..q+3 (see k_blur), lane = column with a
+  // ---- vertical pass + rounding with v_dot2_u32_u16 on row pairs: blurred rows 2q and 2q+1 both use pairs q..q+3,
+  //      even row taps (18,34)(48,56)(48,34)(18,0), odd row taps (0,18)(34,48)(56,48)(34,18); lane = column with a
   //      rolling window of row pairs; the blurred bytes overwrite the raw window (no longer needed) ----
   if (lane < PW_COLS) {
     const uint32_t E0 = 18u | (34u << 16), E1 = 48u | (56u << 16), E2 = 48u | (34u << 16), E3 = 18u;
@@ -1325,13 +1127,6 @@ hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long lo
   return hipGetLastError();
 }
 
-hipError_t launch_blur(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, int img0Aligned,
-                       const uint8_t* pyr, const Geom& g, uint8_t* blur) {
-  dim3 block(256, 1, 1), grid(g.nBlurTiles, nFrames, 1);
-  hipLaunchKernelGGL(k_blur, grid, block, 0, st, img0, img0FrameStride, img0Aligned, pyr, g, blur);
-  return hipGetLastError();
-}
-
 hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const uint8_t* img0, long long img0FrameStride,
                                  int img0Aligned, const uint8_t* pyr, const Geom& g, const SelKp* sel, const int* nsel,
                                  orbx_keypoint* kps, uint8_t* desc, int capacity) {
@@ -1339,15 +1134,6 @@ hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const 
   dim3 block(64, 1, 1), grid(maxSel, nFrames, 1);
   hipLaunchKernelGGL(k_describe_patch, grid, block, 0, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps, desc,
                      capacity);
-  return hipGetLastError();
-}
-
-hipError_t launch_describe(hipStream_t st, int nFrames, int maxSel, const uint8_t* img0, long long img0FrameStride,
-                           const uint8_t* pyr, const uint8_t* blur, const Geom& g, const SelKp* sel, const int* nsel,
-                           orbx_keypoint* kps, uint8_t* desc, int capacity) {
-  if (maxSel <= 0) return hipSuccess;
-  dim3 block(256, 1, 1), grid((maxSel + 4 * DESC_G - 1) / (4 * DESC_G), nFrames, 1);
-  hipLaunchKernelGGL(k_describe, grid, block, 0, st, img0, img0FrameStride, pyr, blur, g, sel, nsel, kps, desc, capacity);
   return hipGetLastError();
 }
 
