@@ -143,6 +143,16 @@ def main():
         avg_launch_ms = prof[kern][0] / launches
         bytes_per_launch = ab[kern] * B * args.steps / launches
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        kname = {"pyramid": "k_resize_dw", "fast": "k_fast", "describe": "k_describe_patch"}[kern]
+        # HBM bytes per launch from the committed PMC pass (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json);
+        # null when that profile has no entry for the dominant kernel
+        traffic = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["bytes_per_frame"].get(kname)
+            if tr:
+                traffic = (tr["fetch"] + tr["write"]) * B * args.steps / launches
+        except Exception:
+            traffic = None
         out = {
             "metric": "frames/sec (extract+match, 1000 feat, 640x480)",
             "value": B * world * args.steps / dt,
@@ -156,10 +166,9 @@ def main():
                                    % (B, B // 2),
                        "frames_per_gpu": B, "pairs_per_gpu": B // 2, "mean_keypoints": n_kp, "mean_nmatches": nm_mean,
                        "parallelism": "frames sharded per GPU (%d ranks), RCCL all_gather of keypoint counts" % world},
-            "roofline": {"bound": "hbm", "kernel": {"pyramid": "k_resize_dw", "fast": "k_fast",
-                                                   "describe": "k_describe_patch"}[kern],
+            "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "traffic": traffic, "avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "whole_path_GBs": ab["total"] * B * world * args.steps / dt / 1e9},
             "stage_ms_per_step": {s: prof[s][0] / args.steps for s in prof},
         }
