@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline leg")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 path)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -79,10 +82,16 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
 
     B = args.batch
     cap = 1000
@@ -97,7 +106,7 @@ def main():
     d_nm = torch.zeros(B // 2, dtype=torch.int32, device=dev)
     first = np.arange(0, B, 2, dtype=np.int32)
     second = first + 1
-    counts_all = torch.zeros(B * world, dtype=torch.int32, device=dev)
+    counts_all = torch.zeros(B * world, dtype=torch.int32, device=cdev)
 
     ext = orbx.ORBextractor(*PARAMS, max_width=W, max_height=H, max_batch=B, device=local_rank)
 
@@ -107,7 +116,7 @@ def main():
         ext.extract_match_batch_device(d_img, B, W, H, W, W * H, d_k, d_d, d_n, first, second, (0, W, 0, H), d_m, d_nm, None,
                                        100, 0.9, True, cap)
         if world > 1:
-            sharding.gather_counts(d_n, counts_all)  # RCCL all_gather over xGMI
+            sharding.gather_counts(d_n.to(cdev), counts_all)  # RCCL all_gather over xGMI (the call above has completed)
 
     def barrier():
         torch.cuda.synchronize()
@@ -126,7 +135,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = ext.profile_get()
