@@ -139,6 +139,27 @@ int orbx_extract_match_batch_device(orbx_ctx* ctx, int n_frames, const uint8_t* 
                                     const int32_t* h_second, const orbx_bounds* bounds, int window_size, float nnratio,
                                     int check_orientation, int32_t* d_matches12, int32_t* d_nmatches, int32_t* d_stats);
 
+/* ---- between extractor and matcher: Frame::UndistortKeyPoints / ComputeImageBounds ---------- */
+/* (SlamTypes/Frame.cpp:101-161)  The camera as the reference holds it: mK's four entries and
+ * mDistCoef = (k1, k2, p1, p2), all CV_32F (Config/Settings.hpp:28-39). */
+typedef struct orbx_camera {
+  float fx, fy, cx, cy;
+  float k1, k2, p1, p2;
+} orbx_camera;
+
+/* mvKeysUn of one frame, host memory: out[i] = kps[i] with pt replaced by cv::undistortPoints(pt, K, dist, R = I, P = K)
+ * (5 fixed iterations in f64, result stored as f32).  k1 == 0 copies the keypoints unchanged (Frame.cpp:138-142). */
+int orbx_undistort_keypoints(orbx_ctx* ctx, const orbx_keypoint* kps, int n, const orbx_camera* cam, orbx_keypoint* out);
+
+/* Batched, device-resident: frame f's d_n[f] keypoints at d_kps + f*capacity -> d_kps_un + f*capacity (the layout of
+ * orbx_extract_batch_device; d_kps_un may equal d_kps).  Feed d_kps_un to orbx_match_init_batch_device. */
+int orbx_undistort_batch_device(orbx_ctx* ctx, int n_frames, const orbx_keypoint* d_kps, const int32_t* d_n, int capacity,
+                                const orbx_camera* cam, orbx_keypoint* d_kps_un);
+
+/* Frame::ComputeImageBounds (Frame.cpp:101-134): the four image corners undistorted on the device, min/max truncated
+ * to the reference's static ints; k1 == 0 gives (0, width, 0, height). */
+int orbx_image_bounds(orbx_ctx* ctx, const orbx_camera* cam, int width, int height, orbx_bounds* out);
+
 /* ---- measurement hooks (bench.py; HIP events on the ctx stream) ---------------------------- */
 #define ORBX_STAGE_PYRAMID 0
 #define ORBX_STAGE_FAST 1

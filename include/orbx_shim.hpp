@@ -157,6 +157,23 @@ class ORBextractor {
 
   orbx_ctx* context() { return ctx_; }
 
+  // Drop-ins for the bodies of Frame::UndistortKeyPoints / Frame::ComputeImageBounds (SlamTypes/Frame.cpp:101-161):
+  //   void Frame::UndistortKeyPoints() { mpORBextractor->UndistortKeyPoints(mvKeys, cam, mvKeysUn); N = mvKeysUn.size(); }
+  //   void Frame::ComputeImageBounds() { mpORBextractor->ComputeImageBounds(cam, im.cols, im.rows, mnMinX, mnMaxX, mnMinY, mnMaxY); }
+  // with cam = {mK(0,0), mK(1,1), mK(0,2), mK(1,2), mDistCoef(0..3)} (all CV_32F, Settings.hpp:28-39).
+  void UndistortKeyPoints(const std::vector<KeyPointT>& mvKeys, const orbx_camera& cam, std::vector<KeyPointT>& mvKeysUn) {
+    mvKeysUn.resize(mvKeys.size());
+    const int r = orbx_undistort_keypoints(ctx_, reinterpret_cast<const orbx_keypoint*>(mvKeys.data()), (int)mvKeys.size(), &cam,
+                                           reinterpret_cast<orbx_keypoint*>(mvKeysUn.data()));
+    if (r != ORBX_OK) throw orbx::Error(r, orbx_last_error(ctx_));
+  }
+  void ComputeImageBounds(const orbx_camera& cam, int cols, int rows, int& mnMinX, int& mnMaxX, int& mnMinY, int& mnMaxY) {
+    orbx_bounds b{0, 0, 0, 0};
+    const int r = orbx_image_bounds(ctx_, &cam, cols, rows, &b);
+    if (r != ORBX_OK) throw orbx::Error(r, orbx_last_error(ctx_));
+    mnMinX = b.min_x; mnMaxX = b.max_x; mnMinY = b.min_y; mnMaxY = b.max_y;
+  }
+
  protected:
 #ifdef ORBX_WITH_OPENCV
   void refreshPyramid() {

@@ -793,6 +793,64 @@ int orbo_distribute(const float* xyr, int n, int minX, int maxX, int minY, int m
   for (int i = 0; i < (int)r.size() && i < cap; i++) { out_xyr[3 * i] = r[i].x; out_xyr[3 * i + 1] = r[i].y; out_xyr[3 * i + 2] = r[i].response; }
   return (int)r.size();
 }
+// ---------------------------------------------------------------------------------------------
+// keypoint undistortion + image bounds (SlamTypes/Frame.cpp:101-161).
+// cv::undistortPoints(src, dst, K, dist(k1,k2,p1,p2), R = I, P = K) restated from OpenCV 4.x:
+// K and dist are CV_32F (Config/Settings.hpp:32,39) converted to double; 5 fixed iterations
+// (TermCriteria(MAX_ITER, 5, 0.01)); all arithmetic in double, in this exact operation order; result cast to float.
+// ---------------------------------------------------------------------------------------------
+struct Camera { float fx, fy, cx, cy, k1, k2, p1, p2; };
+
+static void undistortPointD(const Camera& c, float xin, float yin, float* xo, float* yo) {
+  const double fx = c.fx, fy = c.fy, cx = c.cx, cy = c.cy;
+  const double k0 = c.k1, k1 = c.k2, k2 = c.p1, k3 = c.p2;  // OpenCV's k[0..3]; k[4..13] = 0
+  const double ifx = 1. / fx, ify = 1. / fy;
+  double x = xin, y = yin;
+  const double u = x, v = y;
+  x = (x - cx) * ifx;
+  y = (y - cy) * ify;
+  const double x0 = x, y0 = y;
+  for (int j = 0; j < 5; j++) {
+    const double r2 = x * x + y * y;
+    const double icdist = (1 + ((0. * r2 + 0.) * r2 + 0.) * r2) / (1 + ((0. * r2 + k1) * r2 + k0) * r2);
+    if (icdist < 0) {
+      x = (u - cx) * ifx;
+      y = (v - cy) * ify;
+      break;
+    }
+    const double deltaX = 2 * k2 * x * y + k3 * (r2 + 2 * x * x) + 0. * r2 + 0. * r2 * r2;
+    const double deltaY = k2 * (r2 + 2 * y * y) + 2 * k3 * x * y + 0. * r2 + 0. * r2 * r2;
+    x = (x0 - deltaX) * icdist;
+    y = (y0 - deltaY) * icdist;
+  }
+  // RR = P * R = K:  xx = fx*x + 0*y + cx, yy = 0*x + fy*y + cy, ww = 1 / (0*x + 0*y + 1)
+  const double xx = fx * x + 0. * y + cx, yy = 0. * x + fy * y + cy, ww = 1. / (0. * x + 0. * y + 1.);
+  *xo = (float)(xx * ww);
+  *yo = (float)(yy * ww);
+}
+
+void orbo_undistort_keypoints(const KP* in, int n, const float* cam8, KP* out) {  // Frame::UndistortKeyPoints, Frame.cpp:136-161
+  Camera c{cam8[0], cam8[1], cam8[2], cam8[3], cam8[4], cam8[5], cam8[6], cam8[7]};
+  for (int i = 0; i < n; i++) {
+    out[i] = in[i];
+    if (c.k1 != 0.0f) undistortPointD(c, in[i].x, in[i].y, &out[i].x, &out[i].y);
+  }
+}
+
+void orbo_image_bounds(const float* cam8, int cols, int rows, int32_t* b4) {  // Frame::ComputeImageBounds, Frame.cpp:101-134
+  Camera c{cam8[0], cam8[1], cam8[2], cam8[3], cam8[4], cam8[5], cam8[6], cam8[7]};
+  if (c.k1 != 0.0f) {
+    float m[4][2] = {{0.f, 0.f}, {(float)cols, 0.f}, {0.f, (float)rows}, {(float)cols, (float)rows}};
+    for (int i = 0; i < 4; i++) undistortPointD(c, m[i][0], m[i][1], &m[i][0], &m[i][1]);
+    b4[0] = (int)std::min(m[0][0], m[2][0]);  // mnMinX (float -> static int)
+    b4[1] = (int)std::max(m[1][0], m[3][0]);  // mnMaxX
+    b4[2] = (int)std::min(m[0][1], m[1][1]);  // mnMinY
+    b4[3] = (int)std::max(m[2][1], m[3][1]);  // mnMaxY
+  } else {
+    b4[0] = 0; b4[1] = cols; b4[2] = 0; b4[3] = rows;
+  }
+}
+
 // the std::sort call of cpp:912 in isolation: (count, UL.x, id) triples ordered with compareNodes (cpp:684-696)
 void orbo_std_sort_sized(int* triples, int n) {
   struct T3 { int c, u, id; };

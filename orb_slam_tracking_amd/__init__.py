@@ -46,6 +46,10 @@ class _Bounds(ctypes.Structure):
     _fields_ = [("min_x", ctypes.c_int32), ("max_x", ctypes.c_int32), ("min_y", ctypes.c_int32), ("max_y", ctypes.c_int32)]
 
 
+class _Camera(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2")]
+
+
 class _Stats(ctypes.Structure):
     _fields_ = [("invalid_by_distance", ctypes.c_int32), ("invalid_by_ratio", ctypes.c_int32),
                 ("invalid_by_orientation", ctypes.c_int32)]
@@ -89,6 +93,9 @@ def lib() -> ctypes.CDLL:
                                                vp, vp, vp]
     L.orbx_extract_match_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, sz, vp, vp, i32, vp, i32, vp, vp,
                                                   ctypes.POINTER(_Bounds), i32, f32, i32, vp, vp, vp]
+    L.orbx_undistort_keypoints.argtypes = [vp, vp, i32, ctypes.POINTER(_Camera), vp]
+    L.orbx_undistort_batch_device.argtypes = [vp, i32, vp, vp, i32, ctypes.POINTER(_Camera), vp]
+    L.orbx_image_bounds.argtypes = [vp, ctypes.POINTER(_Camera), i32, i32, ctypes.POINTER(_Bounds)]
     L.orbx_profile_enable.argtypes = [vp, i32]
     L.orbx_profile_reset.argtypes = [vp]
     L.orbx_profile_get.argtypes = [vp, vp, vp]
@@ -252,6 +259,30 @@ class ORBextractor:
                                                     _ptr(d_nmatches), _ptr(d_stats))
         self._check(r, "orbx_extract_match_batch_device")
 
+    # -- Frame::UndistortKeyPoints / ComputeImageBounds (SlamTypes/Frame.cpp:101-161) ----------------
+    def undistort_keypoints(self, kps: np.ndarray, camera: Sequence[float]) -> np.ndarray:
+        """mvKeysUn from mvKeys; camera = (fx, fy, cx, cy, k1, k2, p1, p2)."""
+        kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+        out = np.zeros(len(kps), KEYPOINT_DTYPE)
+        cam = _Camera(*[float(v) for v in camera])
+        self._check(self._L.orbx_undistort_keypoints(self._h, _ptr(kps), len(kps), ctypes.byref(cam), _ptr(out)),
+                    "orbx_undistort_keypoints")
+        return out
+
+    def undistort_batch_device(self, n_frames: int, d_kps, d_n, camera: Sequence[float], d_kps_un,
+                               capacity: Optional[int] = None) -> None:
+        cam = _Camera(*[float(v) for v in camera])
+        self._check(self._L.orbx_undistort_batch_device(self._h, int(n_frames), _ptr(d_kps), _ptr(d_n),
+                                                        int(capacity or self.capacity), ctypes.byref(cam), _ptr(d_kps_un)),
+                    "orbx_undistort_batch_device")
+
+    def image_bounds(self, camera: Sequence[float], width: int, height: int) -> Tuple[int, int, int, int]:
+        cam = _Camera(*[float(v) for v in camera])
+        b = _Bounds()
+        self._check(self._L.orbx_image_bounds(self._h, ctypes.byref(cam), int(width), int(height), ctypes.byref(b)),
+                    "orbx_image_bounds")
+        return (b.min_x, b.max_x, b.min_y, b.max_y)
+
     # -- mvImagePyramid (hpp:111) ----------------------------------------------------------------
     def level_size(self, level: int) -> Tuple[int, int]:
         w, h = ctypes.c_int(0), ctypes.c_int(0)
@@ -308,20 +339,34 @@ def debug_distribute(xyr: np.ndarray, min_x: int, max_x: int, min_y: int, max_y:
     return out[:r]
 
 
-class Frame:
-    """The slice of SlamTypes/Frame.{hpp,cpp} on this path: runs the extractor (Frame.cpp:58-60), keeps mvKeys /
-    mvKeysUn / mDescriptors / N and the image bounds (Frame.cpp:101-134; identity when there is no distortion).
-    Keypoint undistortion is SURVEY 8(f) rank 1 and not built yet: only distCoef[0] == 0 is accepted."""
+def camera_from(K, distCoef) -> Tuple[float, ...]:
+    """(fx, fy, cx, cy, k1, k2, p1, p2) from mK (3x3) and mDistCoef (4 entries), both float32 as in Settings.hpp:28-39."""
+    K = np.asarray(K, np.float32).reshape(3, 3)
+    d = np.asarray(distCoef, np.float32).reshape(-1)
+    if d.size != 4:
+        raise OrbxError(E_BADARG, "distCoef must hold k1 k2 p1 p2")
+    return (float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), float(d[0]), float(d[1]), float(d[2]), float(d[3]))
 
-    def __init__(self, im: np.ndarray, timestamp: float, extractor: ORBextractor, dist_k1: float = 0.0):
-        if dist_k1 != 0.0:
-            raise NotImplementedError("keypoint undistortion (SURVEY 8(f) rank 1) is not part of this round")
+
+class Frame:
+    """The slice of SlamTypes/Frame.{hpp,cpp} on this path: runs the extractor (Frame.cpp:58-60), undistorts the
+    keypoints (Frame.cpp:136-161) and keeps mvKeys / mvKeysUn / mDescriptors / N and the image bounds
+    (Frame.cpp:101-134).  K / distCoef = None means no distortion (mvKeysUn = mvKeys, bounds = the image)."""
+
+    def __init__(self, im: np.ndarray, timestamp: float, extractor: ORBextractor, K=None, distCoef=None):
         self.mTimestamp = timestamp
         self.mpORBextractor = extractor
         h, w = im.shape
-        self.bounds = (0, w, 0, h)  # mnMinX, mnMaxX, mnMinY, mnMaxY (Frame.cpp:127-131)
+        self.camera = camera_from(K, distCoef) if K is not None and distCoef is not None else None
+        if self.camera is not None:
+            self.bounds = extractor.image_bounds(self.camera, w, h)  # Frame.cpp:44
+        else:
+            self.bounds = (0, w, 0, h)  # mnMinX, mnMaxX, mnMinY, mnMaxY (Frame.cpp:127-131)
         _, self.mvKeys, self.mDescriptors = extractor(im, None, (0, 0))
-        self.mvKeysUn = self.mvKeys  # Frame.cpp:137-140
+        if self.camera is not None and len(self.mvKeys):
+            self.mvKeysUn = extractor.undistort_keypoints(self.mvKeys, self.camera)  # Frame.cpp:64
+        else:
+            self.mvKeysUn = self.mvKeys  # Frame.cpp:137-140
         self.N = len(self.mvKeysUn)
 
     @classmethod

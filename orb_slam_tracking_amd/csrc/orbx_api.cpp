@@ -36,6 +36,8 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
 hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage, const int* nselLevel, const OctLaunch& P,
                               SelKp* sel, int* nsel, int selCap, int* err);
 size_t octScratchBytes(int nMax, int qMax);
+hipError_t launch_undistort(hipStream_t st, int nFrames, const orbx_keypoint* in, const int* nkp, int capacity, const CamD& c,
+                            orbx_keypoint* out);
 
 namespace {
 
@@ -783,6 +785,31 @@ int ensureMatchScratch(orbx_ctx* ctx, int nPairs, int capacity) {
   }
   return ORBX_OK;
 }
+
+// device staging of the host-pointer entry points (orbx_match_init, orbx_undistort_keypoints): two keypoint /
+// descriptor arrays of `cap` entries and a small int area
+int ensureHostPairBuffers(orbx_ctx* ctx, size_t cap) {
+  if (cap <= ctx->mCap) return ORBX_OK;
+  if (ctx->dMk) (void)hipFree(ctx->dMk);
+  if (ctx->dMd) (void)hipFree(ctx->dMd);
+  if (ctx->dMi) (void)hipFree(ctx->dMi);
+  ctx->dMk = nullptr; ctx->dMd = nullptr; ctx->dMi = nullptr; ctx->mCap = 0;
+  HIPCHK(hipMalloc((void**)&ctx->dMk, 2 * cap * sizeof(orbx_keypoint)));
+  HIPCHK(hipMalloc((void**)&ctx->dMd, 2 * cap * 32));
+  HIPCHK(hipMalloc((void**)&ctx->dMi, (cap + 8) * sizeof(int)));
+  ctx->mCap = cap;
+  return ORBX_OK;
+}
+
+// mK / mDistCoef (CV_32F) -> the doubles cv::undistortPoints computes with
+CamD makeCam(const orbx_camera& c) {
+  CamD d{};
+  d.fx = c.fx; d.fy = c.fy; d.cx = c.cx; d.cy = c.cy;
+  d.ifx = 1. / d.fx; d.ify = 1. / d.fy;
+  d.k0 = c.k1; d.k1 = c.k2; d.k2 = c.p1; d.k3 = c.p2;
+  d.distorted = c.k1 != 0.0f;
+  return d;
+}
 }  // namespace
 
 extern "C" {
@@ -838,16 +865,8 @@ int orbx_match_init(orbx_ctx* ctx, const orbx_keypoint* k1, const uint8_t* d1, i
   if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
   const size_t cap = (size_t)std::max(std::max(n1, n2), 1);
   if (cap >= (1u << 20)) return ORBX_E_BADARG;
-  if (cap > ctx->mCap) {
-    if (ctx->dMk) (void)hipFree(ctx->dMk);
-    if (ctx->dMd) (void)hipFree(ctx->dMd);
-    if (ctx->dMi) (void)hipFree(ctx->dMi);
-    ctx->dMk = nullptr; ctx->dMd = nullptr; ctx->dMi = nullptr; ctx->mCap = 0;
-    HIPCHK(hipMalloc((void**)&ctx->dMk, 2 * cap * sizeof(orbx_keypoint)));
-    HIPCHK(hipMalloc((void**)&ctx->dMd, 2 * cap * 32));
-    HIPCHK(hipMalloc((void**)&ctx->dMi, (cap + 8) * sizeof(int)));
-    ctx->mCap = cap;
-  }
+  int er = ensureHostPairBuffers(ctx, cap);
+  if (er != ORBX_OK) return er;
   const size_t c = ctx->mCap;
   hipStream_t st = ctx->st;
   if (n1) {
@@ -874,6 +893,52 @@ int orbx_match_init(orbx_ctx* ctx, const orbx_keypoint* k1, const uint8_t* d1, i
   HIPCHK(hipStreamSynchronize(st));
   if (stats) { stats->invalid_by_distance = res[1]; stats->invalid_by_ratio = res[2]; stats->invalid_by_orientation = res[3]; }
   *nmatches = res[0];
+  return ORBX_OK;
+}
+
+// ---- Frame::UndistortKeyPoints / ComputeImageBounds (SlamTypes/Frame.cpp:101-161) ----------------
+int orbx_undistort_batch_device(orbx_ctx* ctx, int n_frames, const orbx_keypoint* d_kps, const int32_t* d_n, int capacity,
+                                const orbx_camera* cam, orbx_keypoint* d_kps_un) {
+  if (!ctx || n_frames < 0 || !d_kps || !d_n || !cam || !d_kps_un || capacity < 1) return ORBX_E_BADARG;
+  if (n_frames == 0) return ORBX_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  HIPCHK(launch_undistort(ctx->st, n_frames, d_kps, d_n, capacity, makeCam(*cam), d_kps_un));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  return ORBX_OK;
+}
+
+int orbx_undistort_keypoints(orbx_ctx* ctx, const orbx_keypoint* kps, int n, const orbx_camera* cam, orbx_keypoint* out) {
+  if (!ctx || n < 0 || !cam || (n > 0 && (!kps || !out))) return ORBX_E_BADARG;
+  if (n == 0) return ORBX_OK;
+  if (n >= (1 << 20)) return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  int er = ensureHostPairBuffers(ctx, (size_t)n);
+  if (er != ORBX_OK) return er;
+  const size_t c = ctx->mCap;
+  hipStream_t st = ctx->st;
+  HIPCHK(hipMemcpyAsync(ctx->dMk, kps, sizeof(orbx_keypoint) * n, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->dMi, &n, sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(launch_undistort(st, 1, ctx->dMk, ctx->dMi, (int)c, makeCam(*cam), ctx->dMk + c));
+  HIPCHK(hipMemcpyAsync(out, ctx->dMk + c, sizeof(orbx_keypoint) * n, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return ORBX_OK;
+}
+
+int orbx_image_bounds(orbx_ctx* ctx, const orbx_camera* cam, int width, int height, orbx_bounds* out) {
+  if (!ctx || !cam || !out || width <= 0 || height <= 0) return ORBX_E_BADARG;
+  if (cam->k1 == 0.0f) {  // Frame.cpp:127-133
+    out->min_x = 0; out->max_x = width; out->min_y = 0; out->max_y = height;
+    return ORBX_OK;
+  }
+  // Frame.cpp:105-113: corners (0,0) (cols,0) (0,rows) (cols,rows) through the same undistortion kernel
+  orbx_keypoint c4[4]{}, u4[4]{};
+  c4[1].x = (float)width; c4[2].y = (float)height; c4[3].x = (float)width; c4[3].y = (float)height;
+  int r = orbx_undistort_keypoints(ctx, c4, 4, cam, u4);
+  if (r != ORBX_OK) return r;
+  out->min_x = (int)std::min(u4[0].x, u4[2].x);  // Frame.cpp:121-124, float -> static int
+  out->max_x = (int)std::max(u4[1].x, u4[3].x);
+  out->min_y = (int)std::min(u4[0].y, u4[1].y);
+  out->max_y = (int)std::max(u4[2].y, u4[3].y);
   return ORBX_OK;
 }
 

@@ -81,4 +81,11 @@ struct ResizeTab {
   int32_t coef;   // c0 | c1 << 16 (Q11)
 };
 
+// camera of cv::undistortPoints in the doubles OpenCV converts mK / mDistCoef (CV_32F, Settings.hpp:32,39) to
+struct CamD {
+  double fx, fy, cx, cy, ifx, ify;  // ifx = 1./fx, ify = 1./fy
+  double k0, k1, k2, k3;            // k1 k2 p1 p2 of the reference = OpenCV's k[0..3]
+  int32_t distorted, pad_;          // mDistCoef.at<float>(0) != 0 (Frame.cpp:103,138)
+};
+
 }  // namespace orbx

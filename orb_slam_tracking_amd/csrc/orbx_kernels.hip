@@ -1105,8 +1105,59 @@ __global__ __launch_bounds__(MATCH_T) void k_match(const int* __restrict__ pairF
 }
 
 // =================================================================================================
+// Keypoint undistortion: Frame::UndistortKeyPoints (SlamTypes/Frame.cpp:136-161) = cv::undistortPoints with R = I, P = K
+// (SURVEY appendix A8).  One thread per keypoint, f64 arithmetic in OpenCV's operation order (the build has
+// -ffp-contract=off, so no fused multiply-adds), 5 fixed iterations, result stored as f32.  Every other field of the
+// keypoint is copied (Frame.cpp:155-160: `kp = mvKeys[i]; kp.pt = ...`).
+// =================================================================================================
+__device__ __forceinline__ void undistortPoint(const CamD& c, float xin, float yin, float* xo, float* yo) {
+  double x = xin, y = yin;
+  const double u = x, v = y;
+  x = (x - c.cx) * c.ifx;
+  y = (y - c.cy) * c.ify;
+  const double x0 = x, y0 = y;
+#pragma unroll 1
+  for (int j = 0; j < 5; j++) {
+    const double r2 = x * x + y * y;
+    // numerator 1 + ((k[7]*r2 + k[6])*r2 + k[5])*r2 with k[5..7] = 0; denominator with k[4] = 0
+    const double icdist = (1 + ((0. * r2 + 0.) * r2 + 0.) * r2) / (1 + ((0. * r2 + c.k1) * r2 + c.k0) * r2);
+    if (icdist < 0) {
+      x = (u - c.cx) * c.ifx;
+      y = (v - c.cy) * c.ify;
+      break;
+    }
+    const double deltaX = 2 * c.k2 * x * y + c.k3 * (r2 + 2 * x * x) + 0. * r2 + 0. * r2 * r2;
+    const double deltaY = c.k2 * (r2 + 2 * y * y) + 2 * c.k3 * x * y + 0. * r2 + 0. * r2 * r2;
+    x = (x0 - deltaX) * icdist;
+    y = (y0 - deltaY) * icdist;
+  }
+  const double xx = c.fx * x + 0. * y + c.cx, yy = 0. * x + c.fy * y + c.cy, ww = 1. / (0. * x + 0. * y + 1.);
+  *xo = (float)(xx * ww);
+  *yo = (float)(yy * ww);
+}
+
+__global__ __launch_bounds__(256) void k_undistort(const orbx_keypoint* __restrict__ in, const int* __restrict__ nkp, int capacity,
+                                                   CamD c, orbx_keypoint* __restrict__ out) {
+  const int f = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = min(nkp[f], capacity);
+  if (i >= n) return;
+  orbx_keypoint kp = in[(size_t)f * capacity + i];
+  if (c.distorted) undistortPoint(c, kp.x, kp.y, &kp.x, &kp.y);
+  out[(size_t)f * capacity + i] = kp;
+}
+
+// =================================================================================================
 // launch wrappers (called from orbx_api.cpp)
 // =================================================================================================
+hipError_t launch_undistort(hipStream_t st, int nFrames, const orbx_keypoint* in, const int* nkp, int capacity, const CamD& c,
+                            orbx_keypoint* out) {
+  if (nFrames <= 0 || capacity <= 0) return hipSuccess;
+  dim3 block(256, 1, 1), grid((capacity + 255) / 256, nFrames, 1);
+  hipLaunchKernelGGL(k_undistort, grid, block, 0, st, in, nkp, capacity, c, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_resize(hipStream_t st, int nFrames, const uint8_t* src, long long srcFrameStride, int sw, int sh, int sstride,
                          uint8_t* dst, long long dstFrameStride, int dw, int dh, int dstride, const ResizeTab* xtab,
                          const ResizeTab* ytab, int dwordPath) {

@@ -1,6 +1,7 @@
 // shim_demo.cpp — the reference's demo_initialization.cpp:65-113 call sequence, written against include/orbx_shim.hpp
 // (POD types, no OpenCV):  extractor(2 frames) -> Frame-equivalent views -> ORBmatcher::SearchForInitialization.
-// usage: shim_demo W H frameA.raw frameB.raw nfeatures iniTh minTh
+// usage: shim_demo W H frameA.raw frameB.raw nfeatures iniTh minTh [distort]
+//   distort = 1: the Frame constructor's undistortion + image bounds with the camera of Settings.yaml (Frame.cpp:44,64)
 // prints: N1 N2 nmatches fnv1a(keypoints1) fnv1a(desc1) fnv1a(matches12)
 #include <cstdio>
 #include <cstdlib>
@@ -35,7 +36,15 @@ int main(int argc, char** argv) {
     const int r1 = extractor(imA, noMask, k1, d1, unused);
     const int r2 = extractor(imB, noMask, k2, d2, unused);
     if (r1 != (int)k1.size() || r2 != (int)k2.size()) return 3;  // monoIndex == N for a {0,0} lapping area
-    FrameView f1{k1.data(), d1.data(), (int)k1.size(), 0, W, 0, H}, f2{k2.data(), d2.data(), (int)k2.size(), 0, W, 0, H};
+    int minX = 0, maxX = W, minY = 0, maxY = H;
+    std::vector<orbx::KeyPoint> u1 = k1, u2 = k2;  // mvKeysUn
+    if (argc > 8 && std::atoi(argv[8]) == 1) {
+      const orbx_camera cam{609.2855f, 609.3422f, 351.4274f, 237.7324f, -0.3492f, 0.1363f, 0.0f, 0.0f};
+      extractor.ComputeImageBounds(cam, W, H, minX, maxX, minY, maxY);  // Frame.cpp:44
+      extractor.UndistortKeyPoints(k1, cam, u1);                         // Frame.cpp:64
+      extractor.UndistortKeyPoints(k2, cam, u2);
+    }
+    FrameView f1{u1.data(), d1.data(), (int)u1.size(), minX, maxX, minY, maxY}, f2{u2.data(), d2.data(), (int)u2.size(), minX, maxX, minY, maxY};
     ORBmatcher orbMatcher(0.9f, true, &extractor);  // demo :105
     std::vector<int> mvMatches;
     const int nmatches = orbMatcher.SearchForInitialization(f1, f2, mvMatches, 100);  // demo :108

@@ -256,3 +256,31 @@ def std_sort_sized(triples: np.ndarray) -> np.ndarray:
     L.orbo_std_sort_sized.restype = None
     L.orbo_std_sort_sized(_p(t), len(t))
     return t
+
+
+SETTINGS_CAMERA = (609.2855, 609.3422, 351.4274, 237.7324, -0.3492, 0.1363, 0.0, 0.0)  # reference Settings.yaml
+
+
+def _cam(camera) -> np.ndarray:
+    return np.ascontiguousarray(camera, np.float32).reshape(8)
+
+
+def undistort_keypoints(kps: np.ndarray, camera) -> np.ndarray:
+    """Oracle of Frame::UndistortKeyPoints (Frame.cpp:136-161); camera = (fx, fy, cx, cy, k1, k2, p1, p2)."""
+    kps = np.ascontiguousarray(kps, KP)
+    out = np.zeros(len(kps), KP)
+    L = lib()
+    L.orbo_undistort_keypoints.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.orbo_undistort_keypoints.restype = None
+    L.orbo_undistort_keypoints(_p(kps), len(kps), _p(_cam(camera)), _p(out))
+    return out
+
+
+def image_bounds(camera, cols: int, rows: int):
+    """Oracle of Frame::ComputeImageBounds (Frame.cpp:101-134) -> (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    b = np.zeros(4, np.int32)
+    L = lib()
+    L.orbo_image_bounds.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.orbo_image_bounds.restype = None
+    L.orbo_image_bounds(_p(_cam(camera)), cols, rows, _p(b))
+    return tuple(int(v) for v in b)

@@ -402,3 +402,72 @@ def test_cpp_shim_equals_oracle(orbx, oracle, tmp_path):
         return h
     assert [int(v) for v in res[:3]] == [len(ka), len(kb), nm]
     assert int(res[3]) == fnv(ka.tobytes()) and int(res[4]) == fnv(da.tobytes()) and int(res[5]) == fnv(m12.astype(np.int32).tobytes())
+    # the same with the Frame constructor's undistortion and image bounds (Settings.yaml camera)
+    p = subprocess.run([exe, "640", "480", str(fa), str(fb), "1000", "20", "7", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout
+    res = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][0].split()[1:]
+    cam = oracle.SETTINGS_CAMERA
+    nm, m12, _ = oracle.match_init(oracle.undistort_keypoints(ka, cam), da, oracle.undistort_keypoints(kb, cam), db,
+                                   oracle.image_bounds(cam, 640, 480), 100, 0.9, True)
+    assert [int(v) for v in res[:3]] == [len(ka), len(kb), nm] and int(res[5]) == fnv(m12.astype(np.int32).tobytes())
+
+
+def test_undistort_and_bounds(orbx, ext640, oracle, images, golden):
+    """SURVEY 8(f) rank 1: Frame::UndistortKeyPoints / ComputeImageBounds (Frame.cpp:101-161) on the device, bit-exact
+    against the oracle, with the camera of the reference's Settings.yaml and with tangential terms."""
+    rng = np.random.default_rng(5)
+    pts = np.zeros(5000, orbx.KEYPOINT_DTYPE)
+    pts["x"] = rng.uniform(-50, 700, len(pts)).astype(np.float32)
+    pts["y"] = rng.uniform(-50, 530, len(pts)).astype(np.float32)
+    pts["octave"] = rng.integers(0, 8, len(pts))
+    pts["angle"] = rng.uniform(0, 360, len(pts)).astype(np.float32)
+    k = golden["as_shipped/init0/kps"]
+    cams = [oracle.SETTINGS_CAMERA, oracle.SETTINGS_CAMERA[:6] + (0.0011, -0.0007), (500.0, 510.0, 320.0, 240.0, 0.21, -0.4, 0.0, 0.0),
+            oracle.SETTINGS_CAMERA[:4] + (0.0, 0.3, 0.01, 0.01),      # k1 == 0: copy, whatever the other coefficients
+            (100.0, 100.0, 320.0, 240.0, -0.9, 0.0, 0.0, 0.0)]        # strong: icdist < 0 branch for far points
+    for cam in cams:
+        for src in (k, pts, pts[:1], pts[:0]):
+            assert ext640.undistort_keypoints(src, cam).tobytes() == oracle.undistort_keypoints(src, cam).tobytes()
+        for (w, h) in ((640, 480), (1920, 1080), (752, 480)):
+            assert ext640.image_bounds(cam, w, h) == oracle.image_bounds(cam, w, h)
+
+
+def test_frames_with_distortion_match(orbx, oracle, images):
+    """Config C1 as the demo runs it: Frame(im, K, distCoef) -> mvKeysUn + undistorted bounds -> SearchForInitialization
+    (grid over the undistorted bounds, Frame.cpp:44-46, 70-99), host API and device-resident API."""
+    import torch
+    cam = oracle.SETTINGS_CAMERA
+    K = np.array([[cam[0], 0, cam[2]], [0, cam[1], cam[3]], [0, 0, 1]], np.float32)
+    dist = np.array(cam[4:], np.float32)
+    a, b = images["init0"], images["init1"]
+    h, w = a.shape
+    e = orbx.ORBextractor(*SHIPPED, max_width=w, max_height=h, max_batch=2)
+    oe = oracle.Extractor(*SHIPPED)
+    fa, fb = orbx.Frame(a, 0.0, e, K, dist), orbx.Frame(b, 1.0, e, K, dist)
+    oa, ob = oe(a), oe(b)
+    ua, ub = oracle.undistort_keypoints(oa[1], cam), oracle.undistort_keypoints(ob[1], cam)
+    ob_bounds = oracle.image_bounds(cam, w, h)
+    assert fa.bounds == ob_bounds and fb.bounds == ob_bounds
+    assert fa.mvKeysUn.tobytes() == ua.tobytes() and fb.mvKeysUn.tobytes() == ub.tobytes()
+    assert fa.mvKeys.tobytes() == oa[1].tobytes()
+    m = orbx.ORBmatcher(0.9, True)
+    nm, m12 = m.SearchForInitialization(fa, fb, 100)
+    onm, om12, ost = oracle.match_init(ua, oa[2], ub, ob[2], ob_bounds, 100, 0.9, True)
+    assert nm == onm and np.array_equal(m12, om12) and list(m.last_stats) == ost.tolist()
+    assert nm >= 100  # demo_initialization.cpp:110
+    # device-resident chain: extract -> undistort (in place) -> match
+    cap = 2000
+    d_img = torch.from_numpy(np.stack([a, b])).cuda()
+    d_k = torch.zeros(2 * cap * 28, dtype=torch.uint8, device="cuda")
+    d_d = torch.zeros(2 * cap * 32, dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(2, dtype=torch.int32, device="cuda")
+    e.extract_batch_device(d_img, 2, w, h, w, w * h, d_k, d_d, d_n, cap)
+    e.undistort_batch_device(2, d_k, d_n, cam, d_k, cap)
+    kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(2, cap)
+    assert kk[0, :len(ua)].tobytes() == ua.tobytes() and kk[1, :len(ub)].tobytes() == ub.tobytes()
+    d_m = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    d_nm = torch.zeros(1, dtype=torch.int32, device="cuda")
+    e.match_pairs_device(np.array([0]), np.array([1]), d_k, d_d, d_n, ob_bounds, d_m, d_nm, None, 100, 0.9, True, cap)
+    assert int(d_nm.item()) == onm and np.array_equal(d_m.cpu().numpy()[:len(om12)], om12)
+    e.close()

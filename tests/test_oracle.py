@@ -182,3 +182,62 @@ def test_matcher_quirks(oracle):
     k1["octave"] = [0, 1, 0]
     nm, m12, st = oracle.match_init(k1, d1, k2, d2, (0, 640, 0, 480), 100, 0.9, False)
     assert m12.tolist() == [-1, -1, 0] and nm == 1  # q2 (dist 2) steals from q0 (dist 3)
+
+
+def _undistort_np(cam, x, y):
+    """Second, independent restatement of cv::undistortPoints(R = I, P = K) in numpy f64 (SURVEY appendix A8): the same
+    operation order without OpenCV's zero-coefficient terms (adding/multiplying exact zeros does not change a result)."""
+    fx, fy, cx, cy, k1, k2, p1, p2 = [np.float64(np.float32(v)) for v in cam]
+    ifx, ify = np.float64(1.0) / fx, np.float64(1.0) / fy
+    x = (np.float64(np.float32(x)) - cx) * ifx
+    y = (np.float64(np.float32(y)) - cy) * ify
+    x0, y0 = x, y
+    for _ in range(5):
+        r2 = x * x + y * y
+        icdist = np.float64(1.0) / (np.float64(1.0) + (k2 * r2 + k1) * r2)
+        dx = np.float64(2.0) * p1 * x * y + p2 * (r2 + np.float64(2.0) * x * x)
+        dy = p1 * (r2 + np.float64(2.0) * y * y) + np.float64(2.0) * p2 * x * y
+        x = (x0 - dx) * icdist
+        y = (y0 - dy) * icdist
+    return np.float32(fx * x + cx), np.float32(fy * y + cy)
+
+
+def test_undistort_keypoints_and_bounds(oracle, golden):
+    """SURVEY 8(f) rank 1: Frame::UndistortKeyPoints / ComputeImageBounds (Frame.cpp:101-161) with the camera of the
+    reference's Settings.yaml."""
+    cam = oracle.SETTINGS_CAMERA
+    k = golden["as_shipped/init0/kps"]
+    u = oracle.undistort_keypoints(k, cam)
+    for f in ("size", "angle", "response", "octave", "class_id"):
+        assert np.array_equal(u[f], k[f])  # Frame.cpp:156-159: only pt changes
+    for i in range(0, len(k), 7):
+        ex, ey = _undistort_np(cam, k["x"][i], k["y"][i])
+        assert u["x"][i] == ex and u["y"][i] == ey
+    # forward model check: distorting the result again lands near the measured pixel (5 fixed-point iterations leave
+    # up to ~0.1 px at the image edge with this k1)
+    fx, fy, cx, cy, k1, k2, _, _ = cam
+    xn, yn = (u["x"].astype(np.float64) - cx) / fx, (u["y"].astype(np.float64) - cy) / fy
+    r2 = xn * xn + yn * yn
+    cd = 1 + k1 * r2 + k2 * r2 * r2
+    assert np.abs(xn * cd * fx + cx - k["x"]).max() < 0.25 and np.abs(yn * cd * fy + cy - k["y"]).max() < 0.25
+    # the principal point is a fixed point; no distortion = copy (Frame.cpp:137-140)
+    pp = np.zeros(1, oracle.KP)
+    pp["x"], pp["y"] = np.float32(cam[2]), np.float32(cam[3])
+    o = oracle.undistort_keypoints(pp, cam)
+    assert o["x"][0] == pp["x"][0] and o["y"][0] == pp["y"][0]
+    nod = cam[:4] + (0.0, 0.1, 0.0, 0.0)
+    assert oracle.undistort_keypoints(k, nod).tobytes() == k.tobytes()
+    # image bounds: barrel distortion pushes the corners outwards; ints truncated from floats (Frame.cpp:123-126)
+    b = oracle.image_bounds(cam, 640, 480)
+    corners = [(0, 0), (640, 0), (0, 480), (640, 480)]
+    un = [_undistort_np(cam, *c) for c in corners]
+    assert b == (int(min(un[0][0], un[2][0])), int(max(un[1][0], un[3][0])), int(min(un[0][1], un[1][1])),
+                 int(max(un[2][1], un[3][1])))
+    assert b[0] < 0 and b[2] < 0 and b[1] > 640 and b[3] > 480
+    assert oracle.image_bounds(nod, 640, 480) == (0, 640, 0, 480)
+    # tangential terms exercised too (p1, p2 != 0)
+    camt = cam[:6] + (0.0011, -0.0007)
+    ut = oracle.undistort_keypoints(k[:50], camt)
+    for i in range(50):
+        ex, ey = _undistort_np(camt, k["x"][i], k["y"][i])
+        assert ut["x"][i] == ex and ut["y"][i] == ey
