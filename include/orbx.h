@@ -160,6 +160,18 @@ int orbx_undistort_batch_device(orbx_ctx* ctx, int n_frames, const orbx_keypoint
  * to the reference's static ints; k1 == 0 gives (0, width, 0, height). */
 int orbx_image_bounds(orbx_ctx* ctx, const orbx_camera* cam, int width, int height, orbx_bounds* out);
 
+/* ---- in front of the extractor: Converter::toGray (Utils/Converter.cpp:5-19) -------- */
+/* channels == 1 copies, channels == 3 is cv::cvtColor(COLOR_RGB2GRAY if rgb else COLOR_BGR2GRAY) on 8-bit pixels,
+ * Y = (R*4899 + G*9617 + B*1868 + 8192) >> 14; any other channel count returns ORBX_E_BADARG ("Wrong image format",
+ * the reference's `return false`).  Strides in bytes.  Host buffers: */
+int orbx_to_gray(orbx_ctx* ctx, const uint8_t* img, int width, int height, int stride, int channels, int rgb, uint8_t* gray,
+                 int gray_stride);
+/* device-resident batch: frame f at d_src + f*frame_stride_bytes -> d_gray + f*gray_frame_stride_bytes, ready to be
+ * handed to orbx_extract_batch_device / orbx_extract_match_batch_device. */
+int orbx_to_gray_batch_device(orbx_ctx* ctx, int n_frames, const uint8_t* d_src, int width, int height, int stride,
+                              size_t frame_stride_bytes, int channels, int rgb, uint8_t* d_gray, int gray_stride,
+                              size_t gray_frame_stride_bytes);
+
 /* ---- measurement hooks (bench.py; HIP events on the ctx stream) ---------------------------- */
 #define ORBX_STAGE_PYRAMID 0
 #define ORBX_STAGE_FAST 1

@@ -161,6 +161,19 @@ class ORBextractor {
   //   void Frame::UndistortKeyPoints() { mpORBextractor->UndistortKeyPoints(mvKeys, cam, mvKeysUn); N = mvKeysUn.size(); }
   //   void Frame::ComputeImageBounds() { mpORBextractor->ComputeImageBounds(cam, im.cols, im.rows, mnMinX, mnMaxX, mnMinY, mnMaxY); }
   // with cam = {mK(0,0), mK(1,1), mK(0,2), mK(1,2), mDistCoef(0..3)} (all CV_32F, Settings.hpp:28-39).
+  // Drop-in for the body of Converter::toGray (Utils/Converter.cpp:5-19): `in` has `channels` interleaved bytes per pixel
+  // (stride in bytes); out becomes width x height, tightly packed.  false = "Wrong image format", like upstream.
+  bool toGray(const orbx::Image8& in, int channels, std::vector<uint8_t>& outImGray, bool bRGB = false) {
+    outImGray.assign(in.empty() ? 0 : (size_t)in.cols * in.rows, 0);
+    const int r = orbx_to_gray(ctx_, in.data, in.cols, in.rows, in.step, channels, bRGB ? 1 : 0, outImGray.data(), in.cols);
+    if (r == ORBX_E_BADARG && channels != 1 && channels != 3) {
+      std::cerr << "ERROR: Wrong image format" << std::endl;  // Converter.cpp:17
+      return false;
+    }
+    if (r != ORBX_OK) throw orbx::Error(r, orbx_last_error(ctx_));
+    return true;
+  }
+
   void UndistortKeyPoints(const std::vector<KeyPointT>& mvKeys, const orbx_camera& cam, std::vector<KeyPointT>& mvKeysUn) {
     mvKeysUn.resize(mvKeys.size());
     const int r = orbx_undistort_keypoints(ctx_, reinterpret_cast<const orbx_keypoint*>(mvKeys.data()), (int)mvKeys.size(), &cam,

@@ -851,6 +851,25 @@ void orbo_image_bounds(const float* cam8, int cols, int rows, int32_t* b4) {  //
   }
 }
 
+// Converter::toGray (Utils/Converter.cpp:5-19; demo_initialization.cpp:67-68) = copy for one channel,
+// cv::cvtColor(COLOR_RGB2GRAY / COLOR_BGR2GRAY) for three, false otherwise.  8-bit cvtColor restated with the 14-bit
+// coefficients of OpenCV 3.x / early 4.x (Y = (R*4899 + G*9617 + B*1868 + 8192) >> 14; newer 4.x
+// releases use 15-bit coefficients -- unpinned, like the rest of the OpenCV arithmetic).  Returns 1 / 0 like the bool.
+int orbo_to_gray(const uint8_t* src, int w, int h, int stride, int channels, int rgb, uint8_t* dst, int dstride) {
+  if (channels == 1) {
+    for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * dstride, src + (size_t)y * stride, (size_t)w);
+    return 1;
+  }
+  if (channels != 3) return 0;
+  const int c0 = rgb ? 4899 : 1868, c1 = 9617, c2 = rgb ? 1868 : 4899;
+  for (int y = 0; y < h; y++) {
+    const uint8_t* s = src + (size_t)y * stride;
+    uint8_t* d = dst + (size_t)y * dstride;
+    for (int x = 0; x < w; x++) d[x] = (uint8_t)((s[3 * x] * c0 + s[3 * x + 1] * c1 + s[3 * x + 2] * c2 + (1 << 13)) >> 14);
+  }
+  return 1;
+}
+
 // the std::sort call of cpp:912 in isolation: (count, UL.x, id) triples ordered with compareNodes (cpp:684-696)
 void orbo_std_sort_sized(int* triples, int n) {
   struct T3 { int c, u, id; };

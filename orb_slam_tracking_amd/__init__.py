@@ -96,6 +96,8 @@ def lib() -> ctypes.CDLL:
     L.orbx_undistort_keypoints.argtypes = [vp, vp, i32, ctypes.POINTER(_Camera), vp]
     L.orbx_undistort_batch_device.argtypes = [vp, i32, vp, vp, i32, ctypes.POINTER(_Camera), vp]
     L.orbx_image_bounds.argtypes = [vp, ctypes.POINTER(_Camera), i32, i32, ctypes.POINTER(_Bounds)]
+    L.orbx_to_gray.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, i32]
+    L.orbx_to_gray_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, sz, i32, i32, vp, i32, sz]
     L.orbx_profile_enable.argtypes = [vp, i32]
     L.orbx_profile_reset.argtypes = [vp]
     L.orbx_profile_get.argtypes = [vp, vp, vp]
@@ -258,6 +260,27 @@ class ORBextractor:
                                                     int(windowSize), float(nnratio), int(bool(checkOri)), _ptr(d_matches12),
                                                     _ptr(d_nmatches), _ptr(d_stats))
         self._check(r, "orbx_extract_match_batch_device")
+
+    # -- Converter::toGray (Utils/Converter.cpp:5-19) --------------------------------------------------
+    def to_gray(self, image: np.ndarray, bRGB: bool = False) -> np.ndarray:
+        """(h, w) or (h, w, 1) copies; (h, w, 3) is cvtColor(RGB2GRAY if bRGB else BGR2GRAY); else OrbxError (returns false upstream)."""
+        im = np.asarray(image)
+        if im.dtype != np.uint8 or im.ndim not in (2, 3):
+            raise OrbxError(E_BADARG, "image must be uint8 (h, w) or (h, w, c)")
+        ch = 1 if im.ndim == 2 else im.shape[2]
+        h, w = im.shape[:2]
+        if im.strides[-1] != 1 or (im.ndim == 3 and im.strides[1] != ch):
+            im = np.ascontiguousarray(im)
+        out = np.zeros((h, w), np.uint8)
+        self._check(self._L.orbx_to_gray(self._h, _ptr(im), w, h, im.strides[0] if h else w * ch, ch, int(bool(bRGB)), _ptr(out),
+                                         w), "orbx_to_gray")
+        return out
+
+    def to_gray_batch_device(self, d_src, n_frames: int, width: int, height: int, stride: int, frame_stride: int, channels: int,
+                             bRGB: bool, d_gray, gray_stride: int, gray_frame_stride: int) -> None:
+        self._check(self._L.orbx_to_gray_batch_device(self._h, int(n_frames), _ptr(d_src), int(width), int(height), int(stride),
+                                                      int(frame_stride), int(channels), int(bool(bRGB)), _ptr(d_gray),
+                                                      int(gray_stride), int(gray_frame_stride)), "orbx_to_gray_batch_device")
 
     # -- Frame::UndistortKeyPoints / ComputeImageBounds (SlamTypes/Frame.cpp:101-161) ----------------
     def undistort_keypoints(self, kps: np.ndarray, camera: Sequence[float]) -> np.ndarray:

@@ -36,6 +36,8 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
 hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage, const int* nselLevel, const OctLaunch& P,
                               SelKp* sel, int* nsel, int selCap, int* err);
 size_t octScratchBytes(int nMax, int qMax);
+hipError_t launch_to_gray(hipStream_t st, int nFrames, const uint8_t* src, long long srcFrameStride, int sstride, int w, int h,
+                          int channels, int rgb, uint8_t* dst, long long dstFrameStride, int dstride);
 hipError_t launch_undistort(hipStream_t st, int nFrames, const orbx_keypoint* in, const int* nkp, int capacity, const CamD& c,
                             orbx_keypoint* out);
 
@@ -100,6 +102,8 @@ struct orbx_ctx {
   uint8_t* dMd = nullptr;
   int* dMi = nullptr;  // n[2] + matches12[cap] + nmatches + stats[3]
   size_t mCap = 0;
+  uint8_t* dColor = nullptr;  // staging of orbx_to_gray (host API): colour frame followed by its gray image
+  size_t colorBytes = 0;
 
   // last extract call (for orbx_download_pyramid / debug hooks)
   const uint8_t* lastImg0 = nullptr;
@@ -615,7 +619,7 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (ctx->st) (void)hipStreamSynchronize(ctx->st);
   void* dev[] = {ctx->dPyr, ctx->dCand, ctx->dCandCount, ctx->dTab, ctx->dSel, ctx->dNsel, ctx->dSelStage, ctx->dNselLevel,
                  ctx->dOctScratch, ctx->dIn, ctx->dKps, ctx->dDesc, ctx->dMatchScratch, ctx->dPairs, ctx->dMk, ctx->dMd,
-                 ctx->dMi};
+                 ctx->dMi, ctx->dColor};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   void* host[] = {ctx->hNsel, ctx->hFlags};
@@ -939,6 +943,47 @@ int orbx_image_bounds(orbx_ctx* ctx, const orbx_camera* cam, int width, int heig
   out->max_x = (int)std::max(u4[1].x, u4[3].x);
   out->min_y = (int)std::min(u4[0].y, u4[1].y);
   out->max_y = (int)std::max(u4[2].y, u4[3].y);
+  return ORBX_OK;
+}
+
+// ---- Converter::toGray (Utils/Converter.cpp:5-19) ------------------------------------------------
+int orbx_to_gray_batch_device(orbx_ctx* ctx, int n_frames, const uint8_t* d_src, int width, int height, int stride,
+                              size_t frame_stride_bytes, int channels, int rgb, uint8_t* d_gray, int gray_stride,
+                              size_t gray_frame_stride_bytes) {
+  if (!ctx) return ORBX_E_BADARG;
+  if (!d_src || width <= 0 || height <= 0) return ORBX_E_EMPTY;
+  if (channels != 1 && channels != 3) { ctx->err = "Wrong image format"; return ORBX_E_BADARG; }  // Converter.cpp:17
+  if (!d_gray || n_frames < 0 || n_frames > 65535 || height > 65535 || (long long)stride < (long long)width * channels ||
+      gray_stride < width)
+    return ORBX_E_BADARG;
+  if (n_frames == 0) return ORBX_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  HIPCHK(launch_to_gray(ctx->st, n_frames, d_src, (long long)frame_stride_bytes, stride, width, height, channels, rgb, d_gray,
+                        (long long)gray_frame_stride_bytes, gray_stride));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  return ORBX_OK;
+}
+
+int orbx_to_gray(orbx_ctx* ctx, const uint8_t* img, int width, int height, int stride, int channels, int rgb, uint8_t* gray,
+                 int gray_stride) {
+  if (!ctx) return ORBX_E_BADARG;
+  if (!img || width <= 0 || height <= 0) return ORBX_E_EMPTY;
+  if (channels != 1 && channels != 3) { ctx->err = "Wrong image format"; return ORBX_E_BADARG; }
+  if (!gray || height > 65535 || (long long)stride < (long long)width * channels || gray_stride < width) return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  const int sstride = alignUp(width * channels, 64), gstride = alignUp(width, 64);
+  const size_t need = ((size_t)sstride + gstride) * height;
+  if (need > ctx->colorBytes) {
+    if (ctx->dColor) (void)hipFree(ctx->dColor);
+    ctx->dColor = nullptr; ctx->colorBytes = 0;
+    HIPCHK(hipMalloc((void**)&ctx->dColor, need));
+    ctx->colorBytes = need;
+  }
+  uint8_t* dG = ctx->dColor + (size_t)sstride * height;
+  HIPCHK(hipMemcpy2DAsync(ctx->dColor, sstride, img, stride, (size_t)width * channels, height, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(launch_to_gray(ctx->st, 1, ctx->dColor, 0, sstride, width, height, channels, rgb, dG, 0, gstride));
+  HIPCHK(hipMemcpy2DAsync(gray, gray_stride, dG, gstride, width, height, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
   return ORBX_OK;
 }
 

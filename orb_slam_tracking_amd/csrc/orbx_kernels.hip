@@ -1148,8 +1148,66 @@ __global__ __launch_bounds__(256) void k_undistort(const orbx_keypoint* __restri
 }
 
 // =================================================================================================
+// Colour -> gray: Converter::toGray (Utils/Converter.cpp:5-19) = cv::cvtColor(COLOR_RGB2GRAY / COLOR_BGR2GRAY) on 8-bit,
+// Y = (c0*ch0 + c1*ch1 + c2*ch2 + 8192) >> 14 with (c0, c1, c2) = (4899, 9617, 1868) for RGB order and reversed for BGR.
+// Thread = 4 output pixels: 12 source bytes as 3 aligned dwords -> one dword store (byte paths when unaligned / at the
+// row tail).  HBM streaming: 3 B read + 1 B written per pixel.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_to_gray(const uint8_t* __restrict__ src, long long srcFrameStride, int sstride, int w,
+                                                 int h, int c0, int c1, int c2, int srcAligned, uint8_t* __restrict__ dst,
+                                                 long long dstFrameStride, int dstride, int dstAligned) {
+  const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int y = blockIdx.y;
+  if (x >= w) return;
+  const uint8_t* s = src + (size_t)blockIdx.z * srcFrameStride + (size_t)y * sstride + (size_t)3 * x;
+  uint8_t* d = dst + (size_t)blockIdx.z * dstFrameStride + (size_t)y * dstride + x;
+  uint32_t out = 0;
+  if (x + 4 <= w && srcAligned) {
+    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s);
+    const uint32_t a = s4[0], b = s4[1], c = s4[2];  // bytes 0..11 = p0(0,1,2) p1(3,4,5) p2(6,7,8) p3(9,10,11)
+    const uint32_t y0 = ((a & 255) * c0 + ((a >> 8) & 255) * c1 + ((a >> 16) & 255) * c2 + 8192) >> 14;
+    const uint32_t y1 = ((a >> 24) * c0 + (b & 255) * c1 + ((b >> 8) & 255) * c2 + 8192) >> 14;
+    const uint32_t y2 = (((b >> 16) & 255) * c0 + (b >> 24) * c1 + (c & 255) * c2 + 8192) >> 14;
+    const uint32_t y3 = (((c >> 8) & 255) * c0 + ((c >> 16) & 255) * c1 + (c >> 24) * c2 + 8192) >> 14;
+    out = y0 | y1 << 8 | y2 << 16 | y3 << 24;
+    if (dstAligned) {
+      *reinterpret_cast<uint32_t*>(d) = out;
+      return;
+    }
+    d[0] = (uint8_t)y0; d[1] = (uint8_t)y1; d[2] = (uint8_t)y2; d[3] = (uint8_t)y3;
+    return;
+  }
+  const int n = min(4, w - x);
+  for (int i = 0; i < n; i++) d[i] = (uint8_t)((s[3 * i] * c0 + s[3 * i + 1] * c1 + s[3 * i + 2] * c2 + 8192) >> 14);
+}
+
+__global__ __launch_bounds__(256) void k_copy_rows(const uint8_t* __restrict__ src, long long srcFrameStride, int sstride, int w,
+                                                   int h, uint8_t* __restrict__ dst, long long dstFrameStride, int dstride) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= w) return;
+  dst[(size_t)blockIdx.z * dstFrameStride + (size_t)blockIdx.y * dstride + x] =
+      src[(size_t)blockIdx.z * srcFrameStride + (size_t)blockIdx.y * sstride + x];
+}
+
+// =================================================================================================
 // launch wrappers (called from orbx_api.cpp)
 // =================================================================================================
+hipError_t launch_to_gray(hipStream_t st, int nFrames, const uint8_t* src, long long srcFrameStride, int sstride, int w, int h,
+                          int channels, int rgb, uint8_t* dst, long long dstFrameStride, int dstride) {
+  if (nFrames <= 0) return hipSuccess;
+  if (channels == 1) {  // Converter.cpp:6-8: copyTo
+    dim3 block(256, 1, 1), grid((w + 255) / 256, h, nFrames);
+    hipLaunchKernelGGL(k_copy_rows, grid, block, 0, st, src, srcFrameStride, sstride, w, h, dst, dstFrameStride, dstride);
+    return hipGetLastError();
+  }
+  const int srcAligned = ((uintptr_t)src % 4 == 0) && (srcFrameStride % 4 == 0) && (sstride % 4 == 0);
+  const int dstAligned = ((uintptr_t)dst % 4 == 0) && (dstFrameStride % 4 == 0) && (dstride % 4 == 0);
+  dim3 block(256, 1, 1), grid((w + 1023) / 1024, h, nFrames);
+  hipLaunchKernelGGL(k_to_gray, grid, block, 0, st, src, srcFrameStride, sstride, w, h, rgb ? 4899 : 1868, 9617, rgb ? 1868 : 4899,
+                     srcAligned, dst, dstFrameStride, dstride, dstAligned);
+  return hipGetLastError();
+}
+
 hipError_t launch_undistort(hipStream_t st, int nFrames, const orbx_keypoint* in, const int* nkp, int capacity, const CamD& c,
                             orbx_keypoint* out) {
   if (nFrames <= 0 || capacity <= 0) return hipSuccess;

@@ -284,3 +284,15 @@ def image_bounds(camera, cols: int, rows: int):
     L.orbo_image_bounds.restype = None
     L.orbo_image_bounds(_p(_cam(camera)), cols, rows, _p(b))
     return tuple(int(v) for v in b)
+
+
+def to_gray(image: np.ndarray, rgb: bool = False):
+    """Oracle of Converter::toGray (Utils/Converter.cpp:5-19).  Returns the gray image, or None for `return false`."""
+    im = np.ascontiguousarray(image, np.uint8)
+    ch = 1 if im.ndim == 2 else im.shape[2]
+    h, w = im.shape[:2]
+    out = np.zeros((h, w), np.uint8)
+    L = lib()
+    L.orbo_to_gray.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int]
+    ok = L.orbo_to_gray(_p(im), w, h, w * ch, ch, int(rgb), _p(out), w)
+    return out if ok else None

@@ -471,3 +471,52 @@ def test_frames_with_distortion_match(orbx, oracle, images):
     e.match_pairs_device(np.array([0]), np.array([1]), d_k, d_d, d_n, ob_bounds, d_m, d_nm, None, 100, 0.9, True, cap)
     assert int(d_nm.item()) == onm and np.array_equal(d_m.cpu().numpy()[:len(om12)], om12)
     e.close()
+
+
+def test_to_gray_and_colour_chain(orbx, ext640, oracle):
+    """SURVEY 8(f) rank 2: Converter::toGray on the device (host and device-resident API), then colour frames -> gray ->
+    extraction equal to the oracle's chain."""
+    import torch
+    rng = np.random.default_rng(12)
+    for (h, w) in ((480, 752), (33, 641), (3, 5), (1, 1), (17, 1024)):
+        im = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for rgb in (False, True):
+            assert np.array_equal(ext640.to_gray(im, rgb), oracle.to_gray(im, rgb))
+        assert np.array_equal(ext640.to_gray(im[..., 1].copy()), im[..., 1])
+        assert np.array_equal(ext640.to_gray(im[:, :, :1].copy()), im[..., 0])
+        padded = np.zeros((h, w + 3, 3), np.uint8)   # a row stride that is not a multiple of 4 for odd w
+        padded[:, :w] = im
+        assert np.array_equal(ext640.to_gray(padded[:, :w], True), oracle.to_gray(im, True))
+    with pytest.raises(orbx.OrbxError) as ei:
+        ext640.to_gray(np.zeros((4, 4, 4), np.uint8))
+    assert ei.value.code == orbx.E_BADARG
+    with pytest.raises(orbx.OrbxError) as ei:
+        ext640.to_gray(np.zeros((0, 0, 3), np.uint8))
+    assert ei.value.code == orbx.E_EMPTY
+    # device-resident: B colour frames (RGB order) built from synthetic gray scenes with a colour cast
+    from orb_slam_tracking_amd import synth
+    B, W, H, cap = 4, 640, 480, 1000
+    g = synth.synth_frames(B, W, H, 4100).astype(np.int32)
+    col = np.stack([np.clip(g + 9, 0, 255), g, np.clip(g * 3 // 4 + 20, 0, 255)], axis=-1).astype(np.uint8)
+    d_col = torch.from_numpy(col).cuda()
+    for (gs, off) in ((W, 0), (W + 5, 1)):  # aligned and unaligned gray destinations
+        d_buf = torch.zeros(B * gs * H + 8, dtype=torch.uint8, device="cuda")
+        d_gray = d_buf[off:]
+        ext640.to_gray_batch_device(d_col, B, W, H, W * 3, W * H * 3, 3, True, d_gray, gs, gs * H)
+        got = d_gray[:B * gs * H].cpu().numpy().reshape(B, H, gs)[:, :, :W]
+        want = np.stack([oracle.to_gray(c, True) for c in col])
+        assert np.array_equal(got, want)
+    d_k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+    d_d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    e = orbx.ORBextractor(*CANON, max_width=W, max_height=H, max_batch=B)
+    e.extract_batch_device(d_gray, B, W, H, gs, gs * H, d_k, d_d, d_n, cap)
+    n = d_n.cpu().numpy()
+    kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, cap)
+    dd = d_d.cpu().numpy().reshape(B, cap, 32)
+    oe = oracle.Extractor(*CANON)
+    for f in range(B):
+        _, ko, do = oe(want[f])
+        assert n[f] == len(ko)
+        _same(kk[f, :n[f]], dd[f, :n[f]], ko, do)
+    e.close()

@@ -241,3 +241,25 @@ def test_undistort_keypoints_and_bounds(oracle, golden):
     for i in range(50):
         ex, ey = _undistort_np(camt, k["x"][i], k["y"][i])
         assert ut["x"][i] == ex and ut["y"][i] == ey
+
+
+def test_to_gray(oracle, images):
+    """SURVEY 8(f) rank 2: Converter::toGray (Utils/Converter.cpp:5-19) with the 14-bit cvtColor coefficients."""
+    rng = np.random.default_rng(11)
+    for (h, w) in ((480, 752), (33, 641), (3, 5), (1, 1)):
+        im = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        a = im.astype(np.int64)
+        assert np.array_equal(oracle.to_gray(im, True), ((a[..., 0] * 4899 + a[..., 1] * 9617 + a[..., 2] * 1868 + 8192) >> 14))
+        assert np.array_equal(oracle.to_gray(im, False), ((a[..., 2] * 4899 + a[..., 1] * 9617 + a[..., 0] * 1868 + 8192) >> 14))
+        assert np.array_equal(oracle.to_gray(im[..., 0].copy()), im[..., 0])                    # one channel: copyTo
+    assert oracle.to_gray(np.zeros((4, 4, 4), np.uint8)) is None                                # "Wrong image format"
+    assert oracle.to_gray(np.full((2, 2, 3), 255, np.uint8), True).tolist() == [[255, 255], [255, 255]]  # coefficients sum to 2^14
+    # the committed gray fixtures of the two init images are this conversion of the reference's RGB PNGs
+    pngs = sorted(__import__("glob").glob("/root/reference/demo/initImages/*.png"))
+    if len(pngs) == 2:
+        try:
+            from PIL import Image
+        except ImportError:
+            return
+        for i, f in enumerate(pngs):
+            assert np.array_equal(oracle.to_gray(np.array(Image.open(f).convert("RGB")), True), images["init%d" % i])
