@@ -110,7 +110,9 @@ __global__ __launch_bounds__(256) void k_resize_dw(const uint8_t* __restrict__ s
 // =================================================================================================
 #define TILE_STRIDE 84   // bytes per LDS tile row (21 words)
 #define SMAP_STRIDE 72   // 70 + 2 zero apron
-#define FAST_OUT_MAX 1296
+struct FastLds {
+  int32_t tileBytes, smapBytes, listBytes, outCap;
+};
 
 __device__ __forceinline__ bool arc9(uint32_t m) {  // 16-bit circular mask has a run of >= 9 ones
   m |= m << 16;
@@ -124,11 +126,14 @@ __device__ __forceinline__ bool arc9(uint32_t m) {  // 16-bit circular mask has 
 __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img0, long long img0FrameStride, int img0Aligned,
                                               const uint8_t* __restrict__ pyr, const Geom g,
                                               uint32_t* __restrict__ cand, int* __restrict__ candCount,
-                                              int* __restrict__ overflow) {
-  __shared__ __attribute__((aligned(16))) uint8_t tile[ORBX_CELL_MAX * TILE_STRIDE];
-  __shared__ __attribute__((aligned(16))) uint8_t smap[SMAP_STRIDE * SMAP_STRIDE];
-  __shared__ uint16_t list[70 * 70];
-  __shared__ uint32_t outl[FAST_OUT_MAX];
+                                              int* __restrict__ overflow, const FastLds fl) {
+  // LDS carved to the largest cell of this geometry (launch_fast), so that occupancy is bound by waves, not by LDS:
+  // tile[tileBytes] | strength map[smapBytes] | quick-reject list u16[listCap] | survivors u32[outCap]
+  extern __shared__ __attribute__((aligned(16))) uint8_t fastLds[];
+  uint8_t* const tile = fastLds;
+  uint8_t* const smap = fastLds + fl.tileBytes;
+  uint16_t* const list = reinterpret_cast<uint16_t*>(fastLds + fl.tileBytes + fl.smapBytes);
+  uint32_t* const outl = reinterpret_cast<uint32_t*>(fastLds + fl.tileBytes + fl.smapBytes + fl.listBytes);
   __shared__ int nList, nOut, outBase;
 
   const int t = threadIdx.x;
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img0, 
   }
   {
     uint32_t* smap32 = reinterpret_cast<uint32_t*>(smap);
-    for (int idx = t; idx < SMAP_STRIDE * SMAP_STRIDE / 4; idx += 256) smap32[idx] = 0;
+    for (int idx = t; idx < fl.smapBytes / 4; idx += 256) smap32[idx] = 0;
   }
   if (t == 0) { nList = 0; nOut = 0; }
   __syncthreads();
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img0, 
                         s > q[1] && s > q[SMAP_STRIDE - 1] && s > q[SMAP_STRIDE] && s > q[SMAP_STRIDE + 1];
       if (keep) {
         const int slot = atomicAdd(&nOut, 1);
-        if (slot < FAST_OUT_MAX) outl[slot] = packCand(px + 3 + cj * L.wCell, py + 3 + ci * L.hCell, s - 1);
+        if (slot < fl.outCap) outl[slot] = packCand(px + 3 + cj * L.wCell, py + 3 + ci * L.hCell, s - 1);
       }
     }
     __syncthreads();
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img0, 
     if (t == 0) nList = 0;  // retry the whole cell at minThFAST
     __syncthreads();
   }
-  const int no = min(nOut, FAST_OUT_MAX);
+  const int no = min(nOut, fl.outCap);
   if (t == 0) outBase = no ? atomicAdd(&candCount[f * g.nlevels + level], no) : 0;
   __syncthreads();
   const int ob = outBase;
@@ -323,7 +328,34 @@ __device__ __forceinline__ uint32_t dot2u16(uint32_t a, uint32_t b, uint32_t c) 
 #define PW_PAIRS 22    // row pairs of horizontal sums (rows 0..43, the last one is a dummy)
 #define PW_COLS 40     // 37 blurred columns padded to 10 groups of 4
 #define BL_ROWS_PAD 38
-#define PW_WAVE_WORDS (PW_ROWS * PW_WORDS + PW_PAIRS * PW_COLS)  // the blurred bytes reuse the raw window's space
+#define PW_RAW_WORDS 560  // PW_ROWS * PW_WORDS = 559, padded so that the row-pair sums behind it are 16-byte aligned
+#define PW_WAVE_WORDS (PW_RAW_WORDS + PW_PAIRS * PW_COLS + 4)  // the blurred bytes reuse the raw window's space; + 2 moment sums
+
+// IC_Angle disc as dot4 weights: row |v| of the 31x31 disc covers u = -umax[|v|] .. umax[|v|]; the row's 32 bytes
+// u = -15 .. 16 are 8 dwords j, and for each the weights are w1 = (1 per valid byte) and wu = (u + 15 per valid byte), so
+// sum I = sum_j dot4(B_j, w1_j),  sum u*I = sum_j dot4(B_j, wu_j) - 15 * sum I   (exact integer identities).
+struct IcTables {
+  uint32_t w1[16 * 8], wu[16 * 8];
+};
+constexpr IcTables makeIcTables() {
+  IcTables t{};
+  constexpr int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // cpp:562-594 (== c_umax)
+  for (int av = 0; av < 16; av++)
+    for (int j = 0; j < 8; j++) {
+      uint32_t m1 = 0, mu = 0;
+      for (int b = 0; b < 4; b++) {
+        const int u = -15 + 4 * j + b, au = u < 0 ? -u : u;
+        if (au <= um[av]) {
+          m1 |= 1u << (8 * b);
+          mu |= (uint32_t)(u + 15) << (8 * b);
+        }
+      }
+      t.w1[av * 8 + j] = m1;
+      t.wu[av * 8 + j] = mu;
+    }
+  return t;
+}
+__device__ const IcTables d_ic = makeIcTables();
 
 __global__ __launch_bounds__(64) void k_describe_patch(const uint8_t* __restrict__ img0, long long img0FrameStride,
                                                        int img0Aligned, const uint8_t* __restrict__ pyr, const Geom g,
@@ -335,100 +367,143 @@ __global__ __launch_bounds__(64) void k_describe_patch(const uint8_t* __restrict
   const int i = blockIdx.x;
   if (i >= nsel[f]) return;  // uniform; the workgroup is one wave
   uint32_t* raw = lds;                               // [43][13] dwords
-  uint32_t* hz2 = raw + PW_ROWS * PW_WORDS;          // [22][40] row-pair packed horizontal sums
+  uint32_t* hz2 = raw + PW_RAW_WORDS;                // [22][40] row-pair packed horizontal sums (16-byte aligned rows)
   uint32_t* bl32 = raw;                              // [38][10] dwords = blurred bytes, row stride 40 (raw is dead by then)
+  int* msum = reinterpret_cast<int*>(hz2 + PW_PAIRS * PW_COLS);  // [2] moment sums of IC_Angle
   static_assert(BL_ROWS_PAD * (PW_COLS / 4) <= PW_ROWS * PW_WORDS, "blurred bytes must fit in the raw window");
+  static_assert(PW_ROWS * PW_WORDS <= PW_RAW_WORDS && PW_RAW_WORDS % 4 == 0, "raw window padding");
   const SelKp k = sel[(long long)f * g.selCap + i];
-  const LevelGeom& L = g.L[k.level];
-  const uint8_t* img = k.level == 0 ? img0 + (long long)f * img0FrameStride : pyr + L.imgOff + (long long)f * L.frameStride;
-  const bool aligned = k.level > 0 || img0Aligned != 0;
-  const int kx = k.x, ky = k.y, w = L.w, h = L.h, stride = L.stride;
+  // the keypoint is wave-uniform: keep its fields in SGPRs so that the level geometry comes through scalar loads
+  const int level = __builtin_amdgcn_readfirstlane((int)k.level);
+  const int kx = __builtin_amdgcn_readfirstlane((int)k.x), ky = __builtin_amdgcn_readfirstlane((int)k.y);
+  const LevelGeom& L = g.L[level];
+  const uint8_t* img = level == 0 ? img0 + (long long)f * img0FrameStride : pyr + L.imgOff + (long long)f * L.frameStride;
+  const bool aligned = level > 0 || img0Aligned != 0;
+  const int w = L.w, h = L.h, stride = L.stride;
   const int ax = (kx - 21) & ~3;          // may be -4
   const int s = (kx - 21) - ax;           // byte offset of window column 0 inside a staged row, 0..3
-  // ---- stage the raw window ----
-  for (int idx = lane; idx < PW_ROWS * PW_WORDS; idx += 64) {
-    const int r = idx / PW_WORDS, d = idx - r * PW_WORDS;
-    int yy = ky - 21 + r;
-    yy = yy < 0 ? -yy : yy; yy = yy >= h ? 2 * h - 2 - yy : yy;
-    const uint8_t* row = img + (long long)yy * stride;
+  // ---- stage the raw window: lanes 0..51 = 4 rows x 13 dwords per step, 11 steps, all loads in flight at once ----
+  {
+    const int rsub = lane / PW_WORDS, d = lane - rsub * PW_WORDS;
     const int xs = ax + 4 * d;
-    uint32_t word;
-    if (aligned && xs >= 0 && xs + 4 <= w) {
-      word = *reinterpret_cast<const uint32_t*>(row + xs);
-    } else {
-      word = 0;
+    const bool active = lane < 4 * PW_WORDS;
+    const bool fastx = aligned && xs >= 0 && xs + 4 <= w;
+    if (lane == 0) { msum[0] = 0; msum[1] = 0; }
 #pragma unroll
-      for (int b = 0; b < 4; b++) {
-        int xx = xs + b;
-        xx = xx < 0 ? -xx : xx; xx = xx >= w ? 2 * w - 2 - xx : xx; xx = min(max(xx, 0), w - 1);
-        word |= (uint32_t)row[xx] << (8 * b);
+    for (int it = 0; it < 11; it++) {
+      const int r = it * 4 + rsub;
+      if (active && fastx && r < PW_ROWS) {
+        int yy = ky - 21 + r;
+        yy = yy < 0 ? -yy : yy; yy = yy >= h ? 2 * h - 2 - yy : yy;
+        raw[it * (4 * PW_WORDS) + lane] = *reinterpret_cast<const uint32_t*>(img + (yy * stride + xs));
       }
     }
-    raw[idx] = word;
+    if (active && !fastx) {  // window dwords that cross the level's left/right edge (or an unaligned level 0): bytes, REFLECT_101
+      for (int r = rsub; r < PW_ROWS; r += 4) {
+        int yy = ky - 21 + r;
+        yy = yy < 0 ? -yy : yy; yy = yy >= h ? 2 * h - 2 - yy : yy;
+        const uint8_t* row = img + (long long)yy * stride;
+        uint32_t word = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          int xx = xs + b;
+          xx = xx < 0 ? -xx : xx; xx = xx >= w ? 2 * w - 2 - xx : xx; xx = min(max(xx, 0), w - 1);
+          word |= (uint32_t)row[xx] << (8 * b);
+        }
+        raw[r * PW_WORDS + d] = word;
+      }
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  const uint8_t* raw8 = reinterpret_cast<const uint8_t*>(raw);
-  // ---- IC_Angle (cpp:103-159) on the un-blurred window: pixel (u, v) is row 21+v, byte s+21+u ----
-  int m10 = 0, m01 = 0;
-  {
-    const int u = (lane & 31) - 15;  // lanes 31 and 63 idle
-    const int au = u < 0 ? -u : u;
-#pragma unroll 4
-    for (int it = 0; it < 16; it++) {
-      const int v = -15 + 2 * it + (lane >> 5);
-      const int av = v < 0 ? -v : v;
-      if (av <= 15 && au <= 15 && au <= c_umax[av & 15]) {
-        const int I = raw8[(21 + v) * (PW_WORDS * 4) + s + 21 + u];
-        m10 += u * I;
-        m01 += v * I;
-      }
-    }
+  // ---- IC_Angle (cpp:103-159) on the un-blurred window: pixel (u, v) is row 21+v, byte s+21+u.  Lane = disc row v;
+  //      the row's bytes u = -15..16 are 8 dwords, each weighted with v_dot4_u32_u8 (tables d_ic) ----
+  if (lane < 31) {
+    const int v = lane - 15, av = v < 0 ? -v : v;
+    const uint4* t1 = reinterpret_cast<const uint4*>(d_ic.w1 + av * 8);
+    const uint4* tu = reinterpret_cast<const uint4*>(d_ic.wu + av * 8);
+    const uint4 w1a = t1[0], w1b = t1[1], wua = tu[0], wub = tu[1];
+    const uint32_t w1[8] = {w1a.x, w1a.y, w1a.z, w1a.w, w1b.x, w1b.y, w1b.z, w1b.w};
+    const uint32_t wu[8] = {wua.x, wua.y, wua.z, wua.w, wub.x, wub.y, wub.z, wub.w};
+    const uint32_t* rowp = raw + (6 + lane) * PW_WORDS + ((s + 6) >> 2);  // row 21 + v, first dword holding u = -15
+    const uint32_t sh = (uint32_t)(s + 6) & 3u;
+    uint32_t src[9];
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      m10 += __shfl_xor(m10, o);
-      m01 += __shfl_xor(m01, o);
+    for (int j = 0; j < 9; j++) src[j] = rowp[j];
+    uint32_t sumI = 0, sumU = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t B = __builtin_amdgcn_alignbyte(src[j + 1], src[j], sh);
+      sumI = __builtin_amdgcn_udot4(B, w1[j], sumI, false);
+      sumU = __builtin_amdgcn_udot4(B, wu[j], sumU, false);
     }
+    atomicAdd(&msum[0], (int)sumU - 15 * (int)sumI);  // m10 = sum u*I
+    atomicAdd(&msum[1], v * (int)sumI);                // m01 = sum v*I
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  const int m10 = msum[0], m01 = msum[1];
   const float angle = fast_atan2_deg((float)m01, (float)m10);
-  // ---- horizontal pass: blurred column c (x = kx-18+c) uses window bytes s+c .. s+c+6 of the staged row ----
-  //      lane = column: consecutive lanes read consecutive (or the same) LDS words -> no bank conflicts
-  if (lane < PW_COLS) {
+  // ---- horizontal pass: blurred column c (x = kx-18+c) uses window bytes s+c .. s+c+6 of the staged row.
+  //      Item = (row pair, group of 4 columns): 4 dwords per row cover the 10 bytes the 4 columns need; 60 lanes x 4 steps ----
+  {
     const uint32_t K0 = 18u | (34u << 8) | (48u << 16) | (56u << 24), K1 = 48u | (34u << 8) | (18u << 16);
-    const int wi = (s + lane) >> 2, sh8 = (s + lane) & 3;  // first word / byte shift of this column's 7 taps
-    const bool has2 = wi + 2 < PW_WORDS;
-#pragma unroll 2
-    for (int rp = 0; rp < PW_PAIRS; rp++) {
-      const int ra = 2 * rp, rb = min(2 * rp + 1, PW_ROWS - 1);
-      const uint32_t* pa = &raw[ra * PW_WORDS + wi];
-      const uint32_t* pb = &raw[rb * PW_WORDS + wi];
-      const uint32_t a0 = pa[0], a1 = pa[1], a2 = has2 ? pa[2] : 0u;
-      const uint32_t b0 = pb[0], b1 = pb[1], b2 = has2 ? pb[2] : 0u;
-      const uint32_t ha = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(a1, a0, sh8), K0,
-                                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(a2, a1, sh8), K1, 0u, false), false);
-      const uint32_t hb = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b1, b0, sh8), K0,
-                                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b2, b1, sh8), K1, 0u, false), false);
-      hz2[rp * PW_COLS + lane] = ha | (hb << 16);
+    const int rpl = lane / 10, gq = lane - rpl * 10;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int rp = it * 6 + rpl;
+      if (lane < 60 && rp < PW_PAIRS) {
+        uint32_t hs[2][4];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) {
+          const int row = h2 ? min(2 * rp + 1, PW_ROWS - 1) : 2 * rp;
+          const uint32_t* p = raw + row * PW_WORDS + gq;
+          const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
+          const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)s), e1 = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)s),
+                         e2 = __builtin_amdgcn_alignbyte(d3, d2, (uint32_t)s);  // window bytes 4g.., 4g+4.., 4g+8..
+          hs[h2][0] = __builtin_amdgcn_udot4(e0, K0, __builtin_amdgcn_udot4(e1, K1, 0u, false), false);
+#pragma unroll
+          for (int kk = 1; kk < 4; kk++)
+            hs[h2][kk] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(e1, e0, (uint32_t)kk), K0,
+                                                __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(e2, e1, (uint32_t)kk), K1, 0u, false), false);
+        }
+        uint4 o4;
+        o4.x = hs[0][0] | (hs[1][0] << 16); o4.y = hs[0][1] | (hs[1][1] << 16);
+        o4.z = hs[0][2] | (hs[1][2] << 16); o4.w = hs[0][3] | (hs[1][3] << 16);
+        *reinterpret_cast<uint4*>(&hz2[rp * PW_COLS + 4 * gq]) = o4;
+      }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   // ---- vertical pass + rounding with v_dot2_u32_u16 on row pairs: blurred rows 2q and 2q+1 both use pairs q..q+3,
-  //      even row taps (18,34)(48,56)(48,34)(18,0), odd row taps (0,18)(34,48)(56,48)(34,18); lane = column with a
-  //      rolling window of row pairs; the blurred bytes overwrite the raw window (no longer needed) ----
-  if (lane < PW_COLS) {
+  //      even row taps (18,34)(48,56)(48,34)(18,0), odd row taps (0,18)(34,48)(56,48)(34,18).  Item = (q, group of 4
+  //      columns), 190 items over 3 steps; the blurred bytes overwrite the raw window (no longer needed) ----
+  {
     const uint32_t E0 = 18u | (34u << 16), E1 = 48u | (56u << 16), E2 = 48u | (34u << 16), E3 = 18u;
     const uint32_t O0 = 18u << 16, O1 = 34u | (48u << 16), O2 = 56u | (48u << 16), O3 = 34u | (18u << 16);
-    uint8_t* bl8 = reinterpret_cast<uint8_t*>(bl32);
-    uint32_t p0 = hz2[0 * PW_COLS + lane], p1 = hz2[1 * PW_COLS + lane], p2 = hz2[2 * PW_COLS + lane];
+    int q = lane / 10, gq = lane - q * 10;
 #pragma unroll
-    for (int q = 0; q < BL_ROWS_PAD / 2; q++) {
-      const uint32_t p3 = hz2[(q + 3) * PW_COLS + lane];
-      const uint32_t se = dot2u16(p0, E0, dot2u16(p1, E1, dot2u16(p2, E2, dot2u16(p3, E3, 32768u))));
-      const uint32_t so = dot2u16(p0, O0, dot2u16(p1, O1, dot2u16(p2, O2, dot2u16(p3, O3, 32768u))));
-      bl8[(2 * q) * PW_COLS + lane] = (uint8_t)(se >> 16);
-      bl8[(2 * q + 1) * PW_COLS + lane] = (uint8_t)(so >> 16);
-      p0 = p1; p1 = p2; p2 = p3;
+    for (int it = 0; it < 3; it++) {
+      if (q < BL_ROWS_PAD / 2) {
+        const uint4 P0 = *reinterpret_cast<const uint4*>(&hz2[(q + 0) * PW_COLS + 4 * gq]);
+        const uint4 P1 = *reinterpret_cast<const uint4*>(&hz2[(q + 1) * PW_COLS + 4 * gq]);
+        const uint4 P2 = *reinterpret_cast<const uint4*>(&hz2[(q + 2) * PW_COLS + 4 * gq]);
+        const uint4 P3 = *reinterpret_cast<const uint4*>(&hz2[(q + 3) * PW_COLS + 4 * gq]);
+#define ORBX_VE(c) dot2u16(P0.c, E0, dot2u16(P1.c, E1, dot2u16(P2.c, E2, dot2u16(P3.c, E3, 32768u))))
+#define ORBX_VO(c) dot2u16(P0.c, O0, dot2u16(P1.c, O1, dot2u16(P2.c, O2, dot2u16(P3.c, O3, 32768u))))
+        const uint32_t e0 = ORBX_VE(x), e1 = ORBX_VE(y), e2 = ORBX_VE(z), e3 = ORBX_VE(w);
+        const uint32_t o0 = ORBX_VO(x), o1 = ORBX_VO(y), o2 = ORBX_VO(z), o3 = ORBX_VO(w);
+#undef ORBX_VE
+#undef ORBX_VO
+        // each sum is < 2^24: its blurred byte is bits 16..23; v_perm_b32 gathers byte 2 of four sums into one dword
+        bl32[(2 * q) * (PW_COLS / 4) + gq] =
+            __builtin_amdgcn_perm(e1, e0, 0x0c0c0602u) | __builtin_amdgcn_perm(e3, e2, 0x06020c0cu);
+        bl32[(2 * q + 1) * (PW_COLS / 4) + gq] =
+            __builtin_amdgcn_perm(o1, o0, 0x0c0c0602u) | __builtin_amdgcn_perm(o3, o2, 0x06020c0cu);
+      }
+      q += 6; gq += 4;  // item + 64
+      if (gq >= 10) { gq -= 10; q++; }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1232,7 +1307,18 @@ hipError_t launch_resize(hipStream_t st, int nFrames, const uint8_t* src, long l
 hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, int img0Aligned,
                        const uint8_t* pyr, const Geom& g, uint32_t* cand, int* candCount, int* overflow) {
   dim3 block(256, 1, 1), grid(g.nCellsTotal, nFrames, 1);
-  hipLaunchKernelGGL(k_fast, grid, block, 0, st, img0, img0FrameStride, img0Aligned, pyr, g, cand, candCount, overflow);
+  int cw = 7, ch = 7;  // largest cell image of this geometry (cell + 6 px overlap, cpp:1094-1103)
+  for (int l = 0; l < g.nlevels; l++) {
+    cw = std::max(cw, std::min(g.L[l].wCell + 6, ORBX_CELL_MAX));
+    ch = std::max(ch, std::min(g.L[l].hCell + 6, ORBX_CELL_MAX));
+  }
+  FastLds fl;
+  fl.tileBytes = (ch * TILE_STRIDE + 15) & ~15;
+  fl.smapBytes = (SMAP_STRIDE * (ch - 6 + 2) + 15) & ~15;
+  fl.listBytes = (2 * (cw - 6) * (ch - 6) + 15) & ~15;
+  fl.outCap = ((cw - 6 + 1) / 2) * ((ch - 6 + 1) / 2);  // NMS survivors are never 8-neighbours
+  const size_t lds = (size_t)fl.tileBytes + fl.smapBytes + fl.listBytes + (size_t)fl.outCap * 4;
+  hipLaunchKernelGGL(k_fast, grid, block, lds, st, img0, img0FrameStride, img0Aligned, pyr, g, cand, candCount, overflow, fl);
   return hipGetLastError();
 }
 
