@@ -422,7 +422,7 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
     StageTimer tm(ctx, ORBX_STAGE_SELECT, si, st);
     HIPCHK(launch_octree(st, n, ctx->dCand, ctx->dCandCount, oct, ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, ctx->maxQuota));
     HIPCHK(launch_sel_compact(st, n, ctx->dSelStage, ctx->dNselLevel, oct, ctx->dSel, ctx->dNsel, g.selCap, ctx->dOverflow + 1));
-    tm.stop(ctx->maxQuota <= 256 ? 3 : 2);
+    tm.stop(2);
   }
   {
     StageTimer tm(ctx, ORBX_STAGE_DESCRIBE, si, st);

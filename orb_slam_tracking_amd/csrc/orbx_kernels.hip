@@ -389,13 +389,23 @@ __global__ __launch_bounds__(64) void k_describe_patch(const uint8_t* __restrict
     const bool active = lane < 4 * PW_WORDS;
     const bool fastx = aligned && xs >= 0 && xs + 4 <= w;
     if (lane == 0) { msum[0] = 0; msum[1] = 0; }
+    if (ky - 21 >= 0 && ky + 21 < h) {  // (uniform) no row of the window is reflected: one address, stepped by 4 rows
+      const uint8_t* p = img + ((ky - 21 + rsub) * stride + xs);
+      const int step = 4 * stride;
 #pragma unroll
-    for (int it = 0; it < 11; it++) {
-      const int r = it * 4 + rsub;
-      if (active && fastx && r < PW_ROWS) {
-        int yy = ky - 21 + r;
-        yy = yy < 0 ? -yy : yy; yy = yy >= h ? 2 * h - 2 - yy : yy;
-        raw[it * (4 * PW_WORDS) + lane] = *reinterpret_cast<const uint32_t*>(img + (yy * stride + xs));
+      for (int it = 0; it < 11; it++) {
+        if (active && fastx && it * 4 + rsub < PW_ROWS) raw[it * (4 * PW_WORDS) + lane] = *reinterpret_cast<const uint32_t*>(p);
+        p += step;
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 11; it++) {
+        const int r = it * 4 + rsub;
+        if (active && fastx && r < PW_ROWS) {
+          int yy = ky - 21 + r;
+          yy = yy < 0 ? -yy : yy; yy = yy >= h ? 2 * h - 2 - yy : yy;
+          raw[it * (4 * PW_WORDS) + lane] = *reinterpret_cast<const uint32_t*>(img + (yy * stride + xs));
+        }
       }
     }
     if (active && !fastx) {  // window dwords that cross the level's left/right edge (or an unaligned level 0): bytes, REFLECT_101

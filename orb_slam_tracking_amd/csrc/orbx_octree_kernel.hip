@@ -688,52 +688,12 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
   OCT_STAMP(15);
 }
 
-// ---- kernels ---------------------------------------------------------------------------------------------------------
-
-// LDS-resident variant: n <= NMAX candidates, quota <= QMAX
-template <int NMAX, int QMAX>
-__global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict__ cand, const int* __restrict__ candCount,
-                                                     const OctLaunch P, SelKp* __restrict__ selStage,
-                                                     int* __restrict__ nselLevel) {
-  constexpr int MCAP = 4 * QMAX, FCAP = 2 * QMAX;
-  static_assert((NMAX & (NMAX - 1)) == 0 && (MCAP & (MCAP - 1)) == 0, "sort buffers must be powers of two");
-  // LDS budget (NMAX 2048, QMAX 256): 16 + 8 + 8 + 12 + 4 + 3 KB = 51 KB -> three workgroups per CU.
-  //   nodes[] is dead once the node records exist, so the partial pass's buffers (sized, pending, childCnt) live in it;
-  //   hiOf[] is dead after step 4 and shares its space with the candidate cache (reloaded before the emit step).
-  __shared__ u64 keys[NMAX];
-  __shared__ u64 nodes[MCAP];
-  __shared__ uint32_t candL[NMAX];
-  __shared__ int nodeLo[MCAP + FCAP], nodeHi[MCAP + FCAP];
-  __shared__ uint8_t div[NMAX + 4], alone[NMAX];
-  __shared__ uint8_t nodeDepth[MCAP + FCAP], nodeAlive[MCAP + FCAP];
-  static_assert(2 * QMAX * 8 + 2 * QMAX * 4 + QMAX * 4 <= MCAP * 8, "partial-pass buffers must fit in nodes[]");
-  u64* sized = nodes;                                             // [2 * QMAX]
-  int* pending = reinterpret_cast<int*>(nodes + 2 * QMAX);        // [2 * QMAX]
-  int* childCnt = pending + 2 * QMAX;                             // [QMAX]
-  uint32_t* hiOf = candL;
-  const int level = blockIdx.x, f = blockIdx.y + P.frame0;
-  const int n = candCount[f * P.nlevels + level];
+// One (frame, level) unit on the global-scratch layout (octScratchBytes()); `xchg` = OCT_SORT_LDS u64 of LDS for the sorts.
+// Scratch of unit (f, level) starts at scrOff[level] + f * scrStride[level].
+__device__ void octreeGlobalUnit(const uint32_t* __restrict__ cand, const int* __restrict__ candCount, const OctLaunch& P,
+                                 SelKp* __restrict__ selStage, int* __restrict__ nselLevel, uint8_t* __restrict__ scratch,
+                                 int level, int f, u64* xchg) {
   int* nOut = &nselLevel[f * P.nlevels + level];
-  if (n > NMAX || P.lev[level].quota > QMAX) {  // handled by the global-scratch variant
-    if (threadIdx.x == 0) *nOut = -2;
-    return;
-  }
-  const uint32_t* src = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
-  for (int i = threadIdx.x; i < n; i += OCT_T) candL[i] = src[i];
-  __syncthreads();
-  OctScratch S{keys, nodes, div, alone, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, childCnt, candL, candL, src, nullptr};
-  octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, MCAP, FCAP, QMAX);
-}
-
-// global-scratch variant for the (frame, level) units the LDS variant left (nselLevel == -2), or for all units when
-// `all` is set.  Scratch of unit (f, level) starts at scrOff[level] + f * scrStride[level]; layout: octScratchBytes().
-__global__ __launch_bounds__(OCT_T) void k_octree_global(const uint32_t* __restrict__ cand, const int* __restrict__ candCount,
-                                                        const OctLaunch P, SelKp* __restrict__ selStage,
-                                                        int* __restrict__ nselLevel, uint8_t* __restrict__ scratch, int all) {
-  __shared__ u64 xchg[OCT_SORT_LDS];
-  const int level = blockIdx.x, f = blockIdx.y + P.frame0;
-  int* nOut = &nselLevel[f * P.nlevels + level];
-  if (!all && *nOut != -2) return;
   const int nMax = P.scrNMax[level], qMax = max(P.lev[level].quota, 1);
   const int n = candCount[f * P.nlevels + level];
   if (n > nMax) {  // more candidates than the selection stage can index (2^19 - 1)
@@ -766,6 +726,61 @@ __global__ __launch_bounds__(OCT_T) void k_octree_global(const uint32_t* __restr
   octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, mCap, fCap, qMax);
   __syncthreads();
   if (threadIdx.x == 0 && *nOut == -2) *nOut = -1;  // even the large scratch was too small: hard error
+}
+
+// ---- kernels ---------------------------------------------------------------------------------------------------------
+
+// LDS-resident variant: n <= NMAX candidates, quota <= QMAX
+template <int NMAX, int QMAX>
+__global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict__ cand, const int* __restrict__ candCount,
+                                                     const OctLaunch P, SelKp* __restrict__ selStage,
+                                                     int* __restrict__ nselLevel, uint8_t* __restrict__ scratch) {
+  constexpr int MCAP = 4 * QMAX, FCAP = 2 * QMAX;
+  static_assert((NMAX & (NMAX - 1)) == 0 && (MCAP & (MCAP - 1)) == 0, "sort buffers must be powers of two");
+  // LDS budget (NMAX 2048, QMAX 256): 16 + 8 + 8 + 12 + 4 + 3 KB = 51 KB -> three workgroups per CU.
+  //   nodes[] is dead once the node records exist, so the partial pass's buffers (sized, pending, childCnt) live in it;
+  //   hiOf[] is dead after step 4 and shares its space with the candidate cache (reloaded before the emit step).
+  __shared__ u64 keys[NMAX];
+  __shared__ u64 nodes[MCAP];
+  __shared__ uint32_t candL[NMAX];
+  __shared__ int nodeLo[MCAP + FCAP], nodeHi[MCAP + FCAP];
+  __shared__ uint8_t div[NMAX + 4], alone[NMAX];
+  __shared__ uint8_t nodeDepth[MCAP + FCAP], nodeAlive[MCAP + FCAP];
+  static_assert(2 * QMAX * 8 + 2 * QMAX * 4 + QMAX * 4 <= MCAP * 8, "partial-pass buffers must fit in nodes[]");
+  u64* sized = nodes;                                             // [2 * QMAX]
+  int* pending = reinterpret_cast<int*>(nodes + 2 * QMAX);        // [2 * QMAX]
+  int* childCnt = pending + 2 * QMAX;                             // [QMAX]
+  uint32_t* hiOf = candL;
+  const int level = blockIdx.y, f = blockIdx.x + P.frame0;  // level-major dispatch, see launch_octree
+  const int n = candCount[f * P.nlevels + level];
+  int* nOut = &nselLevel[f * P.nlevels + level];
+  static_assert(NMAX >= OCT_SORT_LDS, "keys[] doubles as the sort exchange buffer of the global-scratch path");
+  __shared__ int redo;
+  if (n <= NMAX && P.lev[level].quota <= QMAX) {
+    const uint32_t* src = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
+    for (int i = threadIdx.x; i < n; i += OCT_T) candL[i] = src[i];
+    __syncthreads();
+    OctScratch S{keys, nodes, div, alone, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, childCnt, candL, candL, src, nullptr};
+    octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, MCAP, FCAP, QMAX);
+    __syncthreads();
+    if (threadIdx.x == 0) redo = (*nOut == -2);  // a node table overflowed the LDS layout
+    __syncthreads();
+    if (!redo) return;
+  }
+  // the unit does not fit the LDS layout: same workgroup, global scratch (no second kernel on the stream's critical path)
+  __syncthreads();
+  octreeGlobalUnit(cand, candCount, P, selStage, nselLevel, scratch, level, f, keys);
+}
+
+// global-scratch variant for the (frame, level) units the LDS variant left (nselLevel == -2), or for all units when
+// `all` is set.  Scratch of unit (f, level) starts at scrOff[level] + f * scrStride[level]; layout: octScratchBytes().
+__global__ __launch_bounds__(OCT_T) void k_octree_global(const uint32_t* __restrict__ cand, const int* __restrict__ candCount,
+                                                        const OctLaunch P, SelKp* __restrict__ selStage,
+                                                        int* __restrict__ nselLevel, uint8_t* __restrict__ scratch, int all) {
+  __shared__ u64 xchg[OCT_SORT_LDS];
+  const int level = blockIdx.y, f = blockIdx.x + P.frame0;  // level-major dispatch, see launch_octree
+  if (!all && nselLevel[f * P.nlevels + level] != -2) return;
+  octreeGlobalUnit(cand, candCount, P, selStage, nselLevel, scratch, level, f, xchg);
 }
 
 size_t octScratchBytes(int nMax, int qMax) {
@@ -808,11 +823,13 @@ __global__ __launch_bounds__(256) void k_sel_compact(const SelKp* __restrict__ s
 
 hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, const int* candCount, const OctLaunch& P,
                          SelKp* selStage, int* nselLevel, uint8_t* scratch, int maxQuota) {
-  dim3 grid(P.nlevels, nFrames, 1), block(OCT_T, 1, 1);
+  // workgroups are dispatched x-fastest: all frames of level 0 first, then level 1, ...  The units of the lowest levels
+  // run longest (most candidates, largest quota), so this is longest-processing-time-first and keeps the tail short.
+  dim3 grid(nFrames, P.nlevels, 1), block(OCT_T, 1, 1);
   const bool lds = maxQuota <= 256;
-  if (lds) hipLaunchKernelGGL((k_octree_lds<2048, 256>), grid, block, 0, st, cand, candCount, P, selStage, nselLevel);
-  // units the LDS variant could not take (more than 2048 candidates, or scratch overflow) exit at once otherwise
-  hipLaunchKernelGGL(k_octree_global, grid, block, 0, st, cand, candCount, P, selStage, nselLevel, scratch, lds ? 0 : 1);
+  // the LDS variant handles units it cannot take (more than 2048 candidates, node-table overflow) itself on global scratch
+  if (lds) hipLaunchKernelGGL((k_octree_lds<2048, 256>), grid, block, 0, st, cand, candCount, P, selStage, nselLevel, scratch);
+  else hipLaunchKernelGGL(k_octree_global, grid, block, 0, st, cand, candCount, P, selStage, nselLevel, scratch, 1);
   return hipGetLastError();
 }
 
