@@ -707,16 +707,27 @@ __global__ __launch_bounds__(MJ_CAP) void k_match_jacobi(const int* __restrict__
   // ---- candidate list of my query, built once: every train inside the window, with its Hamming distance ----
   int nCand = 0;
   if (hasWindow) {
-    for (int e = 0; e < nT; e++) {
-      const int cx = tCx[e], cy = tCy[e];
-      if (cx < minCX || cx > maxCX || cy < minCY || cy > maxCY) continue;
-      const float dx = tX[e] - qx, dy = tY[e] - qy;
-      if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
-      int dist = 0;
+    for (int e0 = 0; e0 < nT; e0 += 4) {  // four trains per step: 16 independent LDS broadcasts in flight
+      int cx[4], cy[4];
+      float tx[4], ty[4];
 #pragma unroll
-      for (int w = 0; w < 8; w++) dist += __popc(qd[w] ^ tDesc[w][e]);
-      if (nCand < MJ_CMAX) candList[nCand * MJ_CAP + t] = ((uint32_t)dist << 8) | (uint32_t)e;
-      nCand++;
+      for (int j = 0; j < 4; j++) {
+        const int ee = min(e0 + j, MJ_CAP - 1);
+        cx[j] = tCx[ee]; cy[j] = tCy[ee]; tx[j] = tX[ee]; ty[j] = tY[ee];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int e = e0 + j;
+        if (e >= nT) break;
+        if (cx[j] < minCX || cx[j] > maxCX || cy[j] < minCY || cy[j] > maxCY) continue;
+        const float dx = tx[j] - qx, dy = ty[j] - qy;
+        if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
+        int dist = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) dist += __popc(qd[w] ^ tDesc[w][e]);
+        if (nCand < MJ_CMAX) candList[nCand * MJ_CAP + t] = ((uint32_t)dist << 8) | (uint32_t)e;
+        nCand++;
+      }
     }
     if (nCand > MJ_CMAX) sOverflow = 1;
   }
@@ -734,22 +745,33 @@ __global__ __launch_bounds__(MJ_CAP) void k_match_jacobi(const int* __restrict__
     if (nCand > 0) {
       unsigned long long best = MATCH_NONE;  // dist << 32 | cell << 20 | train index
       int second = INF_DIST, bt = -1;
-      for (int k = 0; k < nCand; k++) {
-        const uint32_t ce = candList[k * MJ_CAP + t];
-        const int e = ce & 255, dist = (int)(ce >> 8);
-        // vMatchedDistance[e] as query t sees it: smallest distance of an earlier accepted query that chose e
-        int md = INF_DIST;
-        const int nc = min(clCount[e], MJ_K);
-        for (int c = 0; c < nc; c++)
-          if ((int)clQ[e][c] < t) md = min(md, (int)clD[e][c]);
-        if (md <= dist) continue;  // ORBmatcher.cpp:67
-        const unsigned long long key = ((unsigned long long)dist << 32) | tOrd[e];
-        if (key < best) {
-          second = min(second, (int)(best >> 32));
-          best = key;
-          bt = e;
-        } else {
-          second = min(second, dist);
+      // four candidates per step: their list entries, claim counts and order keys are independent LDS reads that
+      // are in flight together (this loop is bound by LDS round trips, one wave per SIMD)
+      for (int k = 0; k < nCand; k += 4) {
+        uint32_t ce[4], ord[4];
+        int cnt[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) ce[j] = candList[min(k + j, MJ_CMAX - 1) * MJ_CAP + t];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { cnt[j] = clCount[ce[j] & 255]; ord[j] = tOrd[ce[j] & 255]; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (k + j >= nCand) break;
+          const int e = ce[j] & 255, dist = (int)(ce[j] >> 8);
+          // vMatchedDistance[e] as query t sees it: smallest distance of an earlier accepted query that chose e
+          int md = INF_DIST;
+          const int nc = min(cnt[j], MJ_K);
+          for (int c = 0; c < nc; c++)
+            if ((int)clQ[e][c] < t) md = min(md, (int)clD[e][c]);
+          if (md <= dist) continue;  // ORBmatcher.cpp:67
+          const unsigned long long key = ((unsigned long long)dist << 32) | ord[j];
+          if (key < best) {
+            second = min(second, (int)(best >> 32));
+            best = key;
+            bt = e;
+          } else {
+            second = min(second, dist);
+          }
         }
       }
       const int bd = (int)(best >> 32);
