@@ -25,6 +25,8 @@ hipError_t launch_resize(hipStream_t st, int nFrames, const uint8_t* src, long l
                          const ResizeTab* ytab, int dwordPath);
 hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, int img0Aligned,
                        const uint8_t* pyr, const Geom& g, uint32_t* cand, int* candCount, int* overflow);
+hipError_t launch_pyramid_bands(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, uint8_t* pyr,
+                                const Geom& g, const ResizeTab* tab, const PyrBands& pb);
 hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const uint8_t* img0, long long img0FrameStride,
                                  int img0Aligned, const uint8_t* pyr, const Geom& g, const SelKp* sel, const int* nsel,
                                  orbx_keypoint* kps, uint8_t* desc, int capacity);
@@ -392,6 +394,34 @@ struct ExtractArgs {
   int capacity;
 };
 
+// Row bands of k_pyramid_bands.  Band b owns rows [b*h/K, (b+1)*h/K) of every level and, on top of that, every row of
+// level l-1 that its rows of level l read (cv::resize's y table: source rows ofs and ofs+1, clamped), from the last
+// level upwards.
+PyrBands computePyrBands(const orbx_ctx* ctx, int K) {
+  const Geom& g = ctx->g;
+  const int nl = g.nlevels;
+  PyrBands pb{};
+  pb.nBands = K = std::min(K, ORBX_PYR_BANDS_MAX);
+  for (int b = 0; b < K; b++) {
+    int need0 = 0, need1 = 0;  // rows of level l that the band's rows of level l + 1 read
+    for (int l = nl - 1; l >= 1; l--) {
+      const int h = g.L[l].h;
+      int r0 = (int)((long long)b * h / K), r1 = (int)((long long)(b + 1) * h / K);
+      if (l < nl - 1 && need1 > need0) { r0 = std::min(r0, need0); r1 = std::max(r1, need1); }
+      pb.r0[b][l] = (int16_t)r0;
+      pb.r1[b][l] = (int16_t)r1;
+      need0 = need1 = 0;
+      if (r1 > r0 && l >= 2) {
+        const ResizeTab* yt = ctx->hTab.data() + g.L[l].ytabOff;
+        const int sh = g.L[l - 1].h;
+        need0 = std::min(std::max(yt[r0].ofs, 0), sh - 1);
+        need1 = std::min(std::max(yt[r1 - 1].ofs + 1, 0), sh - 1) + 1;
+      }
+    }
+  }
+  return pb;
+}
+
 // issues every kernel of the extraction of frames [f0, f0 + n) on stream `st` (stream slot si); no synchronisation
 int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const ExtractArgs& a) {
   Geom g = ctx->g;
@@ -400,7 +430,16 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   oct.frame0 = f0;
   const int nl = g.nlevels;
   HIPCHK(hipMemsetAsync(ctx->dCandCount + (size_t)f0 * nl, 0, sizeof(int) * (size_t)n * nl, st));
-  {
+  // whole pyramid in one launch (k_pyramid_bands) when every level meets the dword path's preconditions and the batch
+  // is large enough to fill the device with (bands x frames) workgroups; otherwise one launch per level
+  bool banded = nl > 1 && a.aligned0 && n >= 32 && !getenv("ORBX_NO_BANDS");
+  for (int l = 1; l < nl && banded; l++) banded = g.L[l].resizeSpanOk && g.L[l].h < 32768;
+  if (banded) {
+    StageTimer tm(ctx, ORBX_STAGE_PYRAMID, si, st);
+    const PyrBands pb = computePyrBands(ctx, n >= 64 ? 8 : 16);
+    HIPCHK(launch_pyramid_bands(st, n, a.dImg0, a.frameStride0, ctx->dPyr, g, ctx->dTab, pb));
+    tm.stop(1);
+  } else {
     StageTimer tm(ctx, ORBX_STAGE_PYRAMID, si, st);
     for (int l = 1; l < nl; l++) {
       const LevelGeom& S = g.L[l - 1];

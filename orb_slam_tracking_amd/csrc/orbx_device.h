@@ -81,6 +81,13 @@ struct ResizeTab {
   int32_t coef;   // c0 | c1 << 16 (Q11)
 };
 
+// k_pyramid_bands: rows [r0, r1) of level l that band b of a frame produces (host: computePyrBands)
+#define ORBX_PYR_BANDS_MAX 16
+struct PyrBands {
+  int32_t nBands;
+  int16_t r0[ORBX_PYR_BANDS_MAX][ORBX_MAX_LEVELS], r1[ORBX_PYR_BANDS_MAX][ORBX_MAX_LEVELS];
+};
+
 // camera of cv::undistortPoints in the doubles OpenCV converts mK / mDistCoef (CV_32F, Settings.hpp:32,39) to
 struct CamD {
   double fx, fy, cx, cy, ifx, ify;  // ifx = 1./fx, ify = 1./fy

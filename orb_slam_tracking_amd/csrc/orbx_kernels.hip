@@ -100,6 +100,100 @@ __global__ __launch_bounds__(256) void k_resize_dw(const uint8_t* __restrict__ s
   *reinterpret_cast<uint32_t*>(dst + (long long)f * dstFrameStride + (long long)dy * dstride + dx0) = packed;
 }
 
+// The whole pyramid of a frame in ONE launch.  The chain level l <- level l-1 is kept (cpp:1660-1713), but instead of one
+// launch per level a workgroup owns a horizontal band of the frame: the band's rows of the last level need a slightly
+// larger band of the level before, and so on up to level 0 (PyrBands, computed on the host from the same y tables).  The
+// workgroup produces its bands level by level, re-reading what it wrote itself a moment ago (L2 hits) behind a fence +
+// barrier; bands of neighbouring workgroups overlap by a few rows and write identical bytes there.  No inter-workgroup
+// synchronisation, no launch gaps, and the small upper levels no longer pay a launch each.
+// Same arithmetic as k_resize_dw (needs its preconditions: 4-byte aligned rows, tap span <= 11 bytes).
+__global__ __launch_bounds__(256) void k_pyramid_bands(const uint8_t* __restrict__ img0, long long img0FrameStride,
+                                                       uint8_t* __restrict__ pyr, const Geom g,
+                                                       const ResizeTab* __restrict__ tab, const PyrBands pb) {
+  const int f = blockIdx.y + g.frame0, band = blockIdx.x, tid = threadIdx.x;
+  for (int l = 1; l < g.nlevels; l++) {
+    const LevelGeom& S = g.L[l - 1];
+    const LevelGeom& D = g.L[l];
+    const uint8_t* src = l == 1 ? img0 + (long long)f * img0FrameStride : pyr + S.imgOff + (long long)f * S.frameStride;
+    uint8_t* dst = pyr + D.imgOff + (long long)f * D.frameStride;
+    const ResizeTab* xtab = tab + D.xtabOff;
+    const ResizeTab* ytab = tab + D.ytabOff;
+    const int r0 = pb.r0[band][l], r1 = pb.r1[band][l];
+    const int sw = S.w, sh = S.h, sstride = S.stride, dstride = D.stride;
+    const int ng = (D.w + 3) >> 2;               // groups of 4 output pixels per row
+    const int items = (r1 - r0) * ng;
+    // Four items (row, group of 4 pixels) per thread and step, so that their table and source loads are in flight together
+    // (the loop is bound by memory latency, not by arithmetic).  item -> (row, group) without a division per item:
+    // item += 1024  <=>  (gx, dy) += (1024 % ng, 1024 / ng).
+    int dyv[4], gxv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int it0 = tid + 256 * j;
+      dyv[j] = it0 / ng;
+      gxv[j] = it0 - dyv[j] * ng;
+      dyv[j] += r0;
+    }
+    const int stepY = 1024 / ng, stepX = 1024 - stepY * ng;
+    const int lim = (sw - 1) & ~3;  // last dword that holds a pixel of the row: never read beyond it
+    for (int item = tid; item < items; item += 1024) {
+      ResizeTab ty[4];
+      uint4 tA[4], tB[4];
+      uint32_t ra[4][3], rb[4][3];
+      bool live[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        live[j] = item + 256 * j < items;
+        ty[j] = ytab[live[j] ? dyv[j] : r0];
+        const int dx0 = (live[j] ? gxv[j] : 0) * 4;
+        tA[j] = reinterpret_cast<const uint4*>(xtab + dx0)[0];
+        tB[j] = reinterpret_cast<const uint4*>(xtab + dx0)[1];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int sy0 = min(max(ty[j].ofs, 0), sh - 1), sy1 = min(max(ty[j].ofs + 1, 0), sh - 1);
+        const uint8_t* S0 = src + sy0 * sstride;
+        const uint8_t* S1 = src + sy1 * sstride;
+        const int base = (int)tA[j].x & ~3;
+        const int o0 = base, o1 = min(base + 4, lim), o2 = min(base + 8, lim);
+        ra[j][0] = *reinterpret_cast<const uint32_t*>(S0 + o0); ra[j][1] = *reinterpret_cast<const uint32_t*>(S0 + o1);
+        ra[j][2] = *reinterpret_cast<const uint32_t*>(S0 + o2);
+        rb[j][0] = *reinterpret_cast<const uint32_t*>(S1 + o0); rb[j][1] = *reinterpret_cast<const uint32_t*>(S1 + o1);
+        rb[j][2] = *reinterpret_cast<const uint32_t*>(S1 + o2);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int b0 = ty[j].coef & 0xffff, b1 = ty[j].coef >> 16;
+        const int sxs[4] = {(int)tA[j].x, (int)tA[j].z, (int)tB[j].x, (int)tB[j].z};
+        const uint32_t cfs[4] = {tA[j].y, tA[j].w, tB[j].y, tB[j].w};
+        const int base = sxs[0] & ~3;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int k = sxs[i] - base;  // 0..10
+          const int sh8 = k & 3;
+          const uint32_t lo0 = k < 4 ? ra[j][0] : (k < 8 ? ra[j][1] : ra[j][2]), hi0 = k < 4 ? ra[j][1] : ra[j][2];
+          const uint32_t lo1 = k < 4 ? rb[j][0] : (k < 8 ? rb[j][1] : rb[j][2]), hi1 = k < 4 ? rb[j][1] : rb[j][2];
+          const uint32_t w0 = __builtin_amdgcn_alignbyte(hi0, lo0, sh8), w1 = __builtin_amdgcn_alignbyte(hi1, lo1, sh8);
+          const int a0 = cfs[i] & 0xffff, a1 = cfs[i] >> 16;
+          const int t0 = (int)(w0 & 255) * a0 + (int)((w0 >> 8) & 255) * a1;
+          const int t1 = (int)(w1 & 255) * a0 + (int)((w1 >> 8) & 255) * a1;
+          int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+          v = min(max(v, 0), 255);
+          packed |= (uint32_t)v << (8 * i);
+        }
+        if (live[j]) *reinterpret_cast<uint32_t*>(dst + dyv[j] * dstride + gxv[j] * 4) = packed;
+        gxv[j] += stepX;
+        dyv[j] += stepY;
+        if (gxv[j] >= ng) { gxv[j] -= ng; dyv[j]++; }
+      }
+    }
+    // this band of level l is the source of the band of level l + 1 in the same workgroup: the barrier's workgroup-scope
+    // release/acquire is all that is needed (the CU's vector L1 is coherent for its own workgroup; an agent-scope
+    // fence would write back / invalidate L2 once per level and workgroup and was measured 7x slower)
+    __syncthreads();
+  }
+}
+
 // =================================================================================================
 // K2  FAST-9-16 per cell.  One workgroup (256 threads) per (cell, frame).
 //   strength(p) = max over the 16 arcs of 9 contiguous ring pixels of min(+-(v - p_k))
@@ -1333,6 +1427,14 @@ hipError_t launch_resize(hipStream_t st, int nFrames, const uint8_t* src, long l
   else
     hipLaunchKernelGGL(k_resize, grid, block, 0, st, src, srcFrameStride, sw, sh, sstride, dst, dstFrameStride, dw, dh, dstride,
                        xtab, ytab);
+  return hipGetLastError();
+}
+
+hipError_t launch_pyramid_bands(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, uint8_t* pyr,
+                                const Geom& g, const ResizeTab* tab, const PyrBands& pb) {
+  if (nFrames <= 0 || g.nlevels <= 1) return hipSuccess;
+  dim3 block(256, 1, 1), grid(pb.nBands, nFrames, 1);
+  hipLaunchKernelGGL(k_pyramid_bands, grid, block, 0, st, img0, img0FrameStride, pyr, g, tab, pb);
   return hipGetLastError();
 }
 

@@ -520,3 +520,37 @@ def test_to_gray_and_colour_chain(orbx, ext640, oracle):
         assert n[f] == len(ko)
         _same(kk[f, :n[f]], dd[f, :n[f]], ko, do)
     e.close()
+
+
+@pytest.mark.parametrize("nosplit", [False, True])
+def test_banded_pyramid_large_batch(orbx, oracle, nosplit, monkeypatch):
+    """Batches of >= 32 frames per stream build the pyramid with k_pyramid_bands (one launch, row bands with halos; 16
+    bands for 32..63 frames, 8 bands from 64 frames): pyramid levels and extraction results equal the oracle, for an
+    even-sized and an odd-height frame size."""
+    import torch
+    from orb_slam_tracking_amd import synth
+    if nosplit:
+        monkeypatch.setenv("ORBX_NO_SPLIT", "1")
+    else:
+        monkeypatch.delenv("ORBX_NO_SPLIT", raising=False)
+    cap = 1000
+    for (w, h, B) in ((640, 480, 72), (324, 243, 66)):
+        frames = synth.synth_frames(B, w, h, 5200)
+        oe = oracle.Extractor(*CANON)
+        e = orbx.ORBextractor(*CANON, max_width=w, max_height=h, max_batch=B)
+        d_img = torch.from_numpy(frames).cuda()
+        d_k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+        d_d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+        d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+        e.extract_batch_device(d_img, B, w, h, w, w * h, d_k, d_d, d_n, cap)
+        n = d_n.cpu().numpy()
+        kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, cap)
+        dd = d_d.cpu().numpy().reshape(B, cap, 32)
+        for f in list(range(0, B, 5)) + [B // 2 - 1, B // 2, B - 1]:
+            _, ko, do = oe(frames[f])
+            assert n[f] == len(ko)
+            _same(kk[f, :n[f]], dd[f, :n[f]], ko, do)
+            if f in (0, B // 2, B - 1):
+                for l in range(1, 8):
+                    assert np.array_equal(e.image_pyramid(l, f), oe.level_image(l)), (w, h, f, l)
+        e.close()
