@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_pyramid_bands(const uint8_t* __restrict
     const LevelGeom& D = g.L[l];
     const uint8_t* src = l == 1 ? img0 + (long long)f * img0FrameStride : pyr + S.imgOff + (long long)f * S.frameStride;
     uint8_t* dst = pyr + D.imgOff + (long long)f * D.frameStride;
-    const ResizeTab* xtab = tab + D.xtabOff;
+    const uint8_t* xtabB = reinterpret_cast<const uint8_t*>(tab + D.xtabOff);
     const ResizeTab* ytab = tab + D.ytabOff;
     const int r0 = pb.r0[band][l], r1 = pb.r1[band][l];
     const int sw = S.w, sh = S.h, sstride = S.stride, dstride = D.stride;
@@ -143,22 +143,22 @@ __global__ __launch_bounds__(256) void k_pyramid_bands(const uint8_t* __restrict
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         live[j] = item + 256 * j < items;
-        ty[j] = ytab[live[j] ? dyv[j] : r0];
-        const int dx0 = (live[j] ? gxv[j] : 0) * 4;
-        tA[j] = reinterpret_cast<const uint4*>(xtab + dx0)[0];
-        tB[j] = reinterpret_cast<const uint4*>(xtab + dx0)[1];
+        // unsigned 32-bit offsets from uniform base pointers: SGPR base + VGPR offset addressing, no 64-bit address math
+        ty[j] = ytab[(unsigned)(live[j] ? dyv[j] : r0)];
+        const unsigned dx0 = (unsigned)(live[j] ? gxv[j] : 0) * 4u;
+        tA[j] = *reinterpret_cast<const uint4*>(xtabB + dx0 * 8u);
+        tB[j] = *reinterpret_cast<const uint4*>(xtabB + dx0 * 8u + 16u);
       }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int sy0 = min(max(ty[j].ofs, 0), sh - 1), sy1 = min(max(ty[j].ofs + 1, 0), sh - 1);
-        const uint8_t* S0 = src + sy0 * sstride;
-        const uint8_t* S1 = src + sy1 * sstride;
+        const unsigned S0 = (unsigned)(sy0 * sstride), S1 = (unsigned)(sy1 * sstride);
         const int base = (int)tA[j].x & ~3;
-        const int o0 = base, o1 = min(base + 4, lim), o2 = min(base + 8, lim);
-        ra[j][0] = *reinterpret_cast<const uint32_t*>(S0 + o0); ra[j][1] = *reinterpret_cast<const uint32_t*>(S0 + o1);
-        ra[j][2] = *reinterpret_cast<const uint32_t*>(S0 + o2);
-        rb[j][0] = *reinterpret_cast<const uint32_t*>(S1 + o0); rb[j][1] = *reinterpret_cast<const uint32_t*>(S1 + o1);
-        rb[j][2] = *reinterpret_cast<const uint32_t*>(S1 + o2);
+        const unsigned o0 = (unsigned)base, o1 = (unsigned)min(base + 4, lim), o2 = (unsigned)min(base + 8, lim);
+        ra[j][0] = *reinterpret_cast<const uint32_t*>(src + (S0 + o0)); ra[j][1] = *reinterpret_cast<const uint32_t*>(src + (S0 + o1));
+        ra[j][2] = *reinterpret_cast<const uint32_t*>(src + (S0 + o2));
+        rb[j][0] = *reinterpret_cast<const uint32_t*>(src + (S1 + o0)); rb[j][1] = *reinterpret_cast<const uint32_t*>(src + (S1 + o1));
+        rb[j][2] = *reinterpret_cast<const uint32_t*>(src + (S1 + o2));
       }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_pyramid_bands(const uint8_t* __restrict
           v = min(max(v, 0), 255);
           packed |= (uint32_t)v << (8 * i);
         }
-        if (live[j]) *reinterpret_cast<uint32_t*>(dst + dyv[j] * dstride + gxv[j] * 4) = packed;
+        if (live[j]) *reinterpret_cast<uint32_t*>(dst + (unsigned)(dyv[j] * dstride + gxv[j] * 4)) = packed;
         gxv[j] += stepX;
         dyv[j] += stepY;
         if (gxv[j] >= ng) { gxv[j] -= ng; dyv[j]++; }
