@@ -172,6 +172,21 @@ int orbx_to_gray_batch_device(orbx_ctx* ctx, int n_frames, const uint8_t* d_src,
                               size_t frame_stride_bytes, int channels, int rgb, uint8_t* d_gray, int gray_stride,
                               size_t gray_frame_stride_bytes);
 
+/* ---- behind the matcher: the Initializer's model scoring (Initialization/Initializer.cpp:268-438) -- */
+/* CheckHomography / CheckFundamental for `n_models` RANSAC hypotheses at once (the loops of FindHomography :180-211 and
+ * FindFundamental :231-265 call them once per iteration).  H21 / H12 / F21: n_models row-major 3x3 matrices (Eigen's
+ * (row, col)); k1 / k2 = mvKeys1 / mvKeys2 (the frames' mvKeysUn); matches12 = the matcher's vnMatches12 (n1 entries),
+ * from which mvMatches12 is built as in Initializer::Initialize :24-33 (pairs (i, matches12[i]) with matches12[i] >= 0, in
+ * order).  scores[m] = the returned score, inliers[m * N + i] = vbMatchesInliers[i] for the N = *n_matches_out pairs (the
+ * caller provides n_models * n1 bytes).  best (nullable) = the hypothesis the RANSAC loop would keep: first maximum of the
+ * scores, -1 if none is > 0.  Host pointers. */
+int orbx_check_homography(orbx_ctx* ctx, int n_models, const float* H21, const float* H12, const orbx_keypoint* k1, int n1,
+                          const orbx_keypoint* k2, int n2, const int32_t* matches12, float sigma, float* scores,
+                          uint8_t* inliers, int* n_matches_out, int* best);
+int orbx_check_fundamental(orbx_ctx* ctx, int n_models, const float* F21, const orbx_keypoint* k1, int n1,
+                           const orbx_keypoint* k2, int n2, const int32_t* matches12, float sigma, float* scores,
+                           uint8_t* inliers, int* n_matches_out, int* best);
+
 /* ---- measurement hooks (bench.py; HIP events on the ctx stream) ---------------------------- */
 #define ORBX_STAGE_PYRAMID 0
 #define ORBX_STAGE_FAST 1

@@ -174,6 +174,35 @@ class ORBextractor {
     return true;
   }
 
+  // Drop-ins for the RANSAC scoring of Initializer::FindHomography / FindFundamental (Initialization/Initializer.cpp:180-211,
+  // 231-265): all hypotheses of the loop are scored in one call.  H21s / H12s / F21s hold nModels row-major 3x3 matrices,
+  // vnMatches12 is the matcher's output the Initializer builds mvMatches12 from (:24-33).  Returns the index the loop would
+  // keep (-1 = none), scores[m], and vbMatchesInliers of every model (inliers[m * N + i]).
+  int CheckHomography(int nModels, const float* H21s, const float* H12s, const std::vector<KeyPointT>& mvKeys1,
+                      const std::vector<KeyPointT>& mvKeys2, const std::vector<int>& vnMatches12, float sigma,
+                      std::vector<float>& scores, std::vector<uint8_t>& inliers, int& N) {
+    scores.assign((size_t)nModels, 0.f);
+    inliers.assign((size_t)nModels * mvKeys1.size() + 1, 0);
+    int best = -1;
+    const int r = orbx_check_homography(ctx_, nModels, H21s, H12s, reinterpret_cast<const orbx_keypoint*>(mvKeys1.data()),
+                                        (int)mvKeys1.size(), reinterpret_cast<const orbx_keypoint*>(mvKeys2.data()),
+                                        (int)mvKeys2.size(), vnMatches12.data(), sigma, scores.data(), inliers.data(), &N, &best);
+    if (r != ORBX_OK) throw orbx::Error(r, orbx_last_error(ctx_));
+    return best;
+  }
+  int CheckFundamental(int nModels, const float* F21s, const std::vector<KeyPointT>& mvKeys1,
+                       const std::vector<KeyPointT>& mvKeys2, const std::vector<int>& vnMatches12, float sigma,
+                       std::vector<float>& scores, std::vector<uint8_t>& inliers, int& N) {
+    scores.assign((size_t)nModels, 0.f);
+    inliers.assign((size_t)nModels * mvKeys1.size() + 1, 0);
+    int best = -1;
+    const int r = orbx_check_fundamental(ctx_, nModels, F21s, reinterpret_cast<const orbx_keypoint*>(mvKeys1.data()),
+                                         (int)mvKeys1.size(), reinterpret_cast<const orbx_keypoint*>(mvKeys2.data()),
+                                         (int)mvKeys2.size(), vnMatches12.data(), sigma, scores.data(), inliers.data(), &N, &best);
+    if (r != ORBX_OK) throw orbx::Error(r, orbx_last_error(ctx_));
+    return best;
+  }
+
   void UndistortKeyPoints(const std::vector<KeyPointT>& mvKeys, const orbx_camera& cam, std::vector<KeyPointT>& mvKeysUn) {
     mvKeysUn.resize(mvKeys.size());
     const int r = orbx_undistort_keypoints(ctx_, reinterpret_cast<const orbx_keypoint*>(mvKeys.data()), (int)mvKeys.size(), &cam,

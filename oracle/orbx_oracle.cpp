@@ -870,6 +870,73 @@ int orbo_to_gray(const uint8_t* src, int w, int h, int stride, int channels, int
   return 1;
 }
 
+// the Initializer's scoring loops (Initialization/Initializer.cpp:268-438), restated operation by
+// operation: f32 arithmetic evaluated left to right without contraction, the reciprocals `1.0 / x` in double and rounded
+// to float, the score a sequential f32 sum in match order.  H / F are row-major 3x3 (Eigen's (row, col) accessor).
+// Returns the score; inliers[i] = vbMatchesInliers[i].
+float orbo_check_homography(const float* H21, const float* H12, const KP* k1, const KP* k2, const int* first, const int* second,
+                            int N, float sigma, uint8_t* inliers) {
+  const float h11 = H21[0], h12 = H21[1], h13 = H21[2], h21 = H21[3], h22 = H21[4], h23 = H21[5], h31 = H21[6], h32 = H21[7],
+              h33 = H21[8];
+  const float h11inv = H12[0], h12inv = H12[1], h13inv = H12[2], h21inv = H12[3], h22inv = H12[4], h23inv = H12[5],
+              h31inv = H12[6], h32inv = H12[7], h33inv = H12[8];
+  float score = 0;
+  const float th = 5.991;
+  const float invSigmaSquare = 1.0 / (sigma * sigma);
+  for (int i = 0; i < N; i++) {
+    bool bIn = true;
+    const float u1 = k1[first[i]].x, v1 = k1[first[i]].y, u2 = k2[second[i]].x, v2 = k2[second[i]].y;
+    const float w2in1inv = 1.0 / (h31inv * u2 + h32inv * v2 + h33inv);
+    const float u2in1 = (h11inv * u2 + h12inv * v2 + h13inv) * w2in1inv;
+    const float v2in1 = (h21inv * u2 + h22inv * v2 + h23inv) * w2in1inv;
+    const float squareDist1 = (u1 - u2in1) * (u1 - u2in1) + (v1 - v2in1) * (v1 - v2in1);
+    const float chiSquare1 = squareDist1 * invSigmaSquare;
+    if (chiSquare1 > th) bIn = false;
+    else score += th - chiSquare1;
+    const float w1in2inv = 1.0 / (h31 * u1 + h32 * v1 + h33);
+    const float u1in2 = (h11 * u1 + h12 * v1 + h13) * w1in2inv;
+    const float v1in2 = (h21 * u1 + h22 * v1 + h23) * w1in2inv;
+    const float squareDist2 = (u2 - u1in2) * (u2 - u1in2) + (v2 - v1in2) * (v2 - v1in2);
+    const float chiSquare2 = squareDist2 * invSigmaSquare;
+    if (chiSquare2 > th) bIn = false;
+    else score += th - chiSquare2;
+    inliers[i] = bIn ? 1 : 0;
+  }
+  return score;
+}
+
+float orbo_check_fundamental(const float* F21, const KP* k1, const KP* k2, const int* first, const int* second, int N, float sigma,
+                             uint8_t* inliers) {
+  const float f11 = F21[0], f12 = F21[1], f13 = F21[2], f21 = F21[3], f22 = F21[4], f23 = F21[5], f31 = F21[6], f32 = F21[7],
+              f33 = F21[8];
+  float score = 0;
+  const float th = 3.841;
+  const float thScore = 5.991;
+  const float invSigmaSquare = 1.0 / (sigma * sigma);
+  for (int i = 0; i < N; i++) {
+    bool bIn = true;
+    const float u1 = k1[first[i]].x, v1 = k1[first[i]].y, u2 = k2[second[i]].x, v2 = k2[second[i]].y;
+    const float a2 = f11 * u1 + f12 * v1 + f13;
+    const float b2 = f21 * u1 + f22 * v1 + f23;
+    const float c2 = f31 * u1 + f32 * v1 + f33;
+    const float num2 = a2 * u2 + b2 * v2 + c2;
+    const float squareDist1 = num2 * num2 / (a2 * a2 + b2 * b2);
+    const float chiSquare1 = squareDist1 * invSigmaSquare;
+    if (chiSquare1 > th) bIn = false;
+    else score += thScore - chiSquare1;
+    const float a1 = f11 * u2 + f21 * v2 + f31;
+    const float b1 = f12 * u2 + f22 * v2 + f32;
+    const float c1 = f13 * u2 + f23 * v2 + f33;
+    const float num1 = a1 * u1 + b1 * v1 + c1;
+    const float squareDist2 = num1 * num1 / (a1 * a1 + b1 * b1);
+    const float chiSquare2 = squareDist2 * invSigmaSquare;
+    if (chiSquare2 > th) bIn = false;
+    else score += thScore - chiSquare2;
+    inliers[i] = bIn ? 1 : 0;
+  }
+  return score;
+}
+
 // the std::sort call of cpp:912 in isolation: (count, UL.x, id) triples ordered with compareNodes (cpp:684-696)
 void orbo_std_sort_sized(int* triples, int n) {
   struct T3 { int c, u, id; };

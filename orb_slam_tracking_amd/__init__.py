@@ -98,6 +98,8 @@ def lib() -> ctypes.CDLL:
     L.orbx_image_bounds.argtypes = [vp, ctypes.POINTER(_Camera), i32, i32, ctypes.POINTER(_Bounds)]
     L.orbx_to_gray.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, i32]
     L.orbx_to_gray_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, sz, i32, i32, vp, i32, sz]
+    L.orbx_check_homography.argtypes = [vp, i32, vp, vp, vp, i32, vp, i32, vp, f32, vp, vp, vp, vp]
+    L.orbx_check_fundamental.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, f32, vp, vp, vp, vp]
     L.orbx_profile_enable.argtypes = [vp, i32]
     L.orbx_profile_reset.argtypes = [vp]
     L.orbx_profile_get.argtypes = [vp, vp, vp]
@@ -305,6 +307,38 @@ class ORBextractor:
         self._check(self._L.orbx_image_bounds(self._h, ctypes.byref(cam), int(width), int(height), ctypes.byref(b)),
                     "orbx_image_bounds")
         return (b.min_x, b.max_x, b.min_y, b.max_y)
+
+    # -- Initializer::CheckHomography / CheckFundamental (Initialization/Initializer.cpp:268-438) ------
+    def _check_models(self, kind: int, M21, M12, keys1, keys2, matches12, sigma: float):
+        M21 = np.ascontiguousarray(M21, np.float32).reshape(-1, 3, 3)
+        k1 = np.ascontiguousarray(keys1, KEYPOINT_DTYPE)
+        k2 = np.ascontiguousarray(keys2, KEYPOINT_DTYPE)
+        m12 = np.ascontiguousarray(matches12, np.int32)
+        if len(m12) != len(k1):
+            raise OrbxError(E_BADARG, "matches12 must have one entry per keypoint of frame 1")
+        nm = len(M21)
+        scores = np.zeros(nm, np.float32)
+        inl = np.zeros(max(nm * len(k1), 1), np.uint8)
+        n, best = ctypes.c_int(0), ctypes.c_int(-1)
+        if kind == 0:
+            M12 = np.ascontiguousarray(M12, np.float32).reshape(-1, 3, 3)
+            if len(M12) != nm:
+                raise OrbxError(E_BADARG, "H21 and H12 must hold the same number of models")
+            r = self._L.orbx_check_homography(self._h, nm, _ptr(M21), _ptr(M12), _ptr(k1), len(k1), _ptr(k2), len(k2), _ptr(m12),
+                                              float(sigma), _ptr(scores), _ptr(inl), ctypes.byref(n), ctypes.byref(best))
+        else:
+            r = self._L.orbx_check_fundamental(self._h, nm, _ptr(M21), _ptr(k1), len(k1), _ptr(k2), len(k2), _ptr(m12),
+                                               float(sigma), _ptr(scores), _ptr(inl), ctypes.byref(n), ctypes.byref(best))
+        self._check(r, "orbx_check_homography" if kind == 0 else "orbx_check_fundamental")
+        return scores, inl[:nm * n.value].reshape(nm, n.value).astype(bool), best.value
+
+    def check_homography(self, H21, H12, keys1, keys2, matches12, sigma: float = 1.0):
+        """CheckHomography for a stack of hypotheses -> (scores, vbMatchesInliers per model, index the RANSAC loop keeps)."""
+        return self._check_models(0, H21, H12, keys1, keys2, matches12, sigma)
+
+    def check_fundamental(self, F21, keys1, keys2, matches12, sigma: float = 1.0):
+        """CheckFundamental for a stack of hypotheses -> (scores, vbMatchesInliers per model, index the RANSAC loop keeps)."""
+        return self._check_models(1, F21, None, keys1, keys2, matches12, sigma)
 
     # -- mvImagePyramid (hpp:111) ----------------------------------------------------------------
     def level_size(self, level: int) -> Tuple[int, int]:

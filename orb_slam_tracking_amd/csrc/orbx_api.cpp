@@ -40,6 +40,7 @@ hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage
 size_t octScratchBytes(int nMax, int qMax);
 hipError_t launch_to_gray(hipStream_t st, int nFrames, const uint8_t* src, long long srcFrameStride, int sstride, int w, int h,
                           int channels, int rgb, uint8_t* dst, long long dstFrameStride, int dstride);
+hipError_t launch_check_model(hipStream_t st, int nModels, const ScoreArgs& a);
 hipError_t launch_undistort(hipStream_t st, int nFrames, const orbx_keypoint* in, const int* nkp, int capacity, const CamD& c,
                             orbx_keypoint* out);
 
@@ -104,6 +105,8 @@ struct orbx_ctx {
   uint8_t* dMd = nullptr;
   int* dMi = nullptr;  // n[2] + matches12[cap] + nmatches + stats[3]
   size_t mCap = 0;
+  uint8_t* dScore = nullptr;  // staging of orbx_check_homography / _fundamental
+  size_t scoreBytes = 0;
   uint8_t* dColor = nullptr;  // staging of orbx_to_gray (host API): colour frame followed by its gray image
   size_t colorBytes = 0;
 
@@ -658,7 +661,7 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (ctx->st) (void)hipStreamSynchronize(ctx->st);
   void* dev[] = {ctx->dPyr, ctx->dCand, ctx->dCandCount, ctx->dTab, ctx->dSel, ctx->dNsel, ctx->dSelStage, ctx->dNselLevel,
                  ctx->dOctScratch, ctx->dIn, ctx->dKps, ctx->dDesc, ctx->dMatchScratch, ctx->dPairs, ctx->dMk, ctx->dMd,
-                 ctx->dMi, ctx->dColor};
+                 ctx->dMi, ctx->dColor, ctx->dScore};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   void* host[] = {ctx->hNsel, ctx->hFlags};
@@ -983,6 +986,87 @@ int orbx_image_bounds(orbx_ctx* ctx, const orbx_camera* cam, int width, int heig
   out->min_y = (int)std::min(u4[0].y, u4[1].y);
   out->max_y = (int)std::max(u4[2].y, u4[3].y);
   return ORBX_OK;
+}
+
+// ---- Initializer scoring loops (Initialization/Initializer.cpp:268-438) ---------------------------
+namespace {
+int checkModels(orbx_ctx* ctx, int kind, int n_models, const float* M21, const float* M12, const orbx_keypoint* k1, int n1,
+                const orbx_keypoint* k2, int n2, const int32_t* matches12, float sigma, float* scores, uint8_t* inliers,
+                int* n_matches_out, int* best) {
+  if (!ctx || n_models < 0 || n1 < 0 || n2 < 0 || !n_matches_out || (n_models > 0 && (!M21 || (kind == 0 && !M12) || !scores)) ||
+      (n1 > 0 && (!k1 || !matches12)) || (n2 > 0 && !k2))
+    return ORBX_E_BADARG;
+  // mvMatches12, Initializer.cpp:24-33
+  std::vector<int32_t> fs;
+  fs.reserve(2 * (size_t)n1);
+  for (int i = 0; i < n1; i++)
+    if (matches12[i] >= 0) {
+      if (matches12[i] >= n2) return ORBX_E_BADARG;
+      fs.push_back(i);
+    }
+  const int N = (int)fs.size();
+  for (int i = 0; i < N; i++) fs.push_back(matches12[fs[i]]);
+  *n_matches_out = N;
+  if (best) *best = -1;
+  if (n_models == 0) return ORBX_OK;
+  if (N > 0 && !inliers) return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  // one staging allocation: models | keypoints | pairs | scores | inliers
+  const size_t bM = (size_t)n_models * 9 * sizeof(float), bK1 = (size_t)n1 * sizeof(orbx_keypoint),
+               bK2 = (size_t)n2 * sizeof(orbx_keypoint), bP = (size_t)N * sizeof(int32_t), bS = (size_t)n_models * sizeof(float),
+               bI = (size_t)n_models * N;
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t need = 2 * al(bM) + al(bK1) + al(bK2) + 2 * al(bP) + al(bS) + al(bI) + 256;
+  if (need > ctx->scoreBytes) {
+    if (ctx->dScore) (void)hipFree(ctx->dScore);
+    ctx->dScore = nullptr; ctx->scoreBytes = 0;
+    HIPCHK(hipMalloc((void**)&ctx->dScore, need));
+    ctx->scoreBytes = need;
+  }
+  uint8_t* p = ctx->dScore;
+  ScoreArgs a{};
+  hipStream_t st = ctx->st;
+  a.M21 = (const float*)p; p += al(bM);
+  a.M12 = (const float*)p; p += al(bM);
+  a.k1 = (const orbx_keypoint*)p; p += al(bK1);
+  a.k2 = (const orbx_keypoint*)p; p += al(bK2);
+  a.first = (const int32_t*)p; p += al(bP);
+  a.second = (const int32_t*)p; p += al(bP);
+  a.scores = (float*)p; p += al(bS);
+  a.inliers = p;
+  a.N = N; a.kind = kind;
+  a.invSigmaSquare = (float)(1.0 / (double)(sigma * sigma));  // `const float invSigmaSquare = 1.0 / (sigma * sigma)`
+  HIPCHK(hipMemcpyAsync((void*)a.M21, M21, bM, hipMemcpyHostToDevice, st));
+  if (kind == 0) HIPCHK(hipMemcpyAsync((void*)a.M12, M12, bM, hipMemcpyHostToDevice, st));
+  if (n1) HIPCHK(hipMemcpyAsync((void*)a.k1, k1, bK1, hipMemcpyHostToDevice, st));
+  if (n2) HIPCHK(hipMemcpyAsync((void*)a.k2, k2, bK2, hipMemcpyHostToDevice, st));
+  if (N) {
+    HIPCHK(hipMemcpyAsync((void*)a.first, fs.data(), bP, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync((void*)a.second, fs.data() + N, bP, hipMemcpyHostToDevice, st));
+  }
+  HIPCHK(launch_check_model(st, n_models, a));
+  HIPCHK(hipMemcpyAsync(scores, a.scores, bS, hipMemcpyDeviceToHost, st));
+  if (N) HIPCHK(hipMemcpyAsync(inliers, a.inliers, bI, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (best) {  // `if (currentScore > score)` with score starting at 0, Initializer.cpp:205-209 / 259-263
+    float sc = 0;
+    for (int m = 0; m < n_models; m++)
+      if (scores[m] > sc) { sc = scores[m]; *best = m; }
+  }
+  return ORBX_OK;
+}
+}  // namespace
+
+int orbx_check_homography(orbx_ctx* ctx, int n_models, const float* H21, const float* H12, const orbx_keypoint* k1, int n1,
+                          const orbx_keypoint* k2, int n2, const int32_t* matches12, float sigma, float* scores, uint8_t* inliers,
+                          int* n_matches_out, int* best) {
+  return checkModels(ctx, 0, n_models, H21, H12, k1, n1, k2, n2, matches12, sigma, scores, inliers, n_matches_out, best);
+}
+
+int orbx_check_fundamental(orbx_ctx* ctx, int n_models, const float* F21, const orbx_keypoint* k1, int n1, const orbx_keypoint* k2,
+                           int n2, const int32_t* matches12, float sigma, float* scores, uint8_t* inliers, int* n_matches_out,
+                           int* best) {
+  return checkModels(ctx, 1, n_models, F21, nullptr, k1, n1, k2, n2, matches12, sigma, scores, inliers, n_matches_out, best);
 }
 
 // ---- Converter::toGray (Utils/Converter.cpp:5-19) ------------------------------------------------

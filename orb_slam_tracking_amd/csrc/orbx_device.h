@@ -2,6 +2,8 @@
 #pragma once
 #include <cstdint>
 
+#include "../../include/orbx.h"
+
 #define ORBX_MAX_LEVELS 16
 #define ORBX_EDGE 19          // EDGE_THRESHOLD, Features/ORBextractor.cpp:90
 #define ORBX_MIN_BORDER 16    // EDGE_THRESHOLD - 3, cpp:1056
@@ -86,6 +88,20 @@ struct ResizeTab {
 struct PyrBands {
   int32_t nBands;
   int16_t r0[ORBX_PYR_BANDS_MAX][ORBX_MAX_LEVELS], r1[ORBX_PYR_BANDS_MAX][ORBX_MAX_LEVELS];
+};
+
+// k_check_model: CheckHomography (kind 0) / CheckFundamental (kind 1) over nModels hypotheses
+struct ScoreArgs {
+  const float* M21;   // [nModels][9] row-major H21 / F21
+  const float* M12;   // [nModels][9] H12 (kind 0 only)
+  const orbx_keypoint* k1;
+  const orbx_keypoint* k2;
+  const int32_t* first;   // mvMatches12[i].first / .second
+  const int32_t* second;
+  int32_t N, kind;
+  float invSigmaSquare;
+  float* scores;      // [nModels]
+  uint8_t* inliers;   // [nModels][N]
 };
 
 // camera of cv::undistortPoints in the doubles OpenCV converts mK / mDistCoef (CV_32F, Settings.hpp:32,39) to

@@ -1349,6 +1349,78 @@ __global__ __launch_bounds__(256) void k_undistort(const orbx_keypoint* __restri
 }
 
 // =================================================================================================
+// Model scoring of the Initializer: CheckHomography / CheckFundamental (Initialization/Initializer.cpp:268-438), one wave
+// per RANSAC hypothesis.  The per-match terms are independent (lanes); the score is a sequential f32 sum in match
+// order, so lane 0 adds the 128 terms of each step of 64 matches one after the other (a skipped term is an exact + 0.0f).
+// f32 arithmetic as written upstream, uncontracted; `1.0 / x` in double, rounded to float; f32 division correctly
+// rounded (build flags).
+// =================================================================================================
+__global__ __launch_bounds__(64) void k_check_model(const ScoreArgs a) {
+  __shared__ __attribute__((aligned(16))) float add[128];
+  const int hyp = blockIdx.x, lane = threadIdx.x;
+  float m[9], mi[9];
+#pragma unroll
+  for (int q = 0; q < 9; q++) {
+    m[q] = a.M21[hyp * 9 + q];
+    mi[q] = a.kind == 0 ? a.M12[hyp * 9 + q] : 0.f;
+  }
+  const float th = a.kind == 0 ? 5.991f : 3.841f, thScore = 5.991f;
+  const float invSigmaSquare = a.invSigmaSquare;
+  float score = 0;
+  for (int i0 = 0; i0 < a.N; i0 += 64) {
+    const int i = i0 + lane;
+    float c1 = 0.f, c2 = 0.f;
+    if (i < a.N) {
+      bool bIn = true;
+      const orbx_keypoint kp1 = a.k1[a.first[i]], kp2 = a.k2[a.second[i]];
+      const float u1 = kp1.x, v1 = kp1.y, u2 = kp2.x, v2 = kp2.y;
+      float chiSquare1, chiSquare2;
+      if (a.kind == 0) {  // CheckHomography :300-343
+        const float w2in1inv = (float)(1.0 / (double)(mi[6] * u2 + mi[7] * v2 + mi[8]));
+        const float u2in1 = (mi[0] * u2 + mi[1] * v2 + mi[2]) * w2in1inv;
+        const float v2in1 = (mi[3] * u2 + mi[4] * v2 + mi[5]) * w2in1inv;
+        const float squareDist1 = (u1 - u2in1) * (u1 - u2in1) + (v1 - v2in1) * (v1 - v2in1);
+        chiSquare1 = squareDist1 * invSigmaSquare;
+        const float w1in2inv = (float)(1.0 / (double)(m[6] * u1 + m[7] * v1 + m[8]));
+        const float u1in2 = (m[0] * u1 + m[1] * v1 + m[2]) * w1in2inv;
+        const float v1in2 = (m[3] * u1 + m[4] * v1 + m[5]) * w1in2inv;
+        const float squareDist2 = (u2 - u1in2) * (u2 - u1in2) + (v2 - v1in2) * (v2 - v1in2);
+        chiSquare2 = squareDist2 * invSigmaSquare;
+      } else {            // CheckFundamental :385-428
+        const float a2 = m[0] * u1 + m[1] * v1 + m[2];
+        const float b2 = m[3] * u1 + m[4] * v1 + m[5];
+        const float c2f = m[6] * u1 + m[7] * v1 + m[8];
+        const float num2 = a2 * u2 + b2 * v2 + c2f;
+        const float squareDist1 = num2 * num2 / (a2 * a2 + b2 * b2);
+        chiSquare1 = squareDist1 * invSigmaSquare;
+        const float a1 = m[0] * u2 + m[3] * v2 + m[6];
+        const float b1 = m[1] * u2 + m[4] * v2 + m[7];
+        const float c1f = m[2] * u2 + m[5] * v2 + m[8];
+        const float num1 = a1 * u1 + b1 * v1 + c1f;
+        const float squareDist2 = num1 * num1 / (a1 * a1 + b1 * b1);
+        chiSquare2 = squareDist2 * invSigmaSquare;
+      }
+      if (chiSquare1 > th) bIn = false;
+      else c1 = thScore - chiSquare1;
+      if (chiSquare2 > th) bIn = false;
+      else c2 = thScore - chiSquare2;
+      a.inliers[(size_t)hyp * a.N + i] = bIn ? 1 : 0;
+    }
+    add[2 * lane] = c1;
+    add[2 * lane + 1] = c2;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+#pragma unroll 8
+      for (int q = 0; q < 128; q++) score += add[q];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) a.scores[hyp] = score;
+}
+
+// =================================================================================================
 // Colour -> gray: Converter::toGray (Utils/Converter.cpp:5-19) = cv::cvtColor(COLOR_RGB2GRAY / COLOR_BGR2GRAY) on 8-bit,
 // Y = (c0*ch0 + c1*ch1 + c2*ch2 + 8192) >> 14 with (c0, c1, c2) = (4899, 9617, 1868) for RGB order and reversed for BGR.
 // Thread = 4 output pixels: 12 source bytes as 3 aligned dwords -> one dword store (byte paths when unaligned / at the
@@ -1406,6 +1478,12 @@ hipError_t launch_to_gray(hipStream_t st, int nFrames, const uint8_t* src, long 
   dim3 block(256, 1, 1), grid((w + 1023) / 1024, h, nFrames);
   hipLaunchKernelGGL(k_to_gray, grid, block, 0, st, src, srcFrameStride, sstride, w, h, rgb ? 4899 : 1868, 9617, rgb ? 1868 : 4899,
                      srcAligned, dst, dstFrameStride, dstride, dstAligned);
+  return hipGetLastError();
+}
+
+hipError_t launch_check_model(hipStream_t st, int nModels, const ScoreArgs& a) {
+  if (nModels <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_check_model, dim3(nModels), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 

@@ -296,3 +296,67 @@ def to_gray(image: np.ndarray, rgb: bool = False):
     L.orbo_to_gray.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int]
     ok = L.orbo_to_gray(_p(im), w, h, w * ch, ch, int(rgb), _p(out), w)
     return out if ok else None
+
+
+def _pairs(matches12):
+    m = np.ascontiguousarray(matches12, np.int32)
+    first = np.nonzero(m >= 0)[0].astype(np.int32)  # mvMatches12, Initializer.cpp:24-33
+    return first, m[first].copy()
+
+
+def check_homography(H21, H12, k1, k2, matches12, sigma=1.0):
+    """Oracle of Initializer::CheckHomography (Initializer.cpp:268-352) -> (score, inliers)."""
+    k1, k2 = np.ascontiguousarray(k1, KP), np.ascontiguousarray(k2, KP)
+    first, second = _pairs(matches12)
+    H21 = np.ascontiguousarray(H21, np.float32).reshape(9)
+    H12 = np.ascontiguousarray(H12, np.float32).reshape(9)
+    inl = np.zeros(max(len(first), 1), np.uint8)
+    L = lib()
+    L.orbo_check_homography.restype = ctypes.c_float
+    L.orbo_check_homography.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+    sc = L.orbo_check_homography(_p(H21), _p(H12), _p(k1), _p(k2), _p(first), _p(second), len(first), sigma, _p(inl))
+    return np.float32(sc), inl[:len(first)].astype(bool)
+
+
+def check_fundamental(F21, k1, k2, matches12, sigma=1.0):
+    """Oracle of Initializer::CheckFundamental (Initializer.cpp:355-438) -> (score, inliers)."""
+    k1, k2 = np.ascontiguousarray(k1, KP), np.ascontiguousarray(k2, KP)
+    first, second = _pairs(matches12)
+    F21 = np.ascontiguousarray(F21, np.float32).reshape(9)
+    inl = np.zeros(max(len(first), 1), np.uint8)
+    L = lib()
+    L.orbo_check_fundamental.restype = ctypes.c_float
+    L.orbo_check_fundamental.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+    sc = L.orbo_check_fundamental(_p(F21), _p(k1), _p(k2), _p(first), _p(second), len(first), sigma, _p(inl))
+    return np.float32(sc), inl[:len(first)].astype(bool)
+
+
+def scoring_case(seed=0, n=400, n_models=24):
+    """Synthetic two-view case for the scoring loops: keypoints of frame 1, their images under a homography plus noise and
+    outliers, a matches12 vector with holes, and stacks of perturbed H / F hypotheses (float32)."""
+    rng = np.random.default_rng(seed)
+    k1, k2 = np.zeros(n, KP), np.zeros(n + 30, KP)
+    k1["x"], k1["y"] = rng.uniform(20, 620, n).astype(np.float32), rng.uniform(20, 460, n).astype(np.float32)
+    H = np.array([[1.02, 0.03, 5.0], [-0.02, 0.99, -3.0], [1e-5, -2e-5, 1.0]])
+    p = H @ np.stack([k1["x"].astype(np.float64), k1["y"].astype(np.float64), np.ones(n)])
+    perm = rng.permutation(n + 30)
+    xy = (p[:2] / p[2]).T + rng.normal(0, 0.7, (n, 2))
+    out = rng.random(n) < 0.2
+    xy[out] += rng.uniform(-40, 40, (int(out.sum()), 2))
+    k2["x"][perm[:n]], k2["y"][perm[:n]] = xy[:, 0].astype(np.float32), xy[:, 1].astype(np.float32)
+    m12 = perm[:n].astype(np.int32)
+    m12[rng.random(n) < 0.3] = -1
+    H21 = np.stack([H + rng.normal(0, 1, (3, 3)) * np.array([[2e-3, 2e-3, 0.5], [2e-3, 2e-3, 0.5], [1e-6, 1e-6, 0]]) * (i > 0)
+                    for i in range(n_models)])
+    H12 = np.stack([np.linalg.inv(h) for h in H21])
+    # fundamental matrices of a translating + rotating camera, perturbed
+    K = np.array([[520.0, 0, 320], [0, 520, 240], [0, 0, 1]])
+    Ki = np.linalg.inv(K)
+    F21 = []
+    for i in range(n_models):
+        t = np.array([1.0, 0.1, 0.05]) + rng.normal(0, 0.05, 3) * (i > 0)
+        a = rng.normal(0, 0.01, 3) * (i > 0)
+        R = np.eye(3) + np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        F21.append(Ki.T @ tx @ R @ Ki)
+    return k1, k2, m12, H21.astype(np.float32), H12.astype(np.float32), np.stack(F21).astype(np.float32)

@@ -554,3 +554,36 @@ def test_banded_pyramid_large_batch(orbx, oracle, nosplit, monkeypatch):
                 for l in range(1, 8):
                     assert np.array_equal(e.image_pyramid(l, f), oe.level_image(l)), (w, h, f, l)
         e.close()
+
+
+def _same_f32(a, b):
+    """bitwise equal except that any NaN equals any NaN (x86 and the GPU produce different default-NaN signs)"""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    nan = np.isnan(a)
+    return np.array_equal(nan, np.isnan(b)) and a[~nan].tobytes() == b[~nan].tobytes()
+
+
+def test_initializer_scoring_loops(orbx, ext640, oracle):
+    """CheckHomography / CheckFundamental for stacks of RANSAC hypotheses on the device equal the
+    oracle bit for bit (scores are sequential f32 sums), incl. degenerate models, N not a multiple of 64 and N = 0."""
+    for (seed, n, nm) in ((1, 400, 200), (2, 63, 5), (3, 129, 9)):
+        k1, k2, m12, H21, H12, F21 = oracle.scoring_case(seed, n=n, n_models=nm)
+        H21[-1] = 0; H12[-1] = 0; F21[-1] = 0           # degenerate: 1/0 and 0/0 paths
+        for sigma in (1.0, 2.5):
+            with np.errstate(all="ignore"):
+                sc, inl, best = ext640.check_homography(H21, H12, k1, k2, m12, sigma)
+                ref = [oracle.check_homography(H21[i], H12[i], k1, k2, m12, sigma) for i in range(nm)]
+                assert _same_f32(sc, [r[0] for r in ref])
+                assert all(np.array_equal(inl[i], ref[i][1]) for i in range(nm))
+                esc, ebest = np.float32(0), -1
+                for i in range(nm):
+                    if ref[i][0] > esc:
+                        esc, ebest = ref[i][0], i
+                assert best == ebest == 0
+                sc, inl, best = ext640.check_fundamental(F21, k1, k2, m12, sigma)
+                ref = [oracle.check_fundamental(F21[i], k1, k2, m12, sigma) for i in range(nm)]
+                assert _same_f32(sc, [r[0] for r in ref])
+                assert all(np.array_equal(inl[i], ref[i][1]) for i in range(nm))
+    none = np.full(len(k1), -1, np.int32)
+    sc, inl, best = ext640.check_homography(H21, H12, k1, k2, none, 1.0)
+    assert (sc == 0).all() and inl.shape == (len(H21), 0) and best == -1

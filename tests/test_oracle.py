@@ -263,3 +263,72 @@ def test_to_gray(oracle, images):
             return
         for i, f in enumerate(pngs):
             assert np.array_equal(oracle.to_gray(np.array(Image.open(f).convert("RGB")), True), images["init%d" % i])
+
+
+def _check_h_np(H21, H12, k1, k2, first, second, sigma):
+    """Independent numpy-f32 restatement of CheckHomography (same operation order, one IEEE f32 operation per step)."""
+    f = np.float32
+    h, hi = H21.reshape(9).astype(f), H12.reshape(9).astype(f)
+    th, inv = f(5.991), f(1.0 / np.float64(f(sigma) * f(sigma)))
+    score, inl = f(0), []
+    for a, b in zip(first, second):
+        u1, v1, u2, v2 = f(k1["x"][a]), f(k1["y"][a]), f(k2["x"][b]), f(k2["y"][b])
+        ok = True
+        w = f(1.0 / np.float64(f(f(hi[6] * u2) + f(hi[7] * v2)) + hi[8]))
+        uu, vv = f(f(f(f(hi[0] * u2) + f(hi[1] * v2)) + hi[2]) * w), f(f(f(f(hi[3] * u2) + f(hi[4] * v2)) + hi[5]) * w)
+        chi = f(f(f(f(u1 - uu) * f(u1 - uu)) + f(f(v1 - vv) * f(v1 - vv))) * inv)
+        if chi > th: ok = False
+        else: score = f(score + f(th - chi))
+        w = f(1.0 / np.float64(f(f(h[6] * u1) + f(h[7] * v1)) + h[8]))
+        uu, vv = f(f(f(f(h[0] * u1) + f(h[1] * v1)) + h[2]) * w), f(f(f(f(h[3] * u1) + f(h[4] * v1)) + h[5]) * w)
+        chi = f(f(f(f(u2 - uu) * f(u2 - uu)) + f(f(v2 - vv) * f(v2 - vv))) * inv)
+        if chi > th: ok = False
+        else: score = f(score + f(th - chi))
+        inl.append(ok)
+    return score, np.array(inl, bool)
+
+
+def _check_f_np(F21, k1, k2, first, second, sigma):
+    f = np.float32
+    m = F21.reshape(9).astype(f)
+    th, ths, inv = f(3.841), f(5.991), f(1.0 / np.float64(f(sigma) * f(sigma)))
+    score, inl = f(0), []
+    for a, b in zip(first, second):
+        u1, v1, u2, v2 = f(k1["x"][a]), f(k1["y"][a]), f(k2["x"][b]), f(k2["y"][b])
+        ok = True
+        a2, b2, c2 = f(f(f(m[0] * u1) + f(m[1] * v1)) + m[2]), f(f(f(m[3] * u1) + f(m[4] * v1)) + m[5]), f(f(f(m[6] * u1) + f(m[7] * v1)) + m[8])
+        num = f(f(f(a2 * u2) + f(b2 * v2)) + c2)
+        chi = f(f(f(num * num) / f(f(a2 * a2) + f(b2 * b2))) * inv)
+        if chi > th: ok = False
+        else: score = f(score + f(ths - chi))
+        a1, b1, c1 = f(f(f(m[0] * u2) + f(m[3] * v2)) + m[6]), f(f(f(m[1] * u2) + f(m[4] * v2)) + m[7]), f(f(f(m[2] * u2) + f(m[5] * v2)) + m[8])
+        num = f(f(f(a1 * u1) + f(b1 * v1)) + c1)
+        chi = f(f(f(num * num) / f(f(a1 * a1) + f(b1 * b1))) * inv)
+        if chi > th: ok = False
+        else: score = f(score + f(ths - chi))
+        inl.append(ok)
+    return score, np.array(inl, bool)
+
+
+def test_initializer_scoring_loops(oracle):
+    """CheckHomography / CheckFundamental (Initializer.cpp:268-438): the C restatement equals an
+    independent numpy-f32 evaluation bit for bit, and behaves as a score should (true model wins, outliers rejected)."""
+    k1, k2, m12, H21, H12, F21 = oracle.scoring_case(3, n=200, n_models=6)
+    first = np.nonzero(m12 >= 0)[0]
+    second = m12[first]
+    with np.errstate(all="ignore"):
+        for sigma in (1.0, 1.7):
+            scores = []
+            for i in range(len(H21)):
+                sc, inl = oracle.check_homography(H21[i], H12[i], k1, k2, m12, sigma)
+                esc, einl = _check_h_np(H21[i], H12[i], k1, k2, first, second, sigma)
+                assert sc == esc and np.array_equal(inl, einl)
+                scores.append(sc)
+                sc, inl = oracle.check_fundamental(F21[i], k1, k2, m12, sigma)
+                esc, einl = _check_f_np(F21[i], k1, k2, first, second, sigma)
+                assert sc == esc and np.array_equal(inl, einl)
+            assert int(np.argmax(scores)) == 0            # hypothesis 0 is the generating homography
+    sc, inl = oracle.check_homography(H21[0], H12[0], k1, k2, m12, 1.0)
+    assert 0.6 < inl.mean() < 0.95 and len(inl) == len(first)  # ~20 % of the pairs are gross outliers
+    sc0, inl0 = oracle.check_homography(H21[0], H12[0], k1, k2, np.full(len(k1), -1, np.int32), 1.0)
+    assert sc0 == 0 and len(inl0) == 0
