@@ -372,9 +372,19 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img0, 
 // =================================================================================================
 // K4+K5+K6  orientation + patch-local Gaussian + steered BRIEF per keypoint.
 // =================================================================================================
-__device__ const int8_t d_pattern[256 * 4] = {
+constexpr int8_t k_pattern[256 * 4] = {
 #include "orbx_pattern_data.inc"
 };
+// the same 256 point pairs as f32 (x0, y0, x1, y1): the steered-BRIEF loop needs them as floats (cpp:184-188)
+struct PatternF {
+  float v[256 * 4];
+};
+constexpr PatternF makePatternF() {
+  PatternF t{};
+  for (int i = 0; i < 256 * 4; i++) t.v[i] = (float)k_pattern[i];
+  return t;
+}
+__device__ const PatternF d_patternf = makePatternF();
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // cpp:562-594
 
 __device__ __forceinline__ int reflect101(int p, int n) {
@@ -621,8 +631,8 @@ __global__ __launch_bounds__(64) void k_describe_patch(const uint8_t* __restrict
   unsigned long long words[4];
 #pragma unroll
   for (int wq = 0; wq < 4; wq++) {
-    const char4 pt = reinterpret_cast<const char4*>(d_pattern)[wq * 64 + lane];
-    const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
+    const float4 pt = reinterpret_cast<const float4*>(d_patternf.v)[wq * 64 + lane];
+    const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
     const int r0 = __float2int_rn(x0 * sn + y0 * cs), c0 = __float2int_rn(x0 * cs - y0 * sn);
     const int r1 = __float2int_rn(x1 * sn + y1 * cs), c1 = __float2int_rn(x1 * cs - y1 * sn);
     const int t0 = bl[(18 + r0) * PW_COLS + 18 + c0];
