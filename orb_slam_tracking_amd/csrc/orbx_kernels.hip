@@ -100,6 +100,11 @@ __global__ __launch_bounds__(256) void k_resize_dw(const uint8_t* __restrict__ s
   *reinterpret_cast<uint32_t*>(dst + (long long)f * dstFrameStride + (long long)dy * dstride + dx0) = packed;
 }
 
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t dot2u16(uint32_t a, uint32_t b, uint32_t c) {  // v_dot2_u32_u16
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, b), c, false);
+}
+
 // The whole pyramid of a frame in ONE launch.  The chain level l <- level l-1 is kept (cpp:1660-1713), but instead of one
 // launch per level a workgroup owns a horizontal band of the frame: the band's rows of the last level need a slightly
 // larger band of the level before, and so on up to level 0 (PyrBands, computed on the host from the same y tables).  The
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256) void k_pyramid_bands(const uint8_t* __restrict
     for (int item = tid; item < items; item += 1024) {
       ResizeTab ty[4];
       uint4 tA[4], tB[4];
-      uint32_t ra[4][3], rb[4][3];
+      uint32_t ra[4][3], rb[4][3];  // three consecutive dwords of each source row hold all taps of the 4 outputs
       bool live[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
@@ -153,6 +158,7 @@ __global__ __launch_bounds__(256) void k_pyramid_bands(const uint8_t* __restrict
       for (int j = 0; j < 4; j++) {
         const int sy0 = min(max(ty[j].ofs, 0), sh - 1), sy1 = min(max(ty[j].ofs + 1, 0), sh - 1);
         const unsigned S0 = (unsigned)(sy0 * sstride), S1 = (unsigned)(sy1 * sstride);
+        // a dword beyond the row's last one is replaced by the last one and can only supply bytes whose weight is 0
         const int base = (int)tA[j].x & ~3;
         const unsigned o0 = (unsigned)base, o1 = (unsigned)min(base + 4, lim), o2 = (unsigned)min(base + 8, lim);
         ra[j][0] = *reinterpret_cast<const uint32_t*>(src + (S0 + o0)); ra[j][1] = *reinterpret_cast<const uint32_t*>(src + (S0 + o1));
@@ -162,24 +168,23 @@ __global__ __launch_bounds__(256) void k_pyramid_bands(const uint8_t* __restrict
       }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const int b0 = ty[j].coef & 0xffff, b1 = ty[j].coef >> 16;
+        const uint32_t wy0 = ty[j].coef & 0xffff, wy1 = (uint32_t)ty[j].coef >> 16;
         const int sxs[4] = {(int)tA[j].x, (int)tA[j].z, (int)tB[j].x, (int)tB[j].z};
         const uint32_t cfs[4] = {tA[j].y, tA[j].w, tB[j].y, tB[j].w};
-        const int base = sxs[0] & ~3;
         uint32_t packed = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          const int k = sxs[i] - base;  // 0..10
-          const int sh8 = k & 3;
-          const uint32_t lo0 = k < 4 ? ra[j][0] : (k < 8 ? ra[j][1] : ra[j][2]), hi0 = k < 4 ? ra[j][1] : ra[j][2];
-          const uint32_t lo1 = k < 4 ? rb[j][0] : (k < 8 ? rb[j][1] : rb[j][2]), hi1 = k < 4 ? rb[j][1] : rb[j][2];
-          const uint32_t w0 = __builtin_amdgcn_alignbyte(hi0, lo0, sh8), w1 = __builtin_amdgcn_alignbyte(hi1, lo1, sh8);
-          const int a0 = cfs[i] & 0xffff, a1 = cfs[i] >> 16;
-          const int t0 = (int)(w0 & 255) * a0 + (int)((w0 >> 8) & 255) * a1;
-          const int t1 = (int)(w1 & 255) * a0 + (int)((w1 >> 8) & 255) * a1;
-          int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
-          v = min(max(v, 0), 255);
-          packed |= (uint32_t)v << (8 * i);
+          const int k = sxs[i] - (sxs[0] & ~3);  // 0..10: byte offset of the left tap inside the 12 staged bytes
+          // taps k, k+1 come from dwords (0,1) when k <= 6, else from dwords (1,2); v_perm_b32 picks the two bytes as the
+          // u16 halves (0x0c = constant 0) and v_dot2_u32_u16 applies the Q11 pair (c0 | c1 << 16)
+          const bool up = k > 6;
+          const uint32_t sel = (uint32_t)(up ? k - 4 : k) * 0x00010001u + 0x0c010c00u;
+          const uint32_t p0 = __builtin_amdgcn_perm(up ? ra[j][2] : ra[j][1], up ? ra[j][1] : ra[j][0], sel);
+          const uint32_t p1 = __builtin_amdgcn_perm(up ? rb[j][2] : rb[j][1], up ? rb[j][1] : rb[j][0], sel);
+          const uint32_t t0 = dot2u16(p0, cfs[i], 0u), t1 = dot2u16(p1, cfs[i], 0u);
+          uint32_t v = (((wy0 * (t0 >> 4)) >> 16) + ((wy1 * (t1 >> 4)) >> 16) + 2) >> 2;
+          v = min(v, 255u);
+          packed |= v << (8 * i);
         }
         if (live[j]) *reinterpret_cast<uint32_t*>(dst + (unsigned)(dyv[j] * dstride + gxv[j] * 4)) = packed;
         gxv[j] += stepX;
@@ -416,10 +421,6 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   return a;
 }
 
-typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t dot2u16(uint32_t a, uint32_t b, uint32_t c) {  // v_dot2_u32_u16
-  return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, b), c, false);
-}
 
 // -------------------------------------------------------------------------------------------------
 // K4+K5+K6 fused, patch-local: one wave per keypoint.  The 43x43 raw window (REFLECT_101 at the level's edges) is

@@ -5,7 +5,7 @@ def short(n):
     m = re.search(r'(k_[a-z_]+)', n)
     return m.group(1) if m else n[:30]
 for path in sys.argv[1:]:
-    for f in glob.glob(path + '/*/*_counter_collection.csv'):
+    for f in glob.glob(path + '/*/*_counter_collection.csv') + glob.glob(path + '/*_counter_collection.csv'):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = short(r['Kernel_Name'])
