@@ -152,7 +152,7 @@ def main():
         avg_launch_ms = prof[kern][0] / launches
         bytes_per_launch = ab[kern] * B * args.steps / launches
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        kname = {"pyramid": "k_resize_dw", "fast": "k_fast", "describe": "k_describe_patch"}[kern]
+        kname = {"pyramid": "k_pyramid_bands", "fast": "k_fast", "describe": "k_describe_patch"}[kern]
         # HBM bytes per launch from the committed PMC pass (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json);
         # null when that profile has no entry for the dominant kernel
         traffic = None

@@ -23,7 +23,7 @@ assert L.orbx_diag_oct_stamps(st.ctypes.data, nb) == 0
 names = ["codes", "keysort", "div/alone", "passloop", "nodelist", "nodesort", "noderec", "(a)sized", "(b)introsort", "(b2)ranksort", "(c)children", "(d)cut", "(e)create", "emit"]
 st = st.astype(np.int64)
 for lvl in range(8):
-    s = st[lvl::8]
+    s = st[lvl * B:(lvl + 1) * B]  # workgroups are dispatched level-major: block = level * nFrames + frame
     d = [s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], s[:, 4] - s[:, 3], s[:, 5] - s[:, 4], s[:, 6] - s[:, 5], s[:, 7] - s[:, 6],
          s[:, 8], s[:, 9], s[:, 10], s[:, 11], s[:, 12], s[:, 13], s[:, 15] - s[:, 14]]
     tot = s[:, 15] - s[:, 0]
