@@ -700,29 +700,35 @@ __device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const 
 // double-decrement quirk) follows from the final outcomes: a train belongs to its LAST claimant.
 // All threads walk the trains together, so train data are LDS broadcasts.
 // -------------------------------------------------------------------------------------------------
-#define MJ_CAP 256
+#define MJ_CAP 256    // queries / trains per pair
+#define MJ_P 4        // threads per query: thread t works for query t % MJ_CAP on the trains e with e % MJ_P == t / MJ_CAP
+#define MJ_T (MJ_CAP * MJ_P)
 #define MJ_K 4
 #define MJ_SWEEPS 64
-#define MJ_CMAX 64   // trains inside one query's window
+#define MJ_CP 24      // trains inside one query's window, per part (a fuller window hands the pair to the sequential kernels)
 
-__global__ __launch_bounds__(MJ_CAP) void k_match_jacobi(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
-                                                         const orbx_keypoint* __restrict__ kps,
-                                                         const uint8_t* __restrict__ desc, const int* __restrict__ nkp,
-                                                         const MatchParams mp, int* __restrict__ matches12,
-                                                         int* __restrict__ nmatchesOut, int* __restrict__ statsOut) {
+__global__ __launch_bounds__(MJ_T) void k_match_jacobi(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
+                                                       const orbx_keypoint* __restrict__ kps,
+                                                       const uint8_t* __restrict__ desc, const int* __restrict__ nkp,
+                                                       const MatchParams mp, int* __restrict__ matches12,
+                                                       int* __restrict__ nmatchesOut, int* __restrict__ statsOut) {
   __shared__ float tX[MJ_CAP], tY[MJ_CAP], tAng[MJ_CAP];
   __shared__ uint32_t tDesc[8][MJ_CAP];
   __shared__ uint16_t tIdx[MJ_CAP];
   __shared__ uint8_t tCx[MJ_CAP], tCy[MJ_CAP];
   __shared__ int clCount[MJ_CAP], lastQ[MJ_CAP];
   __shared__ uint16_t clQ[MJ_CAP][MJ_K], clD[MJ_CAP][MJ_K];
-  __shared__ uint32_t candList[MJ_CMAX * MJ_CAP];  // [k][query]: dist << 8 | train slot
-  __shared__ uint32_t tOrd[MJ_CAP];                // cell << 20 | F2 index: the reference's candidate order
+  __shared__ uint32_t candList[MJ_P * MJ_CP * MJ_CAP];  // [part][k][query]: dist << 8 | train slot
+  __shared__ uint32_t tOrd[MJ_CAP];                      // cell << 20 | F2 index: the reference's candidate order
+  __shared__ unsigned long long pBest[MJ_P][MJ_CAP];     // per part: best key of the sweep
+  __shared__ uint32_t pAux[MJ_P][MJ_CAP];                // per part: second-best distance (0xffff = none) | best train slot << 16
+  __shared__ uint8_t pCnt[MJ_P][MJ_CAP];                 // per part: candidates listed for the query
   __shared__ int hist[HISTO_LENGTH];
   __shared__ int sNT, sBase, sChanged, sOverflow, sNm, sBadDist, sBadRatio, sBadOri, sKeep[3];
-  __shared__ int wcnt[MJ_CAP / 64];
+  __shared__ int wcnt[MJ_T / 64];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int part = t / MJ_CAP, q = t - part * MJ_CAP;  // waves 0-3 = part 0, ...
   const int pair = blockIdx.x + mp.pair0;
   const int fa = pairFirst[pair], fb = pairSecond[pair];
   const int n1 = nkp[fa], n2 = nkp[fb];
@@ -740,7 +746,7 @@ __global__ __launch_bounds__(MJ_CAP) void k_match_jacobi(const int* __restrict__
   if (t < HISTO_LENGTH) hist[t] = 0;
   __syncthreads();
   // ---- stage the grid-eligible octave-0 trains of F2 (slot order is irrelevant: ties are broken by cell and index) ----
-  for (int j0 = 0; j0 < n2; j0 += MJ_CAP) {
+  for (int j0 = 0; j0 < n2; j0 += MJ_T) {
     const int j = j0 + t;
     if (j < n2) {
       const orbx_keypoint kp = k2[j];
@@ -758,17 +764,15 @@ __global__ __launch_bounds__(MJ_CAP) void k_match_jacobi(const int* __restrict__
     }
   }
   __syncthreads();
-  // ---- my query: the q-th octave-0 keypoint of F1 in index order goes to thread q ----
+  // ---- the q-th octave-0 keypoint of F1 in index order is query q ----
   float qx = 0, qy = 0, qang = 0;
   int qi = -1;
   uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i0 = 0; i0 < n1; i0 += MJ_CAP) {
+  for (int i0 = 0; i0 < n1; i0 += MJ_T) {
     const int i = i0 + t;
     bool ok = false;
-    orbx_keypoint kp;
     if (i < n1) {
-      kp = k1[i];
-      ok = !(kp.octave > 0);  // ORBmatcher.cpp:38-39
+      ok = !(k1[i].octave > 0);  // ORBmatcher.cpp:38-39
       m12[i] = -1;
     }
     const unsigned long long bm = __ballot(ok);
@@ -781,7 +785,7 @@ __global__ __launch_bounds__(MJ_CAP) void k_match_jacobi(const int* __restrict__
     __syncthreads();
     if (t == 0) {
       int tot = sBase;
-      for (int w2 = 0; w2 < MJ_CAP / 64; w2++) tot += wcnt[w2];
+      for (int w2 = 0; w2 < MJ_T / 64; w2++) tot += wcnt[w2];
       sBase = tot;
     }
     __syncthreads();
@@ -791,8 +795,8 @@ __global__ __launch_bounds__(MJ_CAP) void k_match_jacobi(const int* __restrict__
     if (t == 0) nmatchesOut[pair] = MATCH_PENDING;
     return;
   }
-  if (t < nQ) {
-    qi = clCount[t];
+  if (q < nQ) {  // every part loads its query
+    qi = clCount[q];
     const orbx_keypoint kp = k1[qi];
     qx = kp.x; qy = kp.y; qang = kp.angle;
 #pragma unroll
@@ -807,22 +811,24 @@ __global__ __launch_bounds__(MJ_CAP) void k_match_jacobi(const int* __restrict__
   const int maxCX = min(ORBX_GRID_COLS - 1, (int)ceilf((qx - fminX + r) * wInv));
   const int minCY = max(0, (int)floorf((qy - fminY - r) * hInv));
   const int maxCY = min(ORBX_GRID_ROWS - 1, (int)ceilf((qy - fminY + r) * hInv));
-  const bool hasWindow = t < nQ && !(minCX >= ORBX_GRID_COLS || maxCX < 0 || minCY >= ORBX_GRID_ROWS || maxCY < 0);
+  const bool hasWindow = q < nQ && !(minCX >= ORBX_GRID_COLS || maxCX < 0 || minCY >= ORBX_GRID_ROWS || maxCY < 0);
 
-  // ---- candidate list of my query, built once: every train inside the window, with its Hamming distance ----
+  // ---- candidate list of (my query, my part of the trains), built once: every train inside the window, with its
+  //      Hamming distance.  The order inside a list is irrelevant: the comparison key is a total order. ----
+  uint32_t* const myList = candList + (size_t)part * MJ_CP * MJ_CAP + q;
   int nCand = 0;
   if (hasWindow) {
-    for (int e0 = 0; e0 < nT; e0 += 4) {  // four trains per step: 16 independent LDS broadcasts in flight
+    for (int e0 = part; e0 < nT; e0 += 4 * MJ_P) {  // four trains per step: 16 independent LDS broadcasts in flight
       int cx[4], cy[4];
       float tx[4], ty[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const int ee = min(e0 + j, MJ_CAP - 1);
+        const int ee = min(e0 + j * MJ_P, MJ_CAP - 1);
         cx[j] = tCx[ee]; cy[j] = tCy[ee]; tx[j] = tX[ee]; ty[j] = tY[ee];
       }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const int e = e0 + j;
+        const int e = e0 + j * MJ_P;
         if (e >= nT) break;
         if (cx[j] < minCX || cx[j] > maxCX || cy[j] < minCY || cy[j] > maxCY) continue;
         const float dx = tx[j] - qx, dy = ty[j] - qy;
@@ -830,62 +836,92 @@ __global__ __launch_bounds__(MJ_CAP) void k_match_jacobi(const int* __restrict__
         int dist = 0;
 #pragma unroll
         for (int w = 0; w < 8; w++) dist += __popc(qd[w] ^ tDesc[w][e]);
-        if (nCand < MJ_CMAX) candList[nCand * MJ_CAP + t] = ((uint32_t)dist << 8) | (uint32_t)e;
+        if (nCand < MJ_CP) myList[nCand * MJ_CAP] = ((uint32_t)dist << 8) | (uint32_t)e;
         nCand++;
       }
     }
-    if (nCand > MJ_CMAX) sOverflow = 1;
+    if (nCand > MJ_CP) sOverflow = 1;
   }
+  pCnt[part][q] = (uint8_t)min(nCand, 255);
   if (t < nT) tOrd[t] = ((uint32_t)(tCx[t] * ORBX_GRID_ROWS + tCy[t]) << 20) | (uint32_t)tIdx[t];
   __syncthreads();
-  if (sOverflow) {  // a window with more than MJ_CMAX trains: leave the pair to the sequential kernels
+  if (sOverflow) {  // a window too full for the lists: leave the pair to the sequential kernels
     if (t == 0) nmatchesOut[pair] = MATCH_PENDING;
     return;
   }
+  // a query has a candidate in its window iff some part listed one (vIndices2.empty() -> continue, ORBmatcher.cpp:46-47)
+  bool hasCand = false;
+#pragma unroll
+  for (int pp = 0; pp < MJ_P; pp++) hasCand |= pCnt[pp][q] != 0;
   // outcome of my query: 0 = no candidate in the window, 1 = invalid by distance, 2 = invalid by ratio, 3 = accepted
+  // (kept by the part-0 thread of the query)
   int outcome = 0, bestT = -1, bestD = 0;
   bool converged = false;
   for (int sweep = 0; sweep < MJ_SWEEPS; sweep++) {
-    int nOutcome = 0, nBestT = -1, nBestD = 0;
-    if (nCand > 0) {
-      unsigned long long best = MATCH_NONE;  // dist << 32 | cell << 20 | train index
-      int second = INF_DIST, bt = -1;
-      // four candidates per step: their list entries, claim counts and order keys are independent LDS reads that
-      // are in flight together (this loop is bound by LDS round trips, one wave per SIMD)
-      for (int k = 0; k < nCand; k += 4) {
-        uint32_t ce[4], ord[4];
-        int cnt[4];
+    // ---- every part scans its share of the query's candidates ----
+    unsigned long long best = MATCH_NONE;  // dist << 32 | cell << 20 | train index
+    int second = INF_DIST, bt = 0;
+    // four candidates per step: their list entries, claim counts and order keys are independent LDS reads that
+    // are in flight together (this loop is bound by LDS round trips)
+    for (int k = 0; k < nCand; k += 4) {
+      uint32_t ce[4], ord[4];
+      int cnt[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) ce[j] = candList[min(k + j, MJ_CMAX - 1) * MJ_CAP + t];
+      for (int j = 0; j < 4; j++) ce[j] = myList[min(k + j, MJ_CP - 1) * MJ_CAP];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { cnt[j] = clCount[ce[j] & 255]; ord[j] = tOrd[ce[j] & 255]; }
+      for (int j = 0; j < 4; j++) { cnt[j] = clCount[ce[j] & 255]; ord[j] = tOrd[ce[j] & 255]; }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          if (k + j >= nCand) break;
-          const int e = ce[j] & 255, dist = (int)(ce[j] >> 8);
-          // vMatchedDistance[e] as query t sees it: smallest distance of an earlier accepted query that chose e
-          int md = INF_DIST;
-          const int nc = min(cnt[j], MJ_K);
-          for (int c = 0; c < nc; c++)
-            if ((int)clQ[e][c] < t) md = min(md, (int)clD[e][c]);
-          if (md <= dist) continue;  // ORBmatcher.cpp:67
-          const unsigned long long key = ((unsigned long long)dist << 32) | ord[j];
-          if (key < best) {
-            second = min(second, (int)(best >> 32));
-            best = key;
-            bt = e;
-          } else {
-            second = min(second, dist);
-          }
+      for (int j = 0; j < 4; j++) {
+        if (k + j >= nCand) break;
+        const int e = ce[j] & 255, dist = (int)(ce[j] >> 8);
+        // vMatchedDistance[e] as query q sees it: smallest distance of an earlier accepted query that chose e
+        int md = INF_DIST;
+        const int nc = min(cnt[j], MJ_K);
+        for (int c = 0; c < nc; c++)
+          if ((int)clQ[e][c] < q) md = min(md, (int)clD[e][c]);
+        if (md <= dist) continue;  // ORBmatcher.cpp:67
+        const unsigned long long key = ((unsigned long long)dist << 32) | ord[j];
+        if (key < best) {
+          second = min(second, (int)(best >> 32));
+          best = key;
+          bt = e;
+        } else {
+          second = min(second, dist);
+        }
+      }
+    }
+    pBest[part][q] = best;
+    pAux[part][q] = (uint32_t)min(second, 0xffff) | ((uint32_t)bt << 16);
+    __syncthreads();
+    // ---- part 0 merges the four partial results: best = smallest key, second = second smallest distance overall ----
+    bool changed = false;
+    if (part == 0) {
+      int nOutcome = 0, nBestT = -1, nBestD = 0;
+#pragma unroll
+      for (int pp = 0; pp < MJ_P; pp++) {
+        const unsigned long long kb = pBest[pp][q];
+        const uint32_t ax = pAux[pp][q];
+        const int sec = (int)(ax & 0xffff);
+        if (pp == 0) { best = kb; bt = (int)(ax >> 16); second = sec == 0xffff ? INF_DIST : sec; continue; }
+        if (sec != 0xffff) second = min(second, sec);
+        if (kb == MATCH_NONE) continue;
+        if (kb < best) {
+          if (best != MATCH_NONE) second = min(second, (int)(best >> 32));
+          best = kb;
+          bt = (int)(ax >> 16);
+        } else {
+          second = min(second, (int)(kb >> 32));
         }
       }
       const int bd = (int)(best >> 32);
-      if (best == MATCH_NONE || bd > TH_LOW) nOutcome = 1;
-      else if ((float)bd > mp.nnratio * (float)second) nOutcome = 2;
-      else { nOutcome = 3; nBestT = bt; nBestD = bd; }
+      if (hasCand) {
+        if (best == MATCH_NONE || bd > TH_LOW) nOutcome = 1;
+        else if ((float)bd > mp.nnratio * (float)second) nOutcome = 2;
+        else { nOutcome = 3; nBestT = bt; nBestD = bd; }
+      }
+      changed = nOutcome != outcome || nBestT != bestT || nBestD != bestD;
+      outcome = nOutcome; bestT = nBestT; bestD = nBestD;
     }
-    const bool changed = nOutcome != outcome || nBestT != bestT || nBestD != bestD;
-    outcome = nOutcome; bestT = nBestT; bestD = nBestD;
     if (t == 0) sChanged = 0;
     __syncthreads();
     if (changed) sChanged = 1;
@@ -894,7 +930,7 @@ __global__ __launch_bounds__(MJ_CAP) void k_match_jacobi(const int* __restrict__
     if (!sChanged) { converged = true; break; }
     if (outcome == 3) {
       const int slot = atomicAdd(&clCount[bestT], 1);
-      if (slot < MJ_K) { clQ[bestT][slot] = (uint16_t)t; clD[bestT][slot] = (uint16_t)bestD; }
+      if (slot < MJ_K) { clQ[bestT][slot] = (uint16_t)q; clD[bestT][slot] = (uint16_t)bestD; }
       else sOverflow = 1;
     }
     __syncthreads();
@@ -904,10 +940,10 @@ __global__ __launch_bounds__(MJ_CAP) void k_match_jacobi(const int* __restrict__
     if (t == 0) nmatchesOut[pair] = MATCH_PENDING;
     return;
   }
-  // ---- final bookkeeping from the converged outcomes ----
+  // ---- final bookkeeping from the converged outcomes (part-0 threads hold them; the others have outcome 0) ----
   if (t < MJ_CAP) lastQ[t] = -1;
   __syncthreads();
-  if (outcome == 3) atomicMax(&lastQ[bestT], t);
+  if (outcome == 3) atomicMax(&lastQ[bestT], q);
   if (outcome == 1) atomicAdd(&sBadDist, 1);
   if (outcome == 2) atomicAdd(&sBadRatio, 1);
   int bin = -1;
@@ -922,7 +958,7 @@ __global__ __launch_bounds__(MJ_CAP) void k_match_jacobi(const int* __restrict__
   __syncthreads();
   // nmatches before pruning = trains that ended up with a claimant (every steal took one match away again)
   if (t < nT && lastQ[t] >= 0) atomicAdd(&sNm, 1);
-  if (outcome == 3 && lastQ[bestT] == t) m12[qi] = (int)tIdx[bestT];
+  if (outcome == 3 && lastQ[bestT] == q) m12[qi] = (int)tIdx[bestT];
   if (mp.checkOri) {
     if (t == 0) {  // ComputeThreeMaxima, ORBmatcher.cpp:152-183
       int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
@@ -1565,7 +1601,7 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
   mp.pair0 = pair0;
   // small pairs (<= 256 octave-0 queries and eligible trains): parallel fixpoint sweeps, one thread per query;
   // what it marks MATCH_PENDING goes to the sequential one-wave kernel (<= 512), and the rest to the general kernel
-  hipLaunchKernelGGL(k_match_jacobi, dim3(nPairs), dim3(MJ_CAP), 0, st, dFirst, dSecond, kps, desc, nkp, mp, matches12, nmatches,
+  hipLaunchKernelGGL(k_match_jacobi, dim3(nPairs), dim3(MJ_T), 0, st, dFirst, dSecond, kps, desc, nkp, mp, matches12, nmatches,
                      stats);
   hipLaunchKernelGGL(k_match_wave, dim3(nPairs), dim3(64), 0, st, dFirst, dSecond, kps, desc, nkp, mp, matches12, nmatches,
                      stats);
