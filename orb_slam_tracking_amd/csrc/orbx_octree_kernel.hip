@@ -74,6 +74,7 @@ struct OctScratch {
   uint32_t* candLds;     // if set: the LDS copy shares its space with hiOf and is re-read from candSrc before the emit step
   const uint32_t* candSrc;
   u64* xchg;          // LDS exchange buffer for the register sort when keys/nodes live in global memory, else nullptr
+  uint32_t* parScr;   // OCT_PAR_SCR dwords of LDS that are free during the partial pass (parallel std::sort replay), or nullptr
 };
 
 __device__ __forceinline__ int divDepth(u64 a, u64 b) {  // first depth at which two path codes differ
@@ -318,6 +319,148 @@ __device__ void stdSortPartitionPhase(u64* p, int n, int tid) {
   stdIntrosortLoop(A, n, sortStack);
 }
 
+// The same partition phase with the whole workgroup, for n <= OCT_PAR_MAX keys in LDS.  std::sort's recursion is a tree of
+// disjoint ranges that are partitioned independently, so all ranges of one recursion level are processed together
+// (breadth first), and one __unguarded_partition is evaluated in closed form: with L[k] = position of the k-th element that
+// stops the upward scan (!(a < pivot), ascending) and R[k] = position of the k-th element that stops the downward scan
+// (!(pivot < a), descending), the library swaps exactly the pairs (L[k], R[k]) with L[k] < R[k] -- a prefix k < K because L
+// increases and R decreases -- and returns cut = min(L[K], R[K-1]) (the upward scan then stops at the next original stop
+// or at the element the last swap put at R[K-1], whichever comes first).  Ranks come from two workgroup prefix sums.
+// Median-of-3, the depth budget and the heapsort fallback stay literal, per range, on the range's owner thread.
+// `scr` = OCT_PAR_SCR dwords of LDS, `ws` = 4 ints of LDS (blockScanExcl).
+#define OCT_PAR_MAX 512
+#define OCT_PAR_RANGES 64
+#define OCT_PAR_SCR (4 * 260 + 2 * OCT_PAR_RANGES + 2 * OCT_PAR_RANGES + OCT_PAR_RANGES + 4)
+__device__ void stdSortPartitionPhasePar(u64* p, int n, int tid, uint32_t* scr, int* ws) {
+  if (n <= 16) return;
+  uint16_t* Lpos = reinterpret_cast<uint16_t*>(scr);          // [514]
+  uint16_t* Rpos = reinterpret_cast<uint16_t*>(scr + 260);    // [514]
+  uint16_t* sl = reinterpret_cast<uint16_t*>(scr + 520);      // [514] exclusive prefix of the upward-stop flags
+  uint16_t* sr = reinterpret_cast<uint16_t*>(scr + 780);      // [514] exclusive prefix of the downward-stop flags
+  uint32_t* rngA = scr + 1040;                                // ranges: first | last << 10 | depth << 20, sorted by first
+  uint32_t* rngB = rngA + OCT_PAR_RANGES;
+  u64* rPivot = reinterpret_cast<u64*>(rngB + OCT_PAR_RANGES);  // [OCT_PAR_RANGES]
+  int* rK = reinterpret_cast<int*>(rngB + OCT_PAR_RANGES + 2 * OCT_PAR_RANGES);  // swaps of the range; -1 = not partitioned
+  int* sN = rK + OCT_PAR_RANGES;
+  MemKeys A{p};
+  if (tid == 0) {
+    rngA[0] = 0u | ((uint32_t)n << 10) | ((uint32_t)(2 * (31 - __builtin_clz((unsigned)n))) << 20);
+    *sN = 1;
+  }
+  __syncthreads();
+  uint32_t* cur = rngA;
+  uint32_t* nxt = rngB;
+  for (;;) {
+    const int nAct = *sN;
+    if (nAct == 0) break;
+    // ---- owners: depth check, median of three, pivot ----
+    if (tid < nAct) {
+      const uint32_t rg = cur[tid];
+      const int first = rg & 1023, last = (rg >> 10) & 1023, depth = (int)(rg >> 20);
+      if (depth == 0) {
+        stdHeapSortRange(A, first, last);
+        rK[tid] = -1;
+      } else {
+        const int mid = first + (last - first) / 2;
+        const int ia = first + 1, ib = mid, ic = last - 1;  // __move_median_to_first(first, first + 1, mid, last - 1)
+        const u64 a = p[ia], b = p[ib], c = p[ic], f = p[first];
+        int sel;
+        if (SLESS(a, b)) sel = SLESS(b, c) ? ib : (SLESS(a, c) ? ic : ia);
+        else sel = SLESS(a, c) ? ia : (SLESS(b, c) ? ic : ib);
+        const u64 pv = p[sel];
+        p[first] = pv;
+        p[sel] = f;
+        rPivot[tid] = pv;
+        rK[tid] = 0;
+      }
+    }
+    __syncthreads();
+    // ---- every position: its range and its stop flags ----
+    int myR[2], gl[2], ll[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int i = 2 * tid + j;
+      int lo = 0, hi = nAct;  // last range whose first <= i
+      while (hi - lo > 1) {
+        const int m = (lo + hi) >> 1;
+        if ((int)(cur[m] & 1023) <= i) lo = m; else hi = m;
+      }
+      const uint32_t rg = cur[lo];
+      const int first = rg & 1023, last = (rg >> 10) & 1023;
+      const bool act = i > first && i < last && rK[lo] >= 0;
+      myR[j] = act ? lo : -1;
+      gl[j] = 0; ll[j] = 0;
+      if (act) {
+        const u64 v = p[i], pv = rPivot[lo];
+        gl[j] = !SLESS(v, pv);
+        ll[j] = !SLESS(pv, v);
+      }
+    }
+    int totL, totR;
+    const int exL = blockScanExcl(gl[0] + gl[1], tid, ws, &totL);
+    const int exR = blockScanExcl(ll[0] + ll[1], tid, ws, &totR);
+    sl[2 * tid] = (uint16_t)exL; sl[2 * tid + 1] = (uint16_t)(exL + gl[0]);
+    sr[2 * tid] = (uint16_t)exR; sr[2 * tid + 1] = (uint16_t)(exR + ll[0]);
+    if (tid == 0) { sl[512] = (uint16_t)totL; sr[512] = (uint16_t)totR; }
+    __syncthreads();
+    // ---- scatter the stop positions by rank: upward stops ascending, downward stops descending ----
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      if (myR[j] < 0) continue;
+      const int i = 2 * tid + j;
+      const uint32_t rg = cur[myR[j]];
+      const int first = rg & 1023, last = (rg >> 10) & 1023;
+      if (gl[j]) Lpos[first + 1 + ((int)sl[i] - (int)sl[first + 1])] = (uint16_t)i;
+      if (ll[j]) {
+        const int nR = (int)sr[last] - (int)sr[first + 1];
+        Rpos[first + 1 + (nR - 1 - ((int)sr[i] - (int)sr[first + 1]))] = (uint16_t)i;
+      }
+    }
+    __syncthreads();
+    // ---- the swaps: pair k of the range lives at index first + 1 + k ----
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      if (myR[j] < 0) continue;
+      const int i = 2 * tid + j;
+      const uint32_t rg = cur[myR[j]];
+      const int first = rg & 1023, last = (rg >> 10) & 1023;
+      const int k = i - (first + 1);
+      const int nL = (int)sl[last] - (int)sl[first + 1], nR = (int)sr[last] - (int)sr[first + 1];
+      if (k < min(nL, nR)) {
+        const int a = Lpos[i], b = Rpos[i];
+        if (a < b) {
+          const u64 va = p[a], vb = p[b];
+          p[a] = vb;
+          p[b] = va;
+          atomicAdd(&rK[myR[j]], 1);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- owners: cut point and the ranges of the next level (both halves inherit depth - 1) ----
+    int cnt = 0, cFirst = 0, cCut = 0, cLast = 0, cDepth = 0;
+    if (tid < nAct && rK[tid] >= 0) {
+      const uint32_t rg = cur[tid];
+      cFirst = rg & 1023; cLast = (rg >> 10) & 1023; cDepth = (int)(rg >> 20) - 1;
+      const int K = rK[tid];
+      const int nL = (int)sl[cLast] - (int)sl[cFirst + 1], nR = (int)sr[cLast] - (int)sr[cFirst + 1];
+      const int cutL = K < nL ? (int)Lpos[cFirst + 1 + K] : 4096;
+      const int cutR = (K > 0 && K - 1 < nR) ? (int)Rpos[cFirst + K] : 4096;
+      cCut = min(cutL, cutR);
+      cnt = (cCut - cFirst > 16) + (cLast - cCut > 16);
+    }
+    int tot;
+    int base = blockScanExcl(cnt, tid, ws, &tot);
+    if (cnt) {
+      if (cCut - cFirst > 16) nxt[base++] = (uint32_t)cFirst | ((uint32_t)cCut << 10) | ((uint32_t)cDepth << 20);
+      if (cLast - cCut > 16) nxt[base] = (uint32_t)cCut | ((uint32_t)cLast << 10) | ((uint32_t)cDepth << 20);
+    }
+    if (tid == 0) *sN = tot;
+    __syncthreads();
+    uint32_t* tmp = cur; cur = nxt; nxt = tmp;
+  }
+}
+
 // reference candidate order (cell row, cell col, y, x) of a packed candidate (cpp:1078-1137; cv::FAST is row-major)
 __device__ __forceinline__ u64 candRank(uint32_t e, const OctLevel& L) {
   const int x = e & 0xfff, y = (e >> 12) & 0xfff;
@@ -537,7 +680,8 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
       __syncthreads();
       OCT_STAMP_ACC(8, tAcc);
       // (b) std::sort (cpp:912): partition phase on one lane, final insertion sort as a parallel stable rank sort
-      stdSortPartitionPhase(sizedA, nPend, tid);
+      if (nPend <= OCT_PAR_MAX && S.parScr) stdSortPartitionPhasePar(sizedA, nPend, tid, S.parScr, ws);
+      else stdSortPartitionPhase(sizedA, nPend, tid);
       __syncthreads();
       OCT_STAMP_ACC(9, tAcc);
       for (int j = tid; j < nPend; j += OCT_T) {
@@ -723,6 +867,7 @@ __device__ void octreeGlobalUnit(const uint32_t* __restrict__ cand, const int* _
   S.candLds = nullptr;
   S.candSrc = nullptr;
   S.xchg = xchg;
+  S.parScr = reinterpret_cast<uint32_t*>(xchg);  // the sort exchange buffer is idle during the partial pass
   octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, mCap, fCap, qMax);
   __syncthreads();
   if (threadIdx.x == 0 && *nOut == -2) *nOut = -1;  // even the large scratch was too small: hard error
@@ -760,7 +905,8 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
     const uint32_t* src = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
     for (int i = threadIdx.x; i < n; i += OCT_T) candL[i] = src[i];
     __syncthreads();
-    OctScratch S{keys, nodes, div, alone, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, childCnt, candL, candL, src, nullptr};
+    OctScratch S{keys, nodes, div, alone, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, childCnt, candL, candL, src, nullptr,
+                 candL /* hiOf / candidate cache space: dead during the partial pass */};
     octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, MCAP, FCAP, QMAX);
     __syncthreads();
     if (threadIdx.x == 0) redo = (*nOut == -2);  // a node table overflowed the LDS layout
@@ -852,7 +998,18 @@ __global__ __launch_bounds__(OCT_T) void k_debug_sort(int* triples, int n, u64* 
     a[j] = ((u64)(uint32_t)triples[3 * j] << 40) | ((u64)((uint32_t)triples[3 * j + 1] & 0xfffff) << 20) |
            (u64)((uint32_t)triples[3 * j + 2] & 0xfffff);
   __syncthreads();
-  stdSortPartitionPhase(a, n, tid);
+  __shared__ uint32_t parScr[OCT_PAR_SCR];
+  __shared__ u64 parKeys[OCT_PAR_MAX];
+  __shared__ int parWs[4];
+  if (n <= OCT_PAR_MAX) {  // the workgroup-parallel replay works on LDS keys, as in the selection kernels
+    for (int j = tid; j < n; j += OCT_T) parKeys[j] = a[j];
+    __syncthreads();
+    stdSortPartitionPhasePar(parKeys, n, tid, parScr, parWs);
+    __syncthreads();
+    for (int j = tid; j < n; j += OCT_T) a[j] = parKeys[j];
+  } else {
+    stdSortPartitionPhase(a, n, tid);
+  }
   __syncthreads();
   for (int j = tid; j < n; j += OCT_T) {
     const u64 v = a[j], kv = v >> 20;

@@ -294,6 +294,23 @@ def test_device_std_sort_replay(orbx, ext640, oracle):
             killer[i] = k + i
         killer[k + i - 1] = 2 * i
     cases.append(np.stack([killer, np.zeros(n, int), np.arange(n)], 1))
+    # n <= 512 runs the workgroup-parallel replay (closed-form partitions, breadth first): sizes around its limits, sorted /
+    # reversed / constant inputs, few distinct keys, and the median-of-3 killer (depth budget -> per-range heapsort)
+    for n in (19, 31, 64, 200, 300, 400, 449, 511, 512):
+        for hi in (1, 2, 3, 9, 1000):
+            cases.append(np.stack([rng.integers(2, 2 + hi, n), rng.integers(0, 6, n) * 16, np.arange(n)], 1))
+        cases.append(np.stack([np.arange(n), np.zeros(n, int), np.arange(n)], 1))
+        cases.append(np.stack([np.arange(n)[::-1], np.zeros(n, int), np.arange(n)], 1))
+        cases.append(np.stack([np.full(n, 7), np.full(n, 3), np.arange(n)], 1))
+    for n in (256, 512):
+        k = n // 2
+        killer = np.zeros(n, int)
+        for i in range(1, k + 1):
+            if i & 1:
+                killer[i - 1] = i
+                killer[i] = k + i
+            killer[k + i - 1] = 2 * i
+        cases.append(np.stack([killer, np.zeros(n, int), np.arange(n)], 1))
     for t in cases:
         got = ext640.debug_std_sort(t)
         exp = oracle.std_sort_sized(t)
