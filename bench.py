@@ -110,15 +110,31 @@ def main():
 
     ext = orbx.ORBextractor(*PARAMS, max_width=W, max_height=H, max_batch=B, device=local_rank)
 
+    # N > 1: the all_gather of step k's counts (RCCL over xGMI) is issued asynchronously from a snapshot of the counts and
+    # runs under the kernels of step k + 1; it is waited for before the next one is issued and before the clock stops
+    snaps = [torch.zeros(B, dtype=torch.int32, device=cdev) for _ in range(2)]
+    pending = [None]
+    nstep = [0]
+
+    def finish_gather():
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
+
     def step():
         # one call = the whole hot path of the batch (orbx_extract_match_batch_device): extraction of B frames and
         # SearchForInitialization of the B/2 consecutive pairs
         ext.extract_match_batch_device(d_img, B, W, H, W, W * H, d_k, d_d, d_n, first, second, (0, W, 0, H), d_m, d_nm, None,
                                        100, 0.9, True, cap)
         if world > 1:
-            sharding.gather_counts(d_n.to(cdev), counts_all)  # RCCL all_gather over xGMI (the call above has completed)
+            finish_gather()
+            snap = snaps[nstep[0] & 1]
+            snap.copy_(d_n)  # the call above has completed: d_n is final
+            pending[0] = dist.all_gather_into_tensor(counts_all, snap, async_op=True)
+            nstep[0] += 1
 
     def barrier():
+        finish_gather()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
