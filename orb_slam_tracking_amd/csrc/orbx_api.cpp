@@ -726,20 +726,30 @@ int orbx_extract_batch(orbx_ctx* ctx, int n_frames, const uint8_t* imgs, int wid
   const int cap = std::max(ctx->selCap, 1);
   for (int f0 = 0; f0 < n_frames; f0 += ctx->maxB) {
     const int B = std::min(ctx->maxB, n_frames - f0);
-    for (int f = 0; f < B; f++)
-      HIPCHK(hipMemcpy2DAsync(ctx->dIn + f * dfs, dstride, imgs + (size_t)(f0 + f) * frame_stride_bytes, stride, width, height,
+    if (frame_stride_bytes == (size_t)stride * height || B == 1) {
+      // frames stacked without gaps: the whole batch is one tall image -> one copy command instead of one per frame
+      HIPCHK(hipMemcpy2DAsync(ctx->dIn, dstride, imgs + (size_t)f0 * frame_stride_bytes, stride, width, (size_t)height * B,
                               hipMemcpyHostToDevice, ctx->st));
+    } else {
+      for (int f = 0; f < B; f++)
+        HIPCHK(hipMemcpy2DAsync(ctx->dIn + f * dfs, dstride, imgs + (size_t)(f0 + f) * frame_stride_bytes, stride, width, height,
+                                hipMemcpyHostToDevice, ctx->st));
+    }
     int r = extractCore(ctx, B, ctx->dIn, width, height, dstride, (long long)dfs, ctx->dKps, ctx->dDesc, cap, nullptr, nullptr);
     if (r != ORBX_OK) return r;
+    int maxN = 0;
     for (int f = 0; f < B; f++) {
-      const int n = ctx->hNsel[f];
-      n_out[f0 + f] = n;
-      orbx_keypoint* ko = kps + (size_t)(f0 + f) * capacity;
-      uint8_t* dout = desc32 + (size_t)(f0 + f) * capacity * 32;
-      if (n > 0) {
-        HIPCHK(hipMemcpyAsync(ko, ctx->dKps + (size_t)f * cap, sizeof(orbx_keypoint) * n, hipMemcpyDeviceToHost, ctx->st));
-        HIPCHK(hipMemcpyAsync(dout, ctx->dDesc + (size_t)f * cap * 32, (size_t)32 * n, hipMemcpyDeviceToHost, ctx->st));
-      }
+      n_out[f0 + f] = ctx->hNsel[f];
+      maxN = std::max(maxN, ctx->hNsel[f]);
+    }
+    if (maxN > 0) {
+      // one strided copy per array: row f = the first maxN entries of frame f (entries between n_out[f] and maxN are
+      // unspecified, like everything beyond n_out[f] in the caller's capacity-sized rows)
+      HIPCHK(hipMemcpy2DAsync(kps + (size_t)f0 * capacity, sizeof(orbx_keypoint) * (size_t)capacity, ctx->dKps,
+                              sizeof(orbx_keypoint) * (size_t)cap, sizeof(orbx_keypoint) * (size_t)maxN, B, hipMemcpyDeviceToHost,
+                              ctx->st));
+      HIPCHK(hipMemcpy2DAsync(desc32 + (size_t)f0 * capacity * 32, (size_t)32 * capacity, ctx->dDesc, (size_t)32 * cap,
+                              (size_t)32 * maxN, B, hipMemcpyDeviceToHost, ctx->st));
     }
     HIPCHK(hipStreamSynchronize(ctx->st));
     for (int f = 0; f < B; f++) {
