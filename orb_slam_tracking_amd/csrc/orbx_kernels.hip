@@ -213,6 +213,19 @@ struct FastLds {
   int32_t tileBytes, smapBytes, listBytes, outCap;
 };
 
+// ceil(2^20 / n) for n = 1..79: x / n == (x * c_inv20[n]) >> 20 for x < 2^20 / n, so the per-thread index splits of k_fast
+// cost a multiply and a shift instead of an integer division (uses: x < 256 for any n; x < 21 * 76 for n <= 21;
+// x < 76 * 76 for 7 <= n <= 76 -- the products stay below 2^32)
+struct Inv20Table {
+  uint32_t v[80];
+};
+constexpr Inv20Table makeInv20() {
+  Inv20Table t{};
+  for (int n = 1; n < 80; n++) t.v[n] = ((1u << 20) + (uint32_t)n - 1u) / (uint32_t)n;
+  return t;
+}
+__constant__ Inv20Table c_inv20 = makeInv20();
+
 __device__ __forceinline__ bool arc9(uint32_t m) {  // 16-bit circular mask has a run of >= 9 ones
   m |= m << 16;
   uint32_t r = m & (m >> 1);
@@ -267,16 +280,18 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img0, 
   const int ax0 = aligned ? (iniX & ~3) : iniX;
   const int xoff = iniX - ax0;
   if (aligned) {
-    const int nw = (maxX - ax0 + 3) >> 2;
+    const int nw = (maxX - ax0 + 3) >> 2;  // <= 21
+    const uint32_t invNw = c_inv20.v[nw];
     uint32_t* tile32 = reinterpret_cast<uint32_t*>(tile);
     for (int idx = t; idx < nw * ch; idx += 256) {
-      const int r = idx / nw, c = idx - r * nw;
+      const int r = (int)(((uint32_t)idx * invNw) >> 20), c = idx - r * nw;
       tile32[r * (TILE_STRIDE / 4) + c] =
           *reinterpret_cast<const uint32_t*>(base + (long long)(iniY + r) * stride + ax0 + 4 * c);
     }
   } else {
+    const uint32_t invCw = c_inv20.v[cw];  // 7 <= cw <= 76, idx < 76 * 76
     for (int idx = t; idx < cw * ch; idx += 256) {
-      const int r = idx / cw, c = idx - r * cw;
+      const int r = (int)(((uint32_t)idx * invCw) >> 20), c = idx - r * cw;
       tile[r * TILE_STRIDE + c] = base[(long long)(iniY + r) * stride + iniX + c];
     }
   }
@@ -292,8 +307,8 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img0, 
   constexpr int ro[16] = {3 * RS,      3 * RS + 1,  2 * RS + 2,  RS + 3,  3,       -RS + 3,     -2 * RS + 2, -3 * RS + 1,
                           -3 * RS,     -3 * RS - 1, -2 * RS - 2, -RS - 3, -3,      RS - 3,      2 * RS - 2,  3 * RS - 1};
   // per-thread pixel walk without divisions inside the loops: idx += 256  <=>  (px, py) += (256 % iw, 256 / iw)
-  const int py0 = t / iw, px0 = t - py0 * iw;
-  const int dpy = 256 / iw, dpx = 256 - dpy * iw;
+  const int py0 = (int)(((uint32_t)t * c_inv20.v[iw]) >> 20), px0 = t - py0 * iw;  // t / iw, iw <= 70
+  const int dpy = (int)((256u * c_inv20.v[iw]) >> 20), dpx = 256 - dpy * iw;
   const int npix = iw * ih;
   // The reference runs cv::FAST at iniThFAST and, only if the cell yields nothing, again at minThFAST (cpp:1109-1123).
   // Same here: pass 0 at iniTh, pass 1 at minTh only for cells without a survivor.  The strength map is threshold
