@@ -209,6 +209,9 @@ __global__ __launch_bounds__(256) void k_pyramid_bands(const uint8_t* __restrict
 // =================================================================================================
 #define TILE_STRIDE 84   // bytes per LDS tile row (21 words)
 #define SMAP_STRIDE 72   // 70 + 2 zero apron
+// threads per (cell, frame) workgroup.  The kernel is bound by the latency chain of a workgroup (tile load -> phases ->
+// returning atomic -> store), so more, smaller workgroups per CU hide more of it: 128 threads = up to 15 cells in flight per CU
+#define FAST_T 256
 struct FastLds {
   int32_t tileBytes, smapBytes, listBytes, outCap;
 };
@@ -235,7 +238,7 @@ __device__ __forceinline__ bool arc9(uint32_t m) {  // 16-bit circular mask has 
   return (r & 0xFFFFu) != 0;
 }
 
-__global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img0, long long img0FrameStride, int img0Aligned,
+__global__ __launch_bounds__(FAST_T) void k_fast(const uint8_t* __restrict__ img0, long long img0FrameStride, int img0Aligned,
                                               const uint8_t* __restrict__ pyr, const Geom g,
                                               uint32_t* __restrict__ cand, int* __restrict__ candCount,
                                               int* __restrict__ overflow, const FastLds fl) {
@@ -283,21 +286,30 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img0, 
     const int nw = (maxX - ax0 + 3) >> 2;  // <= 21
     const uint32_t invNw = c_inv20.v[nw];
     uint32_t* tile32 = reinterpret_cast<uint32_t*>(tile);
-    for (int idx = t; idx < nw * ch; idx += 256) {
-      const int r = (int)(((uint32_t)idx * invNw) >> 20), c = idx - r * nw;
-      tile32[r * (TILE_STRIDE / 4) + c] =
-          *reinterpret_cast<const uint32_t*>(base + (long long)(iniY + r) * stride + ax0 + 4 * c);
+    // (row, word) of this thread's first dword, then idx += FAST_T  <=>  (c, r) += (FAST_T % nw, FAST_T / nw): one 32-bit
+    // offset from the uniform base pointer and one LDS index, both stepped by constants (no per-iteration address math)
+    const int r0 = (int)(((uint32_t)t * invNw) >> 20), c0 = t - r0 * nw;
+    const int dr = (int)(((uint32_t)FAST_T * invNw) >> 20), dc = FAST_T - dr * nw;
+    uint32_t goff = (uint32_t)((iniY + r0) * stride + ax0 + 4 * c0);
+    const uint32_t dGoff = (uint32_t)(dr * stride + 4 * dc), wrapG = (uint32_t)(stride - 4 * nw);
+    int lidx = r0 * (TILE_STRIDE / 4) + c0, c = c0;
+    const int dLidx = dr * (TILE_STRIDE / 4) + dc, wrapL = TILE_STRIDE / 4 - nw;
+#pragma unroll 1
+    for (int idx = t; idx < nw * ch; idx += FAST_T) {
+      tile32[lidx] = *reinterpret_cast<const uint32_t*>(base + goff);
+      c += dc; goff += dGoff; lidx += dLidx;
+      if (c >= nw) { c -= nw; goff += wrapG; lidx += wrapL; }
     }
   } else {
     const uint32_t invCw = c_inv20.v[cw];  // 7 <= cw <= 76, idx < 76 * 76
-    for (int idx = t; idx < cw * ch; idx += 256) {
+    for (int idx = t; idx < cw * ch; idx += FAST_T) {
       const int r = (int)(((uint32_t)idx * invCw) >> 20), c = idx - r * cw;
       tile[r * TILE_STRIDE + c] = base[(long long)(iniY + r) * stride + iniX + c];
     }
   }
   {
     uint32_t* smap32 = reinterpret_cast<uint32_t*>(smap);
-    for (int idx = t; idx < fl.smapBytes / 4; idx += 256) smap32[idx] = 0;
+    for (int idx = t; idx < fl.smapBytes / 4; idx += FAST_T) smap32[idx] = 0;
   }
   if (t == 0) { nList = 0; nOut = 0; }
   __syncthreads();
@@ -306,9 +318,9 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img0, 
   constexpr int RS = TILE_STRIDE;
   constexpr int ro[16] = {3 * RS,      3 * RS + 1,  2 * RS + 2,  RS + 3,  3,       -RS + 3,     -2 * RS + 2, -3 * RS + 1,
                           -3 * RS,     -3 * RS - 1, -2 * RS - 2, -RS - 3, -3,      RS - 3,      2 * RS - 2,  3 * RS - 1};
-  // per-thread pixel walk without divisions inside the loops: idx += 256  <=>  (px, py) += (256 % iw, 256 / iw)
+  // per-thread pixel walk without divisions inside the loops: idx += FAST_T  <=>  (px, py) += (FAST_T % iw, FAST_T / iw)
   const int py0 = (int)(((uint32_t)t * c_inv20.v[iw]) >> 20), px0 = t - py0 * iw;  // t / iw, iw <= 70
-  const int dpy = (int)((256u * c_inv20.v[iw]) >> 20), dpx = 256 - dpy * iw;
+  const int dpy = (int)(((uint32_t)FAST_T * c_inv20.v[iw]) >> 20), dpx = FAST_T - dpy * iw;
   const int npix = iw * ih;
   // The reference runs cv::FAST at iniThFAST and, only if the cell yields nothing, again at minThFAST (cpp:1109-1123).
   // Same here: pass 0 at iniTh, pass 1 at minTh only for cells without a survivor.  The strength map is threshold
@@ -318,7 +330,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img0, 
     // ---- phase 0: necessary condition on the 4 compass pixels (an arc of 9 holds two adjacent ones) ----
     {
       int px = px0, py = py0;
-      for (int idx = t; idx < npix; idx += 256) {
+      for (int idx = t; idx < npix; idx += FAST_T) {
         const uint8_t* p = &tile[(py + 3) * TILE_STRIDE + xoff + px + 3];
         const int v = p[0], hi = v + th, lo = v - th;
         const int q0 = p[ro[0]], q4 = p[ro[4]], q8 = p[ro[8]], q12 = p[ro[12]];
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img0, 
     __syncthreads();
     const int nl = nList;
     // ---- phase 1: exact strength of the remaining pixels; corners (s > th) enter the strength map ----
-    for (int e = t; e < nl; e += 256) {
+    for (int e = t; e < nl; e += FAST_T) {
       const int code = list[e];
       const int py = code >> 7, px = code & 127;
       const uint8_t* p = &tile[(py + 3) * TILE_STRIDE + xoff + px + 3];
@@ -360,14 +372,17 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img0, 
     }
     __syncthreads();
     // ---- phase 2: in-cell NMS on the strength map; survivors are the cell's keypoints ----
-    for (int e = t; e < nl; e += 256) {
+    for (int e = t; e < nl; e += FAST_T) {
       const int code = list[e];
       if (code == 0xFFFF) continue;
       const int py = code >> 7, px = code & 127;
       const uint8_t* q = &smap[(py + 1) * SMAP_STRIDE + px + 1];
+      // all nine reads are issued together (short-circuit tests would chain nine LDS round trips)
       const int s = q[0];
-      const bool keep = s > 1 && s > q[-SMAP_STRIDE - 1] && s > q[-SMAP_STRIDE] && s > q[-SMAP_STRIDE + 1] && s > q[-1] &&
-                        s > q[1] && s > q[SMAP_STRIDE - 1] && s > q[SMAP_STRIDE] && s > q[SMAP_STRIDE + 1];
+      const int n0 = q[-SMAP_STRIDE - 1], n1 = q[-SMAP_STRIDE], n2 = q[-SMAP_STRIDE + 1], n3 = q[-1], n4 = q[1],
+                n5 = q[SMAP_STRIDE - 1], n6 = q[SMAP_STRIDE], n7 = q[SMAP_STRIDE + 1];
+      const int nmax = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+      const bool keep = s > 1 && s > nmax;
       if (keep) {
         const int slot = atomicAdd(&nOut, 1);
         if (slot < fl.outCap) outl[slot] = packCand(px + 3 + cj * L.wCell, py + 3 + ci * L.hCell, s - 1);
@@ -383,7 +398,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img0, 
   __syncthreads();
   const int ob = outBase;
   uint32_t* dstc = cand + L.candOff + (long long)f * L.candCap;
-  for (int e = t; e < no; e += 256) {
+  for (int e = t; e < no; e += FAST_T) {
     if (ob + e < L.candCap) dstc[ob + e] = outl[e];
     else *overflow = 1;
   }
@@ -1580,7 +1595,7 @@ hipError_t launch_pyramid_bands(hipStream_t st, int nFrames, const uint8_t* img0
 
 hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, int img0Aligned,
                        const uint8_t* pyr, const Geom& g, uint32_t* cand, int* candCount, int* overflow) {
-  dim3 block(256, 1, 1), grid(g.nCellsTotal, nFrames, 1);
+  dim3 block(FAST_T, 1, 1), grid(g.nCellsTotal, nFrames, 1);
   int cw = 7, ch = 7;  // largest cell image of this geometry (cell + 6 px overlap, cpp:1094-1103)
   for (int l = 0; l < g.nlevels; l++) {
     cw = std::max(cw, std::min(g.L[l].wCell + 6, ORBX_CELL_MAX));
