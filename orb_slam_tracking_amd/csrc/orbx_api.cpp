@@ -213,6 +213,8 @@ int buildGeometry(orbx_ctx* c, int w, int h, int stride0, Geom* out, std::vector
     L.wCell = (int)std::ceil(width / L.nCols);
     L.hCell = (int)std::ceil(height / L.nRows);
     L.cellBase = cellBase;
+    L.colsInv24 = L.nCols > 0 ? (uint32_t)(((1u << 24) + (uint32_t)L.nCols - 1u) / (uint32_t)L.nCols) : 0u;
+    // exact for index < 2^24 / nCols and index * colsInv24 < 2^32, i.e. nRows < 256: far beyond any frame the context accepts
     cellBase += L.nCols * L.nRows;
     // worst-case number of NMS survivors (no two are 8-neighbours)
     int cap = 0;

@@ -29,6 +29,7 @@ struct LevelGeom {
   int64_t frameStride;        // bytes between consecutive frames of this level
   int64_t candOff;            // entry offset of frame 0's candidate list (frame stride = candCap)
   int32_t resizeSpanOk;       // 1 if the taps of any 4 consecutive outputs span <= 8 source pixels (k_resize_dw usable)
+  uint32_t colsInv24;         // ceil(2^24 / nCols): cell index / nCols == (index * colsInv24) >> 24 (k_fast)
 };
 
 struct Geom {

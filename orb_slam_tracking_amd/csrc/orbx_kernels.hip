@@ -258,7 +258,7 @@ __global__ __launch_bounds__(FAST_T) void k_fast(const uint8_t* __restrict__ img
   while (level + 1 < g.nlevels && cid >= g.L[level + 1].cellBase) level++;
   const LevelGeom& L = g.L[level];
   const int local = cid - L.cellBase;
-  const int ci = local / L.nCols, cj = local - ci * L.nCols;
+  const int ci = (int)(((uint32_t)local * L.colsInv24) >> 24), cj = local - ci * L.nCols;  // local / nCols
   // cell rectangle, cpp:1082-1103
   const int iniY = ORBX_MIN_BORDER + ci * L.hCell;
   const int iniX = ORBX_MIN_BORDER + cj * L.wCell;
@@ -308,8 +308,8 @@ __global__ __launch_bounds__(FAST_T) void k_fast(const uint8_t* __restrict__ img
     }
   }
   {
-    uint32_t* smap32 = reinterpret_cast<uint32_t*>(smap);
-    for (int idx = t; idx < fl.smapBytes / 4; idx += FAST_T) smap32[idx] = 0;
+    uint4* smap128 = reinterpret_cast<uint4*>(smap);  // smapBytes is a multiple of 16
+    for (int idx = t; idx < fl.smapBytes / 16; idx += FAST_T) smap128[idx] = make_uint4(0u, 0u, 0u, 0u);
   }
   if (t == 0) { nList = 0; nOut = 0; }
   __syncthreads();
