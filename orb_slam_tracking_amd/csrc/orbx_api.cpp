@@ -24,7 +24,7 @@ hipError_t launch_resize(hipStream_t st, int nFrames, const uint8_t* src, long l
                          uint8_t* dst, long long dstFrameStride, int dw, int dh, int dstride, const ResizeTab* xtab,
                          const ResizeTab* ytab, int dwordPath);
 hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, int img0Aligned,
-                       const uint8_t* pyr, const Geom& g, uint32_t* cand, int* candCount, int* overflow);
+                       const uint8_t* pyr, const Geom& g, uint32_t* cand, int* cellCount);
 hipError_t launch_pyramid_bands(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, uint8_t* pyr,
                                 const Geom& g, const ResizeTab* tab, const PyrBands& pb);
 hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const uint8_t* img0, long long img0FrameStride,
@@ -33,7 +33,7 @@ hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const 
 hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int* dSecond, const orbx_keypoint* kps,
                         const uint8_t* desc, const int* nkp, int capacity, orbx_bounds b, int window, float nnratio, int checkOri,
                         int* matches12, int* nmatches, int* stats, int* scratch, int pair0);
-hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, const int* candCount, const OctLaunch& P,
+hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, const int* cellCount, const OctLaunch& P,
                          SelKp* selStage, int* nselLevel, uint8_t* scratch, int maxQuota);
 hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage, const int* nselLevel, const OctLaunch& P,
                               SelKp* sel, int* nsel, int selCap, int* err);
@@ -76,7 +76,9 @@ struct orbx_ctx {
   size_t pyrBytes = 0;
   uint32_t* dCand = nullptr;
   size_t candEntries = 0;
-  int* dCandCount = nullptr;
+  int* dCandCount = nullptr;   // only its tail is used: the two error flags (dOverflow)
+  int* dCellCount = nullptr;   // [frame][cell of all levels]: candidates in the cell's segment
+  size_t cellCountEntries = 0;
   int* dOverflow = nullptr;
   ResizeTab* dTab = nullptr;
   size_t tabEntries = 0;
@@ -230,7 +232,10 @@ int buildGeometry(orbx_ctx* c, int w, int h, int stride0, Geom* out, std::vector
         cap += ((cw - 6 + 1) / 2) * ((ch - 6 + 1) / 2);
       }
     }
-    L.candCap = std::max(cap, 1);
+    // k_fast writes the survivors of a cell into the cell's own fixed segment (no atomics); the selection stage gathers
+    L.candMax = std::max(cap, 1);
+    L.segCap = std::max(((L.wCell + 1) / 2) * ((L.hCell + 1) / 2), 1);
+    L.candCap = L.nCols * L.nRows * L.segCap;
     L.candOff = candOff;
     candOff += (int64_t)L.candCap * c->maxB;
     L.quota = c->quota[l];
@@ -316,15 +321,19 @@ size_t buildOctLaunch(const orbx_ctx* c, const Geom& g, OctLaunch* out) {
     O.hCell = L.hCell;
     O.nCols = L.nCols;
     O.quota = L.quota;
+    O.cellBase = L.cellBase;
+    O.nCells = L.nCols * L.nRows;
+    O.segCap = L.segCap;
     P.candOff[l] = L.candOff;
     P.candCap[l] = L.candCap;
     P.selOff[l] = selOff;
     selOff += L.quota;
-    P.scrNMax[l] = std::min(L.candCap, ORBX_OCT_MAX_CAND);
+    P.scrNMax[l] = std::min(L.candMax, ORBX_OCT_MAX_CAND);
     P.scrStride[l] = (int64_t)octScratchBytes(P.scrNMax[l], L.quota);
     P.scrOff[l] = scr;
     scr += P.scrStride[l] * c->maxB;
   }
+  P.nCellsTotal = g.nCellsTotal;
   *out = P;
   return (size_t)scr;
 }
@@ -341,7 +350,7 @@ int ensureGeometry(orbx_ctx* ctx, int w, int h, int stride0) {
   OctLaunch oct;
   const size_t octBytes = buildOctLaunch(ctx, g, &oct);
   if (s.pyrBytes > ctx->pyrBytes || s.candEntries > ctx->candEntries || s.tabEntries > ctx->tabEntries ||
-      octBytes > ctx->octScratchBytes) {
+      octBytes > ctx->octScratchBytes || (size_t)g.nCellsTotal * ctx->maxB > ctx->cellCountEntries) {
     ctx->err = "internal: geometry exceeds the buffers sized at orbx_create";
     return ORBX_E_BADARG;
   }
@@ -434,7 +443,8 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   OctLaunch oct = ctx->oct;
   oct.frame0 = f0;
   const int nl = g.nlevels;
-  HIPCHK(hipMemsetAsync(ctx->dCandCount + (size_t)f0 * nl, 0, sizeof(int) * (size_t)n * nl, st));
+  // per-cell candidate counts of these frames (k_fast writes the non-empty cells only)
+  HIPCHK(hipMemsetAsync(ctx->dCellCount + (size_t)f0 * g.nCellsTotal, 0, sizeof(int) * (size_t)n * g.nCellsTotal, st));
   // whole pyramid in one launch (k_pyramid_bands) when every level meets the dword path's preconditions and the batch
   // is large enough to fill the device with (bands x frames) workgroups; otherwise one launch per level
   bool banded = nl > 1 && a.aligned0 && n >= 32 && !getenv("ORBX_NO_BANDS");
@@ -459,12 +469,12 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   }
   {
     StageTimer tm(ctx, ORBX_STAGE_FAST, si, st);
-    HIPCHK(launch_fast(st, n, a.dImg0, a.frameStride0, a.aligned0, ctx->dPyr, g, ctx->dCand, ctx->dCandCount, ctx->dOverflow));
+    HIPCHK(launch_fast(st, n, a.dImg0, a.frameStride0, a.aligned0, ctx->dPyr, g, ctx->dCand, ctx->dCellCount));
     tm.stop(1);
   }
   {  // selection stage: quadtree per (frame, level), then level-major compaction
     StageTimer tm(ctx, ORBX_STAGE_SELECT, si, st);
-    HIPCHK(launch_octree(st, n, ctx->dCand, ctx->dCandCount, oct, ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, ctx->maxQuota));
+    HIPCHK(launch_octree(st, n, ctx->dCand, ctx->dCellCount, oct, ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, ctx->maxQuota));
     HIPCHK(launch_sel_compact(st, n, ctx->dSelStage, ctx->dNselLevel, oct, ctx->dSel, ctx->dNsel, g.selCap, ctx->dOverflow + 1));
     tm.stop(2);
   }
@@ -614,7 +624,17 @@ int orbx_create(const orbx_params* params, int device_id, int max_width, int max
   Sizes s = sizesOf(ctx, g, tab.size());
   // row strides grow by at most 63 bytes and tables by a few entries for smaller frames: keep headroom
   ctx->pyrBytes = s.pyrBytes + (size_t)64 * max_height * ctx->p.nlevels * max_batch + 4096;
-  ctx->candEntries = s.candEntries + 1024;
+  {
+    // per-level bound of cells * segCap that holds for every frame size up to max_width x max_height:
+    // cells * ceil(wCell / 2) * ceil(hCell / 2) <= (width / 2 + nCols + 1) * (height / 2 + nRows + 1)
+    size_t bound = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+      const size_t wd = (size_t)(g.L[l].maxBX - ORBX_MIN_BORDER), ht = (size_t)(g.L[l].maxBY - ORBX_MIN_BORDER);
+      bound += (wd / 2 + wd / 35 + 2) * (ht / 2 + ht / 35 + 2) * (size_t)max_batch;
+    }
+    ctx->candEntries = std::max(s.candEntries, bound) + 1024;
+    ctx->cellCountEntries = (size_t)g.nCellsTotal * max_batch + 1024;
+  }
   ctx->tabEntries = s.tabEntries + 64 * ctx->p.nlevels;
   const size_t B = (size_t)max_batch, nl = (size_t)ctx->p.nlevels;
   const size_t cap = (size_t)std::max(ctx->selCap, 1);
@@ -626,6 +646,7 @@ int orbx_create(const orbx_params* params, int device_id, int max_width, int max
   ALLOC(ctx->dPyr, ctx->pyrBytes);
   ALLOC(ctx->dCand, ctx->candEntries * 4);
   ALLOC(ctx->dCandCount, (B * nl + 2) * sizeof(int));
+  ALLOC(ctx->dCellCount, ctx->cellCountEntries * sizeof(int));
   ctx->dOverflow = ctx->dCandCount + B * nl;  // [0] candidate overflow, [1] selection error
   ALLOC(ctx->dTab, ctx->tabEntries * sizeof(ResizeTab));
   ALLOC(ctx->dSel, B * cap * sizeof(SelKp));
@@ -661,7 +682,7 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->st) (void)hipStreamSynchronize(ctx->st);
-  void* dev[] = {ctx->dPyr, ctx->dCand, ctx->dCandCount, ctx->dTab, ctx->dSel, ctx->dNsel, ctx->dSelStage, ctx->dNselLevel,
+  void* dev[] = {ctx->dPyr, ctx->dCand, ctx->dCandCount, ctx->dCellCount, ctx->dTab, ctx->dSel, ctx->dNsel, ctx->dSelStage, ctx->dNselLevel,
                  ctx->dOctScratch, ctx->dIn, ctx->dKps, ctx->dDesc, ctx->dMatchScratch, ctx->dPairs, ctx->dMk, ctx->dMd,
                  ctx->dMi, ctx->dColor, ctx->dScore};
   for (void* p : dev)
@@ -1147,10 +1168,17 @@ int orbx_debug_candidates(orbx_ctx* ctx, int frame, int level, float* xyr, int c
   if (!ctx || frame < 0 || frame >= ctx->lastB || level < 0 || level >= ctx->p.nlevels) return ORBX_E_BADARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
   const LevelGeom& L = ctx->g.L[level];
-  int cnt = 0;
-  HIPCHK(hipMemcpy(&cnt, ctx->dCandCount + (size_t)frame * ctx->p.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
-  std::vector<uint32_t> e(std::max(cnt, 1));
-  if (cnt > 0) HIPCHK(hipMemcpy(e.data(), ctx->dCand + L.candOff + (int64_t)frame * L.candCap, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+  // gather the cells' segments (k_fast writes every cell's survivors into the cell's own segment)
+  const int nCells = L.nCols * L.nRows;
+  std::vector<int> cc(std::max(nCells, 1));
+  HIPCHK(hipMemcpy(cc.data(), ctx->dCellCount + (size_t)frame * ctx->g.nCellsTotal + L.cellBase, sizeof(int) * (size_t)nCells,
+                   hipMemcpyDeviceToHost));
+  std::vector<uint32_t> seg((size_t)std::max(L.candCap, 1));
+  HIPCHK(hipMemcpy(seg.data(), ctx->dCand + L.candOff + (int64_t)frame * L.candCap, (size_t)L.candCap * 4, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> e;
+  for (int c = 0; c < nCells; c++)
+    for (int k = 0; k < cc[c]; k++) e.push_back(seg[(size_t)c * L.segCap + k]);
+  const int cnt = (int)e.size();
   std::vector<uint64_t> keyed(cnt);
   for (int i = 0; i < cnt; i++) keyed[i] = (candOrderKey(L, e[i]) << 8) | (e[i] >> 24);
   std::sort(keyed.begin(), keyed.end());
@@ -1207,6 +1235,8 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
   O.wCell = O.hCell = 1 << 20;  // one "cell": candidate order = row-major
   O.nCols = 1;
   O.quota = n_features;
+  O.cellBase = 0; O.nCells = 1; O.segCap = std::max(n, 1);  // all candidates in the segment of one cell
+  P.nCellsTotal = 1;
   P.candCap[0] = std::max(n, 1);
   P.scrNMax[0] = std::max(n, 1);
   P.scrStride[0] = (int64_t)octScratchBytes(P.scrNMax[0], n_features);

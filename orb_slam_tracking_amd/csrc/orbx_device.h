@@ -20,16 +20,18 @@ struct LevelGeom {
   int32_t wCell, hCell;
   int32_t maxBX, maxBY;       // maxBorderX/Y (cpp:1058-1059); minBorder = 16
   int32_t cellBase;           // index of this level's first cell in the flattened (level, row, col) list
-  int32_t candCap;            // capacity of one frame's candidate list on this level
+  int32_t candCap;            // entries of one frame's candidate area on this level = cells * segCap
   int32_t quota;              // mnFeaturesPerLevel
   int32_t xtabOff, ytabOff;   // offsets into the resize tables (entries)
   int32_t patchSize;          // (int)(31 * scale), cpp:1165
   float scale;                // mvScaleFactor
   int64_t imgOff;             // byte offset of frame 0's image inside the pyramid buffer (levels >= 1)
   int64_t frameStride;        // bytes between consecutive frames of this level
-  int64_t candOff;            // entry offset of frame 0's candidate list (frame stride = candCap)
+  int64_t candOff;            // entry offset of frame 0's candidate area (frame stride = candCap, cell stride = segCap)
   int32_t resizeSpanOk;       // 1 if the taps of any 4 consecutive outputs span <= 8 source pixels (k_resize_dw usable)
   uint32_t colsInv24;         // ceil(2^24 / nCols): cell index / nCols == (index * colsInv24) >> 24 (k_fast)
+  int32_t segCap;             // entries of one cell's candidate segment = worst case of its NMS survivors
+  int32_t candMax;            // worst-case number of candidates of the level (sum over its cells)
 };
 
 struct Geom {
@@ -63,6 +65,8 @@ struct OctLevel {
   float hX;                // cpp:709
   int32_t wCell, hCell, nCols;  // FAST cell grid: defines the reference's candidate order
   int32_t quota;
+  int32_t cellBase, nCells, segCap;  // the level's cells in the per-frame cell-count array; entries per cell segment
+  int32_t pad_;
 };
 
 struct OctLaunch {
@@ -74,7 +78,7 @@ struct OctLaunch {
   int32_t selOff[ORBX_MAX_LEVELS];     // offset of the level inside one frame's SelKp staging area
   int32_t scrNMax[ORBX_MAX_LEVELS];
   int32_t nlevels, selStride;          // SelKp staging entries per frame
-  int32_t frame0, pad_;                // first frame of this launch
+  int32_t frame0, nCellsTotal;         // first frame of this launch; cells of one frame over all levels
 };
 
 #define ORBX_OCT_MAX_CAND ((1 << 19) - 1)  // candidates per (frame, level) the selection stage can index

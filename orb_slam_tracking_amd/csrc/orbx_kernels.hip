@@ -240,8 +240,8 @@ __device__ __forceinline__ bool arc9(uint32_t m) {  // 16-bit circular mask has 
 
 __global__ __launch_bounds__(FAST_T) void k_fast(const uint8_t* __restrict__ img0, long long img0FrameStride, int img0Aligned,
                                               const uint8_t* __restrict__ pyr, const Geom g,
-                                              uint32_t* __restrict__ cand, int* __restrict__ candCount,
-                                              int* __restrict__ overflow, const FastLds fl) {
+                                              uint32_t* __restrict__ cand, int* __restrict__ cellCount,
+                                              const FastLds fl) {
   // LDS carved to the largest cell of this geometry (launch_fast), so that occupancy is bound by waves, not by LDS:
   // tile[tileBytes] | strength map[smapBytes] | quick-reject list u16[listCap] | survivors u32[outCap]
   extern __shared__ __attribute__((aligned(16))) uint8_t fastLds[];
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(FAST_T) void k_fast(const uint8_t* __restrict__ img
   uint8_t* const smap = fastLds + fl.tileBytes;
   uint16_t* const list = reinterpret_cast<uint16_t*>(fastLds + fl.tileBytes + fl.smapBytes);
   uint32_t* const outl = reinterpret_cast<uint32_t*>(fastLds + fl.tileBytes + fl.smapBytes + fl.listBytes);
-  __shared__ int nList, nOut, outBase;
+  __shared__ int nList, nOut;
 
   const int t = threadIdx.x;
   const int f = blockIdx.y + g.frame0;
@@ -393,14 +393,14 @@ __global__ __launch_bounds__(FAST_T) void k_fast(const uint8_t* __restrict__ img
     if (t == 0) nList = 0;  // retry the whole cell at minThFAST
     __syncthreads();
   }
-  const int no = min(nOut, fl.outCap);
-  if (t == 0) outBase = no ? atomicAdd(&candCount[f * g.nlevels + level], no) : 0;
-  __syncthreads();
-  const int ob = outBase;
-  uint32_t* dstc = cand + L.candOff + (long long)f * L.candCap;
-  for (int e = t; e < no; e += FAST_T) {
-    if (ob + e < L.candCap) dstc[ob + e] = outl[e];
-    else *overflow = 1;
+  // The cell's survivors go to the cell's own segment of the (frame, level) candidate area, and their number to the cell's
+  // counter: plain stores, no atomic and no barrier (a returning global atomic per cell kept the workgroup's slot
+  // occupied for a memory round trip and serialised the cells of a level).  The selection stage gathers the segments.
+  const int no = min(nOut, fl.outCap);  // nOut <= outCap = segCap: NMS survivors are never 8-neighbours
+  if (no > 0) {
+    if (t == 0) cellCount[(long long)f * g.nCellsTotal + cid] = no;
+    uint32_t* dstc = cand + L.candOff + (long long)f * L.candCap + (long long)local * L.segCap;
+    for (int e = t; e < no; e += FAST_T) dstc[e] = outl[e];
   }
 }
 
@@ -1594,7 +1594,7 @@ hipError_t launch_pyramid_bands(hipStream_t st, int nFrames, const uint8_t* img0
 }
 
 hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, int img0Aligned,
-                       const uint8_t* pyr, const Geom& g, uint32_t* cand, int* candCount, int* overflow) {
+                       const uint8_t* pyr, const Geom& g, uint32_t* cand, int* cellCount) {
   dim3 block(FAST_T, 1, 1), grid(g.nCellsTotal, nFrames, 1);
   int cw = 7, ch = 7;  // largest cell image of this geometry (cell + 6 px overlap, cpp:1094-1103)
   for (int l = 0; l < g.nlevels; l++) {
@@ -1607,7 +1607,7 @@ hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long lo
   fl.listBytes = (2 * (cw - 6) * (ch - 6) + 15) & ~15;
   fl.outCap = ((cw - 6 + 1) / 2) * ((ch - 6 + 1) / 2);  // NMS survivors are never 8-neighbours
   const size_t lds = (size_t)fl.tileBytes + fl.smapBytes + fl.listBytes + (size_t)fl.outCap * 4;
-  hipLaunchKernelGGL(k_fast, grid, block, lds, st, img0, img0FrameStride, img0Aligned, pyr, g, cand, candCount, overflow, fl);
+  hipLaunchKernelGGL(k_fast, grid, block, lds, st, img0, img0FrameStride, img0Aligned, pyr, g, cand, cellCount, fl);
   return hipGetLastError();
 }
 

@@ -71,8 +71,10 @@ struct OctScratch {
   int* pending;       // [2 * qCap]  two buffers
   int* childCnt;      // [qCap]      per sorted entry: children | multi-key children << 8
   const uint32_t* cand;  // packed candidates (LDS copy or global)
-  uint32_t* candLds;     // if set: the LDS copy shares its space with hiOf and is re-read from candSrc before the emit step
-  const uint32_t* candSrc;
+  uint32_t* candLds;     // if set: the LDS copy shares its space with hiOf and is gathered again before the emit step
+  const uint32_t* segBase;  // the unit's candidate area: cell c's survivors at segBase + c * segCap, cellCnt[c] of them
+  const int* cellCnt;
+  int nCells, segCap;
   u64* xchg;          // LDS exchange buffer for the register sort when keys/nodes live in global memory, else nullptr
   uint32_t* parScr;   // OCT_PAR_SCR dwords of LDS that are free during the partial pass (parallel std::sort replay), or nullptr
 };
@@ -475,6 +477,27 @@ __device__ __forceinline__ void rootRect(const OctLevel& L, int root, int& ulx, 
   bry = L.height;
 }
 
+// Gathers the candidates of one (frame, level) unit from its cells' segments (k_fast writes every cell's survivors into
+// the cell's own segment, without atomics) into dst[0 .. n), cells in index order.  Returns n to every thread; nothing is
+// written when n > cap.  `ws` = 4 ints of LDS.  Call with the whole workgroup.
+__device__ int gatherCandidates(const uint32_t* __restrict__ segBase, const int* __restrict__ cellCnt, int nCells, int segCap,
+                                uint32_t* dst, int cap, int tid, int* ws) {
+  const int chunk = (nCells + OCT_T - 1) / OCT_T;
+  const int b = min(tid * chunk, nCells), e = min(b + chunk, nCells);
+  int c = 0;
+  for (int i = b; i < e; i++) c += cellCnt[i];
+  int n;
+  int pos = blockScanExcl(c, tid, ws, &n);
+  if (n <= cap)
+    for (int i = b; i < e; i++) {
+      const int k = cellCnt[i];
+      const uint32_t* src = segBase + (size_t)i * segCap;
+      for (int j = 0; j < k; j++) dst[pos++] = src[j];
+    }
+  __syncthreads();
+  return n;
+}
+
 // The whole selection for one (frame, level).  S.cand: n unordered packed candidates.  Writes min(#nodes, quota) SelKp
 // records (list order) to `out` and the count to *nOut (-2: scratch too small for this unit).
 __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int level, SelKp* __restrict__ out,
@@ -788,10 +811,8 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
     __syncthreads();
   }
   OCT_STAMP(14);
-  if (S.candLds) {  // hiOf (dead since step 4) shared the candidate cache's space: fetch the candidates again
-    for (int i = tid; i < n; i += OCT_T) S.candLds[i] = S.candSrc[i];
-    __syncthreads();
-  }
+  if (S.candLds)  // hiOf (dead since step 4) shared the candidate cache's space: gather the candidates again
+    (void)gatherCandidates(S.segBase, S.cellCnt, S.nCells, S.segCap, S.candLds, n, tid, ws);
   // ---- 6. output positions: reverse(front alive) ++ list alive; keep the first `quota` ------------------------------
   const int nFront = sFront;
   const int total = nFront + M;  // virtual sequence: pushed nodes in reverse push order, then the list
@@ -834,16 +855,12 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
 
 // One (frame, level) unit on the global-scratch layout (octScratchBytes()); `xchg` = OCT_SORT_LDS u64 of LDS for the sorts.
 // Scratch of unit (f, level) starts at scrOff[level] + f * scrStride[level].
-__device__ void octreeGlobalUnit(const uint32_t* __restrict__ cand, const int* __restrict__ candCount, const OctLaunch& P,
+__device__ void octreeGlobalUnit(const uint32_t* __restrict__ cand, const int* __restrict__ cellCount, const OctLaunch& P,
                                  SelKp* __restrict__ selStage, int* __restrict__ nselLevel, uint8_t* __restrict__ scratch,
                                  int level, int f, u64* xchg) {
+  __shared__ int gws[OCT_T / 64];
   int* nOut = &nselLevel[f * P.nlevels + level];
   const int nMax = P.scrNMax[level], qMax = max(P.lev[level].quota, 1);
-  const int n = candCount[f * P.nlevels + level];
-  if (n > nMax) {  // more candidates than the selection stage can index (2^19 - 1)
-    if (threadIdx.x == 0) *nOut = -1;
-    return;
-  }
   size_t nPad = 256;
   while ((int)nPad < nMax) nPad <<= 1;
   const int mCap = 4 * qMax, fCap = 16 * qMax;
@@ -862,10 +879,20 @@ __device__ void octreeGlobalUnit(const uint32_t* __restrict__ cand, const int* _
   S.div = p; p += nPad + 8;
   S.alone = p; p += nPad + 8;
   S.nodeDepth = p; p += (size_t)(mCap + fCap + 8);
-  S.nodeAlive = p;
-  S.cand = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
+  S.nodeAlive = p; p += (size_t)(mCap + fCap + 8);
+  p = (uint8_t*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+  uint32_t* candBuf = (uint32_t*)p;  // [nPad] the unit's candidates, gathered from the cell segments
+  S.segBase = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
+  S.cellCnt = cellCount + (int64_t)f * P.nCellsTotal + P.lev[level].cellBase;
+  S.nCells = P.lev[level].nCells;
+  S.segCap = P.lev[level].segCap;
+  const int n = gatherCandidates(S.segBase, S.cellCnt, S.nCells, S.segCap, candBuf, nMax, threadIdx.x, gws);
+  if (n > nMax) {  // more candidates than the selection stage can index (2^19 - 1)
+    if (threadIdx.x == 0) *nOut = -1;
+    return;
+  }
+  S.cand = candBuf;
   S.candLds = nullptr;
-  S.candSrc = nullptr;
   S.xchg = xchg;
   S.parScr = reinterpret_cast<uint32_t*>(xchg);  // the sort exchange buffer is idle during the partial pass
   octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, mCap, fCap, qMax);
@@ -877,7 +904,7 @@ __device__ void octreeGlobalUnit(const uint32_t* __restrict__ cand, const int* _
 
 // LDS-resident variant: n <= NMAX candidates, quota <= QMAX
 template <int NMAX, int QMAX>
-__global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict__ cand, const int* __restrict__ candCount,
+__global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict__ cand, const int* __restrict__ cellCount,
                                                      const OctLaunch P, SelKp* __restrict__ selStage,
                                                      int* __restrict__ nselLevel, uint8_t* __restrict__ scratch) {
   constexpr int MCAP = 4 * QMAX, FCAP = 2 * QMAX;
@@ -897,15 +924,16 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   int* childCnt = pending + 2 * QMAX;                             // [QMAX]
   uint32_t* hiOf = candL;
   const int level = blockIdx.y, f = blockIdx.x + P.frame0;  // level-major dispatch, see launch_octree
-  const int n = candCount[f * P.nlevels + level];
   int* nOut = &nselLevel[f * P.nlevels + level];
   static_assert(NMAX >= OCT_SORT_LDS, "keys[] doubles as the sort exchange buffer of the global-scratch path");
   __shared__ int redo;
+  __shared__ int gws[OCT_T / 64];
+  const uint32_t* segBase = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
+  const int* cellCnt = cellCount + (int64_t)f * P.nCellsTotal + P.lev[level].cellBase;
+  const int n = gatherCandidates(segBase, cellCnt, P.lev[level].nCells, P.lev[level].segCap, candL, NMAX, threadIdx.x, gws);
   if (n <= NMAX && P.lev[level].quota <= QMAX) {
-    const uint32_t* src = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
-    for (int i = threadIdx.x; i < n; i += OCT_T) candL[i] = src[i];
-    __syncthreads();
-    OctScratch S{keys, nodes, div, alone, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, childCnt, candL, candL, src, nullptr,
+    OctScratch S{keys, nodes, div, alone, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, childCnt, candL, candL, segBase,
+                 cellCnt, P.lev[level].nCells, P.lev[level].segCap, nullptr,
                  candL /* hiOf / candidate cache space: dead during the partial pass */};
     octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, MCAP, FCAP, QMAX);
     __syncthreads();
@@ -915,18 +943,18 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   }
   // the unit does not fit the LDS layout: same workgroup, global scratch (no second kernel on the stream's critical path)
   __syncthreads();
-  octreeGlobalUnit(cand, candCount, P, selStage, nselLevel, scratch, level, f, keys);
+  octreeGlobalUnit(cand, cellCount, P, selStage, nselLevel, scratch, level, f, keys);
 }
 
 // global-scratch variant for the (frame, level) units the LDS variant left (nselLevel == -2), or for all units when
 // `all` is set.  Scratch of unit (f, level) starts at scrOff[level] + f * scrStride[level]; layout: octScratchBytes().
-__global__ __launch_bounds__(OCT_T) void k_octree_global(const uint32_t* __restrict__ cand, const int* __restrict__ candCount,
+__global__ __launch_bounds__(OCT_T) void k_octree_global(const uint32_t* __restrict__ cand, const int* __restrict__ cellCount,
                                                         const OctLaunch P, SelKp* __restrict__ selStage,
                                                         int* __restrict__ nselLevel, uint8_t* __restrict__ scratch, int all) {
   __shared__ u64 xchg[OCT_SORT_LDS];
   const int level = blockIdx.y, f = blockIdx.x + P.frame0;  // level-major dispatch, see launch_octree
   if (!all && nselLevel[f * P.nlevels + level] != -2) return;
-  octreeGlobalUnit(cand, candCount, P, selStage, nselLevel, scratch, level, f, xchg);
+  octreeGlobalUnit(cand, cellCount, P, selStage, nselLevel, scratch, level, f, xchg);
 }
 
 size_t octScratchBytes(int nMax, int qMax) {
@@ -937,7 +965,7 @@ size_t octScratchBytes(int nMax, int qMax) {
   size_t mPad = 256;
   while (mPad < mCap) mPad <<= 1;
   size_t b = nPad * 8 + mPad * 8 + (size_t)2 * qMax * 8 + nPad * 4 + (mCap + fCap) * 8 + (size_t)3 * qMax * 4 + 2 * (nPad + 8) +
-             2 * (mCap + fCap + 8);
+             2 * (mCap + fCap + 8) + 16 + nPad * 4 /* gathered candidates */;
   return (b + 255) / 256 * 256;
 }
 
@@ -967,15 +995,15 @@ __global__ __launch_bounds__(256) void k_sel_compact(const SelKp* __restrict__ s
   }
 }
 
-hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, const int* candCount, const OctLaunch& P,
+hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, const int* cellCount, const OctLaunch& P,
                          SelKp* selStage, int* nselLevel, uint8_t* scratch, int maxQuota) {
   // workgroups are dispatched x-fastest: all frames of level 0 first, then level 1, ...  The units of the lowest levels
   // run longest (most candidates, largest quota), so this is longest-processing-time-first and keeps the tail short.
   dim3 grid(nFrames, P.nlevels, 1), block(OCT_T, 1, 1);
   const bool lds = maxQuota <= 256;
   // the LDS variant handles units it cannot take (more than 2048 candidates, node-table overflow) itself on global scratch
-  if (lds) hipLaunchKernelGGL((k_octree_lds<2048, 256>), grid, block, 0, st, cand, candCount, P, selStage, nselLevel, scratch);
-  else hipLaunchKernelGGL(k_octree_global, grid, block, 0, st, cand, candCount, P, selStage, nselLevel, scratch, 1);
+  if (lds) hipLaunchKernelGGL((k_octree_lds<2048, 256>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch);
+  else hipLaunchKernelGGL(k_octree_global, grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, 1);
   return hipGetLastError();
 }
 
