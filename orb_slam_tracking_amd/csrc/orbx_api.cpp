@@ -234,7 +234,7 @@ int buildGeometry(orbx_ctx* c, int w, int h, int stride0, Geom* out, std::vector
     }
     // k_fast writes the survivors of a cell into the cell's own fixed segment (no atomics); the selection stage gathers
     L.candMax = std::max(cap, 1);
-    L.segCap = std::max(((L.wCell + 1) / 2) * ((L.hCell + 1) / 2), 1);
+    L.segCap = alignUp(std::max(((L.wCell + 1) / 2) * ((L.hCell + 1) / 2), 1), 4);  // 16-byte aligned segments
     L.candCap = L.nCols * L.nRows * L.segCap;
     L.candOff = candOff;
     candOff += (int64_t)L.candCap * c->maxB;
@@ -630,7 +630,7 @@ int orbx_create(const orbx_params* params, int device_id, int max_width, int max
     size_t bound = 0;
     for (int l = 0; l < g.nlevels; l++) {
       const size_t wd = (size_t)(g.L[l].maxBX - ORBX_MIN_BORDER), ht = (size_t)(g.L[l].maxBY - ORBX_MIN_BORDER);
-      bound += (wd / 2 + wd / 35 + 2) * (ht / 2 + ht / 35 + 2) * (size_t)max_batch;
+      bound += ((wd / 2 + wd / 35 + 2) * (ht / 2 + ht / 35 + 2) + 4 * (wd / 35 + 1) * (ht / 35 + 1)) * (size_t)max_batch;
     }
     ctx->candEntries = std::max(s.candEntries, bound) + 1024;
     ctx->cellCountEntries = (size_t)g.nCellsTotal * max_batch + 1024;
@@ -1235,12 +1235,12 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
   O.wCell = O.hCell = 1 << 20;  // one "cell": candidate order = row-major
   O.nCols = 1;
   O.quota = n_features;
-  O.cellBase = 0; O.nCells = 1; O.segCap = std::max(n, 1);  // all candidates in the segment of one cell
+  O.cellBase = 0; O.nCells = 1; O.segCap = alignUp(std::max(n, 1), 4);  // all candidates in the segment of one cell
   P.nCellsTotal = 1;
   P.candCap[0] = std::max(n, 1);
   P.scrNMax[0] = std::max(n, 1);
   P.scrStride[0] = (int64_t)octScratchBytes(P.scrNMax[0], n_features);
-  std::vector<uint32_t> packed(std::max(n, 1));
+  std::vector<uint32_t> packed((size_t)alignUp(std::max(n, 1), 4));
   for (int i = 0; i < n; i++) {
     const int x = (int)xyr[3 * i], y = (int)xyr[3 * i + 1], r = (int)xyr[3 * i + 2];
     if (x < 0 || x > 4095 || y < 0 || y > 4095 || r < 0 || r > 255) return ORBX_E_BADARG;

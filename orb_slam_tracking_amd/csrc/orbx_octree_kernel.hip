@@ -490,9 +490,17 @@ __device__ int gatherCandidates(const uint32_t* __restrict__ segBase, const int*
   int pos = blockScanExcl(c, tid, ws, &n);
   if (n <= cap)
     for (int i = b; i < e; i++) {
-      const int k = cellCnt[i];
-      const uint32_t* src = segBase + (size_t)i * segCap;
-      for (int j = 0; j < k; j++) dst[pos++] = src[j];
+      const int k = chunk == 1 ? c : cellCnt[i];
+      // segments are 16-byte aligned (segCap is a multiple of 4): four candidates per load, and a cell rarely has more
+      const uint4* src = reinterpret_cast<const uint4*>(segBase + (size_t)i * segCap);
+      for (int j = 0; j < k; j += 4) {
+        const uint4 v = src[j >> 2];
+        dst[pos] = v.x;
+        if (j + 1 < k) dst[pos + 1] = v.y;
+        if (j + 2 < k) dst[pos + 2] = v.z;
+        if (j + 3 < k) dst[pos + 3] = v.w;
+        pos += min(4, k - j);
+      }
     }
   __syncthreads();
   return n;
