@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void k_pyramid_bands(const uint8_t* __restrict
 //   (neighbours outside the cell's detection area count as 0) and s > 1
 //   cell fallback (cpp:1117-1123): no survivor with s > iniTh  =>  use minTh for the whole cell
 // =================================================================================================
-#define TILE_STRIDE 84   // bytes per LDS tile row (21 words)
+#define TILE_STRIDE 84   // bytes per LDS tile row (21 words); k_fast divides tile offsets by it with (x * 3121) >> 18
+static_assert(84 * 3121 > (1 << 18) && 83 * 3121 < (1 << 18), "reciprocal of TILE_STRIDE");
 #define SMAP_STRIDE 72   // 70 + 2 zero apron
 // threads per (cell, frame) workgroup.  The kernel is bound by the latency chain of a workgroup (tile load -> phases ->
 // returning atomic -> store), so more, smaller workgroups per CU hide more of it: 128 threads = up to 15 cells in flight per CU
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(FAST_T) void k_fast(const uint8_t* __restrict__ img
   const int py0 = (int)(((uint32_t)t * c_inv20.v[iw]) >> 20), px0 = t - py0 * iw;  // t / iw, iw <= 70
   const int dpy = (int)(((uint32_t)FAST_T * c_inv20.v[iw]) >> 20), dpx = FAST_T - dpy * iw;
   const int npix = iw * ih;
+  const int off0 = (py0 + 3) * TILE_STRIDE + xoff + px0 + 3, dOff = dpy * TILE_STRIDE + dpx;
   // The reference runs cv::FAST at iniThFAST and, only if the cell yields nothing, again at minThFAST (cpp:1109-1123).
   // Same here: pass 0 at iniTh, pass 1 at minTh only for cells without a survivor.  The strength map is threshold
   // independent, so what pass 0 wrote stays valid for pass 1.
@@ -329,27 +331,28 @@ __global__ __launch_bounds__(FAST_T) void k_fast(const uint8_t* __restrict__ img
     const int th = pass == 0 ? g.iniTh : g.minTh;
     // ---- phase 0: necessary condition on the 4 compass pixels (an arc of 9 holds two adjacent ones) ----
     {
-      int px = px0, py = py0;
+      // the pixel is carried as its byte offset in the LDS tile (row py + 3, column xoff + px + 3): one add per step, and
+      // the same offset is the list entry that phase 1 dereferences directly
+      int px = px0, off = off0;
       for (int idx = t; idx < npix; idx += FAST_T) {
-        const uint8_t* p = &tile[(py + 3) * TILE_STRIDE + xoff + px + 3];
+        const uint8_t* p = &tile[off];
         const int v = p[0], hi = v + th, lo = v - th;
         const int q0 = p[ro[0]], q4 = p[ro[4]], q8 = p[ro[8]], q12 = p[ro[12]];
         const bool b0 = q0 > hi, b4 = q4 > hi, b8 = q8 > hi, b12 = q12 > hi;
         const bool d0 = q0 < lo, d4 = q4 < lo, d8 = q8 < lo, d12 = q12 < lo;
         const bool cand0 = ((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12));
-        if (cand0) list[atomicAdd(&nList, 1)] = (uint16_t)((py << 7) | px);
+        if (cand0) list[atomicAdd(&nList, 1)] = (uint16_t)off;
         px += dpx;
-        py += dpy;
-        if (px >= iw) { px -= iw; py++; }
+        off += dOff;
+        if (px >= iw) { px -= iw; off += TILE_STRIDE - iw; }
       }
     }
     __syncthreads();
     const int nl = nList;
     // ---- phase 1: exact strength of the remaining pixels; corners (s > th) enter the strength map ----
     for (int e = t; e < nl; e += FAST_T) {
-      const int code = list[e];
-      const int py = code >> 7, px = code & 127;
-      const uint8_t* p = &tile[(py + 3) * TILE_STRIDE + xoff + px + 3];
+      const int off = list[e];
+      const uint8_t* p = &tile[off];
       const int v = p[0];
       int d[16];
 #pragma unroll
@@ -367,15 +370,20 @@ __global__ __launch_bounds__(FAST_T) void k_fast(const uint8_t* __restrict__ img
         smx = min(smx, max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]));
       }
       const int s = max(smn, -smx);
-      if (s > th) smap[(py + 1) * SMAP_STRIDE + px + 1] = (uint8_t)s;
-      else list[e] = 0xFFFF;
+      if (s > th) {
+        const int row = (off * 3121) >> 18;  // off / TILE_STRIDE (84): exact for off < 6500
+        smap[(row - 2) * SMAP_STRIDE + (off - row * TILE_STRIDE - xoff - 2)] = (uint8_t)s;  // [(py + 1)][px + 1]
+      } else {
+        list[e] = 0xFFFF;
+      }
     }
     __syncthreads();
     // ---- phase 2: in-cell NMS on the strength map; survivors are the cell's keypoints ----
     for (int e = t; e < nl; e += FAST_T) {
-      const int code = list[e];
-      if (code == 0xFFFF) continue;
-      const int py = code >> 7, px = code & 127;
+      const int off = list[e];
+      if (off == 0xFFFF) continue;
+      const int row = (off * 3121) >> 18;
+      const int py = row - 3, px = off - row * TILE_STRIDE - xoff - 3;
       const uint8_t* q = &smap[(py + 1) * SMAP_STRIDE + px + 1];
       // all nine reads are issued together (short-circuit tests would chain nine LDS round trips)
       const int s = q[0];
