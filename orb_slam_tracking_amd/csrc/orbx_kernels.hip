@@ -509,6 +509,14 @@ __global__ __launch_bounds__(64) void k_describe_patch(const uint8_t* __restrict
   const int f = blockIdx.y + g.frame0, lane = threadIdx.x;
   const int i = blockIdx.x;
   if (i >= nsel[f]) return;  // uniform; the workgroup is one wave
+  // Loads that do not depend on the keypoint are issued first, so that their latency runs under the window fetch: the
+  // disc-row weights of IC_Angle (lane = disc row) and this lane's four point pairs of the BRIEF pattern.
+  const int icRow = min(lane, 30), icAv = icRow < 15 ? 15 - icRow : icRow - 15;
+  const uint4 w1a = reinterpret_cast<const uint4*>(d_ic.w1 + icAv * 8)[0], w1b = reinterpret_cast<const uint4*>(d_ic.w1 + icAv * 8)[1];
+  const uint4 wua = reinterpret_cast<const uint4*>(d_ic.wu + icAv * 8)[0], wub = reinterpret_cast<const uint4*>(d_ic.wu + icAv * 8)[1];
+  float4 pat[4];
+#pragma unroll
+  for (int wq = 0; wq < 4; wq++) pat[wq] = reinterpret_cast<const float4*>(d_patternf.v)[wq * 64 + lane];
   uint32_t* raw = lds;                               // [43][13] dwords
   uint32_t* hz2 = raw + PW_RAW_WORDS;                // [22][40] row-pair packed horizontal sums (16-byte aligned rows)
   uint32_t* bl32 = raw;                              // [38][10] dwords = blurred bytes, row stride 40 (raw is dead by then)
@@ -572,10 +580,7 @@ __global__ __launch_bounds__(64) void k_describe_patch(const uint8_t* __restrict
   // ---- IC_Angle (cpp:103-159) on the un-blurred window: pixel (u, v) is row 21+v, byte s+21+u.  Lane = disc row v;
   //      the row's bytes u = -15..16 are 8 dwords, each weighted with v_dot4_u32_u8 (tables d_ic) ----
   if (lane < 31) {
-    const int v = lane - 15, av = v < 0 ? -v : v;
-    const uint4* t1 = reinterpret_cast<const uint4*>(d_ic.w1 + av * 8);
-    const uint4* tu = reinterpret_cast<const uint4*>(d_ic.wu + av * 8);
-    const uint4 w1a = t1[0], w1b = t1[1], wua = tu[0], wub = tu[1];
+    const int v = lane - 15;
     const uint32_t w1[8] = {w1a.x, w1a.y, w1a.z, w1a.w, w1b.x, w1b.y, w1b.z, w1b.w};
     const uint32_t wu[8] = {wua.x, wua.y, wua.z, wua.w, wub.x, wub.y, wub.z, wub.w};
     const uint32_t* rowp = raw + (6 + lane) * PW_WORDS + ((s + 6) >> 2);  // row 21 + v, first dword holding u = -15
@@ -670,7 +675,7 @@ __global__ __launch_bounds__(64) void k_describe_patch(const uint8_t* __restrict
   unsigned long long words[4];
 #pragma unroll
   for (int wq = 0; wq < 4; wq++) {
-    const float4 pt = reinterpret_cast<const float4*>(d_patternf.v)[wq * 64 + lane];
+    const float4 pt = pat[wq];
     const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
     const int r0 = __float2int_rn(x0 * sn + y0 * cs), c0 = __float2int_rn(x0 * cs - y0 * sn);
     const int r1 = __float2int_rn(x1 * sn + y1 * cs), c1 = __float2int_rn(x1 * cs - y1 * sn);
