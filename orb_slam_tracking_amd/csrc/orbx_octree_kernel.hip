@@ -58,7 +58,7 @@ __device__ unsigned long long g_octStamps[4096 * OCT_NSTAMP];
 typedef unsigned long long u64;
 
 struct OctScratch {
-  u64* keys;          // [nPad]   (code << 24) | candidate index, sorted ascending
+  u64* keys;          // [nPad]   (code << 24) | candidate position in the unit's candidate area, sorted ascending
   u64* nodes;         // [mPad]   (17 - blockDepth) << 59 | orderKey << 19 | lo, sorted ascending = std::list order
   uint8_t* div;       // [n + 1]  divergence depth between sorted neighbours (255 at both ends = "separated")
   uint8_t* alone;     // [n]      first depth at which a key is the only key of its node
@@ -70,11 +70,9 @@ struct OctScratch {
   u64* sized;         // [2 * qCap]  count << 40 | UL.x << 20 | node, two buffers (partitioned / stably sorted)
   int* pending;       // [2 * qCap]  two buffers
   int* childCnt;      // [qCap]      per sorted entry: children | multi-key children << 8
-  const uint32_t* cand;  // packed candidates (LDS copy or global)
-  uint32_t* candLds;     // if set: the LDS copy shares its space with hiOf and is gathered again before the emit step
-  const uint32_t* segBase;  // the unit's candidate area: cell c's survivors at segBase + c * segCap, cellCnt[c] of them
-  const int* cellCnt;
-  int nCells, segCap;
+  const uint32_t* cand;     // [n] positions of the unit's candidates inside its candidate area (gatherCandidates); only step 1
+                            // reads it, so in the LDS kernel it shares its space with hiOf
+  const uint32_t* segBase;  // the unit's candidate area: cell c's survivors at segBase + c * segCap
   u64* xchg;          // LDS exchange buffer for the register sort when keys/nodes live in global memory, else nullptr
   uint32_t* parScr;   // OCT_PAR_SCR dwords of LDS that are free during the partial pass (parallel std::sort replay), or nullptr
 };
@@ -477,11 +475,12 @@ __device__ __forceinline__ void rootRect(const OctLevel& L, int root, int& ulx, 
   bry = L.height;
 }
 
-// Gathers the candidates of one (frame, level) unit from its cells' segments (k_fast writes every cell's survivors into
-// the cell's own segment, without atomics) into dst[0 .. n), cells in index order.  Returns n to every thread; nothing is
-// written when n > cap.  `ws` = 4 ints of LDS.  Call with the whole workgroup.
-__device__ int gatherCandidates(const uint32_t* __restrict__ segBase, const int* __restrict__ cellCnt, int nCells, int segCap,
-                                uint32_t* dst, int cap, int tid, int* ws) {
+// Lists the candidates of one (frame, level) unit: k_fast writes every cell's survivors into the cell's own segment
+// (without atomics); dst[0 .. n) receives the positions (cell * segCap + k) of the n survivors inside the unit's candidate
+// area, cells in index order.  The position doubles as the candidate's index in the sort keys, so the candidates themselves
+// are read from the segments where they lie (L2) and never copied.  Returns n to every thread; nothing is written when
+// n > cap.  `ws` = 4 ints of LDS.  Call with the whole workgroup.
+__device__ int gatherCandidates(const int* __restrict__ cellCnt, int nCells, int segCap, uint32_t* dst, int cap, int tid, int* ws) {
   const int chunk = (nCells + OCT_T - 1) / OCT_T;
   const int b = min(tid * chunk, nCells), e = min(b + chunk, nCells);
   int c = 0;
@@ -491,16 +490,7 @@ __device__ int gatherCandidates(const uint32_t* __restrict__ segBase, const int*
   if (n <= cap)
     for (int i = b; i < e; i++) {
       const int k = chunk == 1 ? c : cellCnt[i];
-      // segments are 16-byte aligned (segCap is a multiple of 4): four candidates per load, and a cell rarely has more
-      const uint4* src = reinterpret_cast<const uint4*>(segBase + (size_t)i * segCap);
-      for (int j = 0; j < k; j += 4) {
-        const uint4 v = src[j >> 2];
-        dst[pos] = v.x;
-        if (j + 1 < k) dst[pos + 1] = v.y;
-        if (j + 2 < k) dst[pos + 2] = v.z;
-        if (j + 3 < k) dst[pos + 3] = v.w;
-        pos += min(4, k - j);
-      }
+      for (int j = 0; j < k; j++) dst[pos++] = (uint32_t)(i * segCap + j);
     }
   __syncthreads();
   return n;
@@ -528,7 +518,8 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
   for (int i = tid; i < nPad; i += OCT_T) {
     u64 key = ~0ull;
     if (i < n) {
-      const uint32_t e = S.cand[i];
+      const uint32_t gi = S.cand[i];  // position of candidate i in the unit's candidate area
+      const uint32_t e = S.segBase[gi];
       const float x = (float)(e & 0xfff), y = (float)((e >> 12) & 0xfff);
       int root = (int)(x / L.hX);  // cpp:747
       root = min(max(root, 0), L.nIni - 1);
@@ -543,7 +534,7 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
         if (qy) uly = midY; else bry = midY;
         code = (code << 2) | (u64)(qy * 2 + qx);
       }
-      key = (code << 24) | (u64)i;
+      key = (code << 24) | (u64)gi;  // gi grows with i: same order among equal codes as the list index
     }
     S.keys[i] = key;
   }
@@ -819,8 +810,6 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
     __syncthreads();
   }
   OCT_STAMP(14);
-  if (S.candLds)  // hiOf (dead since step 4) shared the candidate cache's space: gather the candidates again
-    (void)gatherCandidates(S.segBase, S.cellCnt, S.nCells, S.segCap, S.candLds, n, tid, ws);
   // ---- 6. output positions: reverse(front alive) ++ list alive; keep the first `quota` ------------------------------
   const int nFront = sFront;
   const int total = nFront + M;  // virtual sequence: pushed nodes in reverse push order, then the list
@@ -837,11 +826,11 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
       if (!S.nodeAlive[nd]) continue;
       // first key with the highest response (cpp:984-1007); "first" = reference candidate order
       const int lo = S.nodeLo[nd], hi = S.nodeHi[nd];
-      uint32_t bestE = S.cand[(int)(S.keys[lo] & 0xffffff)];
+      uint32_t bestE = S.segBase[(int)(S.keys[lo] & 0xffffff)];
       if (hi - lo > 1) {
         u64 bestRank = candRank(bestE, L);
         for (int i = lo + 1; i < hi; i++) {
-          const uint32_t e2 = S.cand[(int)(S.keys[i] & 0xffffff)];
+          const uint32_t e2 = S.segBase[(int)(S.keys[i] & 0xffffff)];
           const uint32_t s1 = bestE >> 24, s2 = e2 >> 24;
           if (s2 < s1) continue;
           const u64 r2 = candRank(e2, L);
@@ -889,18 +878,15 @@ __device__ void octreeGlobalUnit(const uint32_t* __restrict__ cand, const int* _
   S.nodeDepth = p; p += (size_t)(mCap + fCap + 8);
   S.nodeAlive = p; p += (size_t)(mCap + fCap + 8);
   p = (uint8_t*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
-  uint32_t* candBuf = (uint32_t*)p;  // [nPad] the unit's candidates, gathered from the cell segments
+  uint32_t* candBuf = (uint32_t*)p;  // [nPad] positions of the unit's candidates
   S.segBase = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
-  S.cellCnt = cellCount + (int64_t)f * P.nCellsTotal + P.lev[level].cellBase;
-  S.nCells = P.lev[level].nCells;
-  S.segCap = P.lev[level].segCap;
-  const int n = gatherCandidates(S.segBase, S.cellCnt, S.nCells, S.segCap, candBuf, nMax, threadIdx.x, gws);
+  const int n = gatherCandidates(cellCount + (int64_t)f * P.nCellsTotal + P.lev[level].cellBase, P.lev[level].nCells,
+                                 P.lev[level].segCap, candBuf, nMax, threadIdx.x, gws);
   if (n > nMax) {  // more candidates than the selection stage can index (2^19 - 1)
     if (threadIdx.x == 0) *nOut = -1;
     return;
   }
   S.cand = candBuf;
-  S.candLds = nullptr;
   S.xchg = xchg;
   S.parScr = reinterpret_cast<uint32_t*>(xchg);  // the sort exchange buffer is idle during the partial pass
   octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, mCap, fCap, qMax);
@@ -919,7 +905,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   static_assert((NMAX & (NMAX - 1)) == 0 && (MCAP & (MCAP - 1)) == 0, "sort buffers must be powers of two");
   // LDS budget (NMAX 2048, QMAX 256): 16 + 8 + 8 + 12 + 4 + 3 KB = 51 KB -> three workgroups per CU.
   //   nodes[] is dead once the node records exist, so the partial pass's buffers (sized, pending, childCnt) live in it;
-  //   hiOf[] is dead after step 4 and shares its space with the candidate cache (reloaded before the emit step).
+  //   hiOf[] (steps 3-4) shares its space with the candidate position list (step 1 only).
   __shared__ u64 keys[NMAX];
   __shared__ u64 nodes[MCAP];
   __shared__ uint32_t candL[NMAX];
@@ -938,11 +924,10 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   __shared__ int gws[OCT_T / 64];
   const uint32_t* segBase = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
   const int* cellCnt = cellCount + (int64_t)f * P.nCellsTotal + P.lev[level].cellBase;
-  const int n = gatherCandidates(segBase, cellCnt, P.lev[level].nCells, P.lev[level].segCap, candL, NMAX, threadIdx.x, gws);
+  const int n = gatherCandidates(cellCnt, P.lev[level].nCells, P.lev[level].segCap, candL, NMAX, threadIdx.x, gws);
   if (n <= NMAX && P.lev[level].quota <= QMAX) {
-    OctScratch S{keys, nodes, div, alone, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, childCnt, candL, candL, segBase,
-                 cellCnt, P.lev[level].nCells, P.lev[level].segCap, nullptr,
-                 candL /* hiOf / candidate cache space: dead during the partial pass */};
+    OctScratch S{keys, nodes, div, alone, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, childCnt, candL, segBase, nullptr,
+                 candL /* hiOf / position list space: dead during the partial pass */};
     octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, MCAP, FCAP, QMAX);
     __syncthreads();
     if (threadIdx.x == 0) redo = (*nOut == -2);  // a node table overflowed the LDS layout
