@@ -210,8 +210,8 @@ int orbx_debug_distribute(const float* xyr, int n, int min_x, int max_x, int min
                           float* out_xyr, int cap);
 /* The same selection on the device (the kernels the pipeline uses).  Candidates must be given in row-major (y, x)
  * order with integer coordinates in [0, 4095] relative to (min_x, min_y) and integer responses in [0, 255].
- * variant 0 = LDS-resident kernel (handing over to the global-scratch kernel when a unit does not fit),
- * variant 1 = global-scratch kernel only. */
+ * variant 0 = LDS-resident kernel (redoing a unit that does not fit on global scratch), variant 1 = global-scratch kernel
+ * only, variant 2 = the smaller LDS instance (<= 1024 candidates) that the pipeline picks when the previous batch allows. */
 int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min_x, int max_x, int min_y, int max_y,
                                  int n_features, int variant, float* out_xyr, int cap);
 /* The device's literal replay of libstdc++ std::sort with the reference's compareNodes (cpp:684-696, 912) on n

@@ -34,9 +34,9 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
                         const uint8_t* desc, const int* nkp, int capacity, orbx_bounds b, int window, float nnratio, int checkOri,
                         int* matches12, int* nmatches, int* stats, int* scratch, int pair0);
 hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, const int* cellCount, const OctLaunch& P,
-                         SelKp* selStage, int* nselLevel, uint8_t* scratch, int maxQuota);
+                         SelKp* selStage, int* nselLevel, uint8_t* scratch, int maxQuota, int* maxN, int nHint);
 hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage, const int* nselLevel, const OctLaunch& P,
-                              SelKp* sel, int* nsel, int selCap, int* err);
+                              SelKp* sel, int* nsel, int selCap, int* err, int* maxN, int* hostMaxN);
 size_t octScratchBytes(int nMax, int qMax);
 hipError_t launch_to_gray(hipStream_t st, int nFrames, const uint8_t* src, long long srcFrameStride, int sstride, int w, int h,
                           int channels, int rgb, uint8_t* dst, long long dstFrameStride, int dstride);
@@ -78,6 +78,11 @@ struct orbx_ctx {
   size_t candEntries = 0;
   int* dCandCount = nullptr;   // only its tail is used: the two error flags (dOverflow)
   int* dCellCount = nullptr;   // [frame][cell of all levels]: candidates in the cell's segment
+  int* dMaxN = nullptr;        // [stream slot][level] largest candidate count of a unit (k_octree_lds), reset by k_sel_compact
+  int* hMaxN = nullptr;        // pinned mirror, written by k_sel_compact
+  int* hMaxNDev = nullptr;
+  int candHint = 0;            // largest candidate count of a unit in the previous batch of this geometry (0 = unknown)
+  int maxSlotsUsed = 0;
   size_t cellCountEntries = 0;
   int* dOverflow = nullptr;
   ResizeTab* dTab = nullptr;
@@ -362,6 +367,7 @@ int ensureGeometry(orbx_ctx* ctx, int w, int h, int stride0) {
   ctx->curW = w;
   ctx->curH = h;
   ctx->curStride0 = stride0;
+  ctx->candHint = 0;  // candidate statistics of another frame size say nothing about this one
   return ORBX_OK;
 }
 
@@ -474,8 +480,13 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   }
   {  // selection stage: quadtree per (frame, level), then level-major compaction
     StageTimer tm(ctx, ORBX_STAGE_SELECT, si, st);
-    HIPCHK(launch_octree(st, n, ctx->dCand, ctx->dCellCount, oct, ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, ctx->maxQuota));
-    HIPCHK(launch_sel_compact(st, n, ctx->dSelStage, ctx->dNselLevel, oct, ctx->dSel, ctx->dNsel, g.selCap, ctx->dOverflow + 1));
+    // per-level candidate maxima of this stream slot: device accumulators + their pinned host mirror (read after the sync)
+    int* dMax = ctx->dMaxN + si * ORBX_MAX_LEVELS;
+    HIPCHK(launch_octree(st, n, ctx->dCand, ctx->dCellCount, oct, ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, ctx->maxQuota,
+                         dMax, ctx->candHint));
+    HIPCHK(launch_sel_compact(st, n, ctx->dSelStage, ctx->dNselLevel, oct, ctx->dSel, ctx->dNsel, g.selCap, ctx->dOverflow + 1, dMax,
+                              ctx->hMaxNDev + si * ORBX_MAX_LEVELS));
+    ctx->maxSlotsUsed |= 1 << si;
     tm.stop(2);
   }
   {
@@ -575,6 +586,14 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
   HIPCHK(hipMemcpyAsync(ctx->hFlags, ctx->dOverflow, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   collectProfile(ctx);
+  {  // largest candidate count of a unit in this batch: picks the selection kernel's instance for the next batch
+    int m = 0;
+    for (int q = 0; q < 2; q++)
+      if (ctx->maxSlotsUsed & (1 << q))
+        for (int l = 0; l < ctx->p.nlevels; l++) m = std::max(m, ctx->hMaxN[q * ORBX_MAX_LEVELS + l]);
+    ctx->candHint = m;
+    ctx->maxSlotsUsed = 0;
+  }
   ctx->lastImg0 = dImg0;
   ctx->lastFrameStride0 = frameStride0;
   ctx->lastB = B;
@@ -665,6 +684,10 @@ int orbx_create(const orbx_params* params, int device_id, int max_width, int max
   ALLOC(ctx->dDesc, B * cap * 32);
   ALLOCH(ctx->hNsel, B * sizeof(int));
   ALLOCH(ctx->hFlags, 2 * sizeof(int));
+  ALLOC(ctx->dMaxN, 2 * ORBX_MAX_LEVELS * sizeof(int));
+  if (hipMemset(ctx->dMaxN, 0, 2 * ORBX_MAX_LEVELS * sizeof(int)) != hipSuccess) return fail(ORBX_E_HIP);
+  ALLOCH(ctx->hMaxN, 2 * ORBX_MAX_LEVELS * sizeof(int));
+  if (hipHostGetDevicePointer((void**)&ctx->hMaxNDev, ctx->hMaxN, 0) != hipSuccess) return fail(ORBX_E_HIP);
 #undef ALLOC
 #undef ALLOCH
   for (int si = 0; si < 2; si++)
@@ -682,12 +705,12 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->st) (void)hipStreamSynchronize(ctx->st);
-  void* dev[] = {ctx->dPyr, ctx->dCand, ctx->dCandCount, ctx->dCellCount, ctx->dTab, ctx->dSel, ctx->dNsel, ctx->dSelStage, ctx->dNselLevel,
+  void* dev[] = {ctx->dPyr, ctx->dCand, ctx->dCandCount, ctx->dCellCount, ctx->dMaxN, ctx->dTab, ctx->dSel, ctx->dNsel, ctx->dSelStage, ctx->dNselLevel,
                  ctx->dOctScratch, ctx->dIn, ctx->dKps, ctx->dDesc, ctx->dMatchScratch, ctx->dPairs, ctx->dMk, ctx->dMd,
                  ctx->dMi, ctx->dColor, ctx->dScore};
   for (void* p : dev)
     if (p) (void)hipFree(p);
-  void* host[] = {ctx->hNsel, ctx->hFlags};
+  void* host[] = {ctx->hNsel, ctx->hFlags, ctx->hMaxN};
   for (void* p : host)
     if (p) (void)hipHostFree(p);
   if (ctx->st2) (void)hipStreamSynchronize(ctx->st2);
@@ -1260,7 +1283,7 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
     HIPCHK(hipMemcpyAsync(dC, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->st));
     int hi[2] = {n, -7};
     HIPCHK(hipMemcpyAsync(dI, hi, sizeof hi, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(launch_octree(ctx->st, 1, dC, dI, P, dS, dI + 1, dScr, variant == 0 ? n_features : (1 << 30)));
+    HIPCHK(launch_octree(ctx->st, 1, dC, dI, P, dS, dI + 1, dScr, variant == 0 ? n_features : (1 << 30), nullptr, variant == 2 ? 1 : 0));
     HIPCHK(hipMemcpyAsync(res, dI, sizeof res, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(sel.data(), dS, sel.size() * sizeof(SelKp), hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "../../include/orbx.h"
 #include "orbx_device.h"
@@ -74,7 +75,8 @@ struct OctScratch {
                             // reads it, so in the LDS kernel it shares its space with hiOf
   const uint32_t* segBase;  // the unit's candidate area: cell c's survivors at segBase + c * segCap
   u64* xchg;          // LDS exchange buffer for the register sort when keys/nodes live in global memory, else nullptr
-  uint32_t* parScr;   // OCT_PAR_SCR dwords of LDS that are free during the partial pass (parallel std::sort replay), or nullptr
+  uint32_t* parScr;   // OCT_PAR_SCR_FOR(parCap) dwords of LDS that are free during the partial pass (parallel std::sort replay)
+  int parCap;         // largest array the parallel replay may take there (512 or 256 keys); larger ones use the one-lane replay
 };
 
 __device__ __forceinline__ int divDepth(u64 a, u64 b) {  // first depth at which two path codes differ
@@ -330,14 +332,17 @@ __device__ void stdSortPartitionPhase(u64* p, int n, int tid) {
 // `scr` = OCT_PAR_SCR dwords of LDS, `ws` = 4 ints of LDS (blockScanExcl).
 #define OCT_PAR_MAX 512
 #define OCT_PAR_RANGES 64
-#define OCT_PAR_SCR (4 * 260 + 2 * OCT_PAR_RANGES + 2 * OCT_PAR_RANGES + OCT_PAR_RANGES + 4)
-__device__ void stdSortPartitionPhasePar(u64* p, int n, int tid, uint32_t* scr, int* ws) {
+// scratch dwords for at most capN keys (capN = 512 or 256): four u16 arrays of capN + 8 entries, then the range tables
+#define OCT_PAR_SCR_FOR(capN) (4 * (((capN) + 8) / 2) + 2 * OCT_PAR_RANGES + 2 * OCT_PAR_RANGES + OCT_PAR_RANGES + 4)
+#define OCT_PAR_SCR OCT_PAR_SCR_FOR(OCT_PAR_MAX)
+__device__ void stdSortPartitionPhasePar(u64* p, int n, int tid, uint32_t* scr, int* ws, int capN) {
   if (n <= 16) return;
-  uint16_t* Lpos = reinterpret_cast<uint16_t*>(scr);          // [514]
-  uint16_t* Rpos = reinterpret_cast<uint16_t*>(scr + 260);    // [514]
-  uint16_t* sl = reinterpret_cast<uint16_t*>(scr + 520);      // [514] exclusive prefix of the upward-stop flags
-  uint16_t* sr = reinterpret_cast<uint16_t*>(scr + 780);      // [514] exclusive prefix of the downward-stop flags
-  uint32_t* rngA = scr + 1040;                                // ranges: first | last << 10 | depth << 20, sorted by first
+  const int seg = (capN + 8) / 2;                              // dwords per u16 array
+  uint16_t* Lpos = reinterpret_cast<uint16_t*>(scr);           // [capN + 8]
+  uint16_t* Rpos = reinterpret_cast<uint16_t*>(scr + seg);
+  uint16_t* sl = reinterpret_cast<uint16_t*>(scr + 2 * seg);   // exclusive prefix of the upward-stop flags, [capN] = total
+  uint16_t* sr = reinterpret_cast<uint16_t*>(scr + 3 * seg);   // exclusive prefix of the downward-stop flags
+  uint32_t* rngA = scr + 4 * seg;                              // ranges: first | last << 10 | depth << 20, sorted by first
   uint32_t* rngB = rngA + OCT_PAR_RANGES;
   u64* rPivot = reinterpret_cast<u64*>(rngB + OCT_PAR_RANGES);  // [OCT_PAR_RANGES]
   int* rK = reinterpret_cast<int*>(rngB + OCT_PAR_RANGES + 2 * OCT_PAR_RANGES);  // swaps of the range; -1 = not partitioned
@@ -399,9 +404,11 @@ __device__ void stdSortPartitionPhasePar(u64* p, int n, int tid, uint32_t* scr, 
     int totL, totR;
     const int exL = blockScanExcl(gl[0] + gl[1], tid, ws, &totL);
     const int exR = blockScanExcl(ll[0] + ll[1], tid, ws, &totR);
-    sl[2 * tid] = (uint16_t)exL; sl[2 * tid + 1] = (uint16_t)(exL + gl[0]);
-    sr[2 * tid] = (uint16_t)exR; sr[2 * tid + 1] = (uint16_t)(exR + ll[0]);
-    if (tid == 0) { sl[512] = (uint16_t)totL; sr[512] = (uint16_t)totR; }
+    if (2 * tid < capN) {  // (flags beyond n are 0: the prefix stays at the total there)
+      sl[2 * tid] = (uint16_t)exL; sl[2 * tid + 1] = (uint16_t)(exL + gl[0]);
+      sr[2 * tid] = (uint16_t)exR; sr[2 * tid + 1] = (uint16_t)(exR + ll[0]);
+    }
+    if (tid == 0) { sl[capN] = (uint16_t)totL; sr[capN] = (uint16_t)totR; }
     __syncthreads();
     // ---- scatter the stop positions by rank: upward stops ascending, downward stops descending ----
 #pragma unroll
@@ -702,7 +709,7 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
       __syncthreads();
       OCT_STAMP_ACC(8, tAcc);
       // (b) std::sort (cpp:912): partition phase on one lane, final insertion sort as a parallel stable rank sort
-      if (nPend <= OCT_PAR_MAX && S.parScr) stdSortPartitionPhasePar(sizedA, nPend, tid, S.parScr, ws);
+      if (nPend <= S.parCap && S.parScr) stdSortPartitionPhasePar(sizedA, nPend, tid, S.parScr, ws, S.parCap);
       else stdSortPartitionPhase(sizedA, nPend, tid);
       __syncthreads();
       OCT_STAMP_ACC(9, tAcc);
@@ -889,6 +896,7 @@ __device__ void octreeGlobalUnit(const uint32_t* __restrict__ cand, const int* _
   S.cand = candBuf;
   S.xchg = xchg;
   S.parScr = reinterpret_cast<uint32_t*>(xchg);  // the sort exchange buffer is idle during the partial pass
+  S.parCap = OCT_PAR_MAX;
   octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, mCap, fCap, qMax);
   __syncthreads();
   if (threadIdx.x == 0 && *nOut == -2) *nOut = -1;  // even the large scratch was too small: hard error
@@ -900,14 +908,17 @@ __device__ void octreeGlobalUnit(const uint32_t* __restrict__ cand, const int* _
 template <int NMAX, int QMAX>
 __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict__ cand, const int* __restrict__ cellCount,
                                                      const OctLaunch P, SelKp* __restrict__ selStage,
-                                                     int* __restrict__ nselLevel, uint8_t* __restrict__ scratch) {
+                                                     int* __restrict__ nselLevel, uint8_t* __restrict__ scratch,
+                                                     int* __restrict__ maxN) {
   constexpr int MCAP = 4 * QMAX, FCAP = 2 * QMAX;
   static_assert((NMAX & (NMAX - 1)) == 0 && (MCAP & (MCAP - 1)) == 0, "sort buffers must be powers of two");
-  // LDS budget (NMAX 2048, QMAX 256): 16 + 8 + 8 + 12 + 4 + 3 KB = 51 KB -> three workgroups per CU.
+  // LDS budget (QMAX 256): NMAX 2048: 16 + 8 + 8 + 12 + 4 + 3 KB = 51 KB -> three workgroups per CU;
+  //                        NMAX 1024:  8 + 8 + 4 + 12 + 2 + 3 KB = 37 KB -> four (launch_octree picks the instance).
   //   nodes[] is dead once the node records exist, so the partial pass's buffers (sized, pending, childCnt) live in it;
   //   hiOf[] (steps 3-4) shares its space with the candidate position list (step 1 only).
-  __shared__ u64 keys[NMAX];
-  __shared__ u64 nodes[MCAP];
+  __shared__ u64 keysNodes[NMAX + MCAP];
+  u64* keys = keysNodes;
+  u64* nodes = keysNodes + NMAX;
   __shared__ uint32_t candL[NMAX];
   __shared__ int nodeLo[MCAP + FCAP], nodeHi[MCAP + FCAP];
   __shared__ uint8_t div[NMAX + 4], alone[NMAX];
@@ -919,15 +930,18 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   uint32_t* hiOf = candL;
   const int level = blockIdx.y, f = blockIdx.x + P.frame0;  // level-major dispatch, see launch_octree
   int* nOut = &nselLevel[f * P.nlevels + level];
-  static_assert(NMAX >= OCT_SORT_LDS, "keys[] doubles as the sort exchange buffer of the global-scratch path");
+  static_assert(NMAX + MCAP >= OCT_SORT_LDS, "keys[] + nodes[] double as the sort exchange buffer of the global-scratch path");
   __shared__ int redo;
   __shared__ int gws[OCT_T / 64];
   const uint32_t* segBase = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
   const int* cellCnt = cellCount + (int64_t)f * P.nCellsTotal + P.lev[level].cellBase;
   const int n = gatherCandidates(cellCnt, P.lev[level].nCells, P.lev[level].segCap, candL, NMAX, threadIdx.x, gws);
+  if (threadIdx.x == 0 && maxN) atomicMax(&maxN[level], n);  // feedback for the next batch's choice of instance
   if (n <= NMAX && P.lev[level].quota <= QMAX) {
+    constexpr int PARCAP = OCT_PAR_SCR_FOR(512) <= NMAX ? 512 : 256;  // what fits into candL[NMAX]
+    static_assert(OCT_PAR_SCR_FOR(PARCAP) <= NMAX, "parallel-replay scratch must fit into the position list's space");
     OctScratch S{keys, nodes, div, alone, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, childCnt, candL, segBase, nullptr,
-                 candL /* hiOf / position list space: dead during the partial pass */};
+                 candL /* hiOf / position list space: dead during the partial pass */, PARCAP};
     octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, MCAP, FCAP, QMAX);
     __syncthreads();
     if (threadIdx.x == 0) redo = (*nOut == -2);  // a node table overflowed the LDS layout
@@ -936,7 +950,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   }
   // the unit does not fit the LDS layout: same workgroup, global scratch (no second kernel on the stream's critical path)
   __syncthreads();
-  octreeGlobalUnit(cand, cellCount, P, selStage, nselLevel, scratch, level, f, keys);
+  octreeGlobalUnit(cand, cellCount, P, selStage, nselLevel, scratch, level, f, keysNodes);
 }
 
 // global-scratch variant for the (frame, level) units the LDS variant left (nselLevel == -2), or for all units when
@@ -965,8 +979,14 @@ size_t octScratchBytes(int nMax, int qMax) {
 // compacts the per-level staging lists of every frame into level-major order and writes the per-frame totals
 __global__ __launch_bounds__(256) void k_sel_compact(const SelKp* __restrict__ selStage, const int* __restrict__ nselLevel,
                                                      const OctLaunch P, SelKp* __restrict__ sel, int* __restrict__ nsel,
-                                                     int selCap, int* __restrict__ err) {
+                                                     int selCap, int* __restrict__ err, int* __restrict__ maxN,
+                                                     int* __restrict__ hostMaxN) {
   const int f = blockIdx.x + P.frame0;
+  // per-level candidate maxima of this launch go to pinned host memory and are reset for the next one
+  if (blockIdx.x == 0 && maxN && threadIdx.x < P.nlevels) {
+    hostMaxN[threadIdx.x] = maxN[threadIdx.x];
+    maxN[threadIdx.x] = 0;
+  }
   __shared__ int off[ORBX_MAX_LEVELS + 1];
   if (threadIdx.x == 0) {
     int acc = 0;
@@ -989,20 +1009,27 @@ __global__ __launch_bounds__(256) void k_sel_compact(const SelKp* __restrict__ s
 }
 
 hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, const int* cellCount, const OctLaunch& P,
-                         SelKp* selStage, int* nselLevel, uint8_t* scratch, int maxQuota) {
+                         SelKp* selStage, int* nselLevel, uint8_t* scratch, int maxQuota, int* maxN, int nHint) {
   // workgroups are dispatched x-fastest: all frames of level 0 first, then level 1, ...  The units of the lowest levels
   // run longest (most candidates, largest quota), so this is longest-processing-time-first and keeps the tail short.
   dim3 grid(nFrames, P.nlevels, 1), block(OCT_T, 1, 1);
   const bool lds = maxQuota <= 256;
   // the LDS variant handles units it cannot take (more than 2048 candidates, node-table overflow) itself on global scratch
-  if (lds) hipLaunchKernelGGL((k_octree_lds<2048, 256>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch);
+  // nHint = largest candidate count of a unit in the previous batch (0 = unknown): with 6 % headroom below 1024 the
+  // smaller instance runs four workgroups per CU instead of three; a unit that outgrows it is still handled correctly
+  // (global scratch), only slower
+  static const bool noSmall = getenv("ORBX_OCT_NO_SMALL") != nullptr;  // diagnostics: always the 2048-candidate instance
+  if (lds && nHint > 0 && nHint <= 960 && !noSmall)
+    hipLaunchKernelGGL((k_octree_lds<1024, 256>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN);
+  else if (lds)
+    hipLaunchKernelGGL((k_octree_lds<2048, 256>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN);
   else hipLaunchKernelGGL(k_octree_global, grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, 1);
   return hipGetLastError();
 }
 
 hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage, const int* nselLevel, const OctLaunch& P,
-                              SelKp* sel, int* nsel, int selCap, int* err) {
-  hipLaunchKernelGGL(k_sel_compact, dim3(nFrames), dim3(256), 0, st, selStage, nselLevel, P, sel, nsel, selCap, err);
+                              SelKp* sel, int* nsel, int selCap, int* err, int* maxN, int* hostMaxN) {
+  hipLaunchKernelGGL(k_sel_compact, dim3(nFrames), dim3(256), 0, st, selStage, nselLevel, P, sel, nsel, selCap, err, maxN, hostMaxN);
   return hipGetLastError();
 }
 
@@ -1025,7 +1052,7 @@ __global__ __launch_bounds__(OCT_T) void k_debug_sort(int* triples, int n, u64* 
   if (n <= OCT_PAR_MAX) {  // the workgroup-parallel replay works on LDS keys, as in the selection kernels
     for (int j = tid; j < n; j += OCT_T) parKeys[j] = a[j];
     __syncthreads();
-    stdSortPartitionPhasePar(parKeys, n, tid, parScr, parWs);
+    stdSortPartitionPhasePar(parKeys, n, tid, parScr, parWs, n <= 256 && (n & 1) ? 256 : OCT_PAR_MAX);  // both layouts get exercised
     __syncthreads();
     for (int j = tid; j < n; j += OCT_T) a[j] = parKeys[j];
   } else {
