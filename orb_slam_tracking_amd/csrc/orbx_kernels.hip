@@ -499,15 +499,19 @@ constexpr IcTables makeIcTables() {
 }
 __device__ const IcTables d_ic = makeIcTables();
 
-__global__ __launch_bounds__(64) void k_describe_patch(const uint8_t* __restrict__ img0, long long img0FrameStride,
+#define DESC_WAVES 4   // keypoints (= waves) per workgroup: consecutive keypoints of a frame's list are spatially close, so
+                       // putting them on one CU lets their overlapping windows hit in that CU's L1
+__global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_t* __restrict__ img0, long long img0FrameStride,
                                                        int img0Aligned, const uint8_t* __restrict__ pyr, const Geom g,
                                                        const SelKp* __restrict__ sel, const int* __restrict__ nsel,
                                                        orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                        int capacity) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds[PW_WAVE_WORDS];
-  const int f = blockIdx.y + g.frame0, lane = threadIdx.x;
-  const int i = blockIdx.x;
-  if (i >= nsel[f]) return;  // uniform; the workgroup is one wave
+  __shared__ __attribute__((aligned(16))) uint32_t ldsAll[DESC_WAVES][PW_WAVE_WORDS];
+  static_assert(PW_WAVE_WORDS % 4 == 0, "every wave's LDS slice must stay 16-byte aligned");
+  const int f = blockIdx.y + g.frame0, lane = threadIdx.x & 63;
+  uint32_t* const lds = ldsAll[threadIdx.x >> 6];
+  const int i = blockIdx.x * DESC_WAVES + (threadIdx.x >> 6);
+  if (i >= nsel[f]) return;  // wave-uniform; the waves of a workgroup never synchronise with each other
   // Loads that do not depend on the keypoint are issued first, so that their latency runs under the window fetch: the
   // disc-row weights of IC_Angle (lane = disc row) and this lane's four point pairs of the BRIEF pattern.
   const int icRow = min(lane, 30), icAv = icRow < 15 ? 15 - icRow : icRow - 15;
@@ -1627,7 +1631,7 @@ hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const 
                                  int img0Aligned, const uint8_t* pyr, const Geom& g, const SelKp* sel, const int* nsel,
                                  orbx_keypoint* kps, uint8_t* desc, int capacity) {
   if (maxSel <= 0) return hipSuccess;
-  dim3 block(64, 1, 1), grid(maxSel, nFrames, 1);
+  dim3 block(64 * DESC_WAVES, 1, 1), grid((maxSel + DESC_WAVES - 1) / DESC_WAVES, nFrames, 1);
   hipLaunchKernelGGL(k_describe_patch, grid, block, 0, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps, desc,
                      capacity);
   return hipGetLastError();
