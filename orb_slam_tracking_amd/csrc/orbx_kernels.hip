@@ -499,8 +499,9 @@ constexpr IcTables makeIcTables() {
 }
 __device__ const IcTables d_ic = makeIcTables();
 
-#define DESC_WAVES 4   // keypoints (= waves) per workgroup: consecutive keypoints of a frame's list are spatially close, so
-                       // putting them on one CU lets their overlapping windows hit in that CU's L1
+#define DESC_WAVES 3   // keypoints (= waves) per workgroup: consecutive keypoints of a frame's list are spatially close, so
+                       // putting them on one CU lets their overlapping windows hit in that CU's L1 (1: 0.44 ms, 2: 0.38,
+                       // 3: 0.365, 4: 0.39, 8: 0.44, 16: 0.63 per 256 frames; 3 slices of 5.8 KB keep 27 waves per CU)
 __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_t* __restrict__ img0, long long img0FrameStride,
                                                        int img0Aligned, const uint8_t* __restrict__ pyr, const Geom g,
                                                        const SelKp* __restrict__ sel, const int* __restrict__ nsel,
