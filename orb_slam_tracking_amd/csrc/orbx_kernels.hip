@@ -511,7 +511,12 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   static_assert(PW_WAVE_WORDS % 4 == 0, "every wave's LDS slice must stay 16-byte aligned");
   const int f = blockIdx.y + g.frame0, lane = threadIdx.x & 63;
   uint32_t* const lds = ldsAll[threadIdx.x >> 6];
-  const int i = blockIdx.x * DESC_WAVES + (threadIdx.x >> 6);
+  // XCD-aware order: workgroups go round-robin to the 8 XCDs (the grid's x size is a multiple of 8); workgroup b takes
+  // keypoint group (b % 8) * chunk + b / 8, so that one XCD works on a contiguous eighth of the frame's keypoint list
+  // (mostly one pyramid level) and its L2 holds that part of the pyramid only.  Every keypoint costs the same, so the
+  // XCDs stay balanced.
+  const int grp = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int i = grp * DESC_WAVES + (threadIdx.x >> 6);
   if (i >= nsel[f]) return;  // wave-uniform; the waves of a workgroup never synchronise with each other
   // Loads that do not depend on the keypoint are issued first, so that their latency runs under the window fetch: the
   // disc-row weights of IC_Angle (lane = disc row) and this lane's four point pairs of the BRIEF pattern.
@@ -1632,7 +1637,7 @@ hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const 
                                  int img0Aligned, const uint8_t* pyr, const Geom& g, const SelKp* sel, const int* nsel,
                                  orbx_keypoint* kps, uint8_t* desc, int capacity) {
   if (maxSel <= 0) return hipSuccess;
-  dim3 block(64 * DESC_WAVES, 1, 1), grid((maxSel + DESC_WAVES - 1) / DESC_WAVES, nFrames, 1);
+  dim3 block(64 * DESC_WAVES, 1, 1), grid(((maxSel + DESC_WAVES - 1) / DESC_WAVES + 7) / 8 * 8, nFrames, 1);  // x: multiple of 8
   hipLaunchKernelGGL(k_describe_patch, grid, block, 0, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps, desc,
                      capacity);
   return hipGetLastError();
