@@ -126,70 +126,93 @@ __global__ __launch_bounds__(256) void k_pyramid_bands(const uint8_t* __restrict
     const int r0 = pb.r0[band][l], r1 = pb.r1[band][l];
     const int sw = S.w, sh = S.h, sstride = S.stride, dstride = D.stride;
     const int ng = (D.w + 3) >> 2;               // groups of 4 output pixels per row
-    const int items = (r1 - r0) * ng;
-    // Four items (row, group of 4 pixels) per thread and step, so that their table and source loads are in flight together
-    // (the loop is bound by memory latency, not by arithmetic).  item -> (row, group) without a division per item:
-    // item += 1024  <=>  (gx, dy) += (1024 % ng, 1024 / ng).
-    int dyv[4], gxv[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int it0 = tid + 256 * j;
-      dyv[j] = it0 / ng;
-      gxv[j] = it0 - dyv[j] * ng;
-      dyv[j] += r0;
-    }
-    const int stepY = 1024 / ng, stepX = 1024 - stepY * ng;
+    // A thread keeps its column(s): it owns G adjacent groups (8 or 4 output pixels) of one thread-column and walks down the
+    // band's rows, so the x table entries of its pixels are loaded ONCE per level and stay in registers (they were 40 of
+    // the 64 bytes every item pulled through L1).  rpp rows are in flight per pass; G = 2 when a row has more than 128
+    // groups keeps the workgroup's lanes busy (134 groups: 67 thread-columns x 3 rows = 201 of 256 lanes).
+    const int G = ng > 128 ? 2 : 1;
+    const int ngt = (ng + G - 1) / G;
+    const int rpp = max(256 / ngt, 1);
+    const int rsub = tid / ngt, col = tid - rsub * ngt;
+    const bool lanes = rsub < rpp;
     const int lim = (sw - 1) & ~3;  // last dword that holds a pixel of the row: never read beyond it
-    for (int item = tid; item < items; item += 1024) {
-      ResizeTab ty[4];
-      uint4 tA[4], tB[4];
-      uint32_t ra[4][3], rb[4][3];  // three consecutive dwords of each source row hold all taps of the 4 outputs
-      bool live[4];
+    uint4 tA[2], tB[2];
+    bool haveG[2];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        live[j] = item + 256 * j < items;
-        // unsigned 32-bit offsets from uniform base pointers: SGPR base + VGPR offset addressing, no 64-bit address math
-        ty[j] = ytab[(unsigned)(live[j] ? dyv[j] : r0)];
-        const unsigned dx0 = (unsigned)(live[j] ? gxv[j] : 0) * 4u;
-        tA[j] = *reinterpret_cast<const uint4*>(xtabB + dx0 * 8u);
-        tB[j] = *reinterpret_cast<const uint4*>(xtabB + dx0 * 8u + 16u);
+    for (int j = 0; j < 2; j++) {
+      const int gx = col * G + j;
+      haveG[j] = lanes && j < G && gx < ng;
+      const unsigned dx0 = (unsigned)(haveG[j] ? gx : 0) * 4u;
+      tA[j] = *reinterpret_cast<const uint4*>(xtabB + dx0 * 8u);
+      tB[j] = *reinterpret_cast<const uint4*>(xtabB + dx0 * 8u + 16u);
+    }
+    // what depends on the x tables only is computed once per level: the byte selector of every pixel's tap pair and
+    // whether the pair starts in the first or the second staged dword
+    uint32_t selv[2][4], cfs[2][4];
+    bool upv[2][4];
+    int basev[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int sxs[4] = {(int)tA[j].x, (int)tA[j].z, (int)tB[j].x, (int)tB[j].z};
+      cfs[j][0] = tA[j].y; cfs[j][1] = tA[j].w; cfs[j][2] = tB[j].y; cfs[j][3] = tB[j].w;
+      basev[j] = sxs[0] & ~3;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int k = sxs[i] - basev[j];  // 0..10: byte offset of the left tap inside the 12 staged bytes
+        // taps k, k+1 come from dwords (0,1) when k <= 6, else from dwords (1,2); v_perm_b32 picks the two bytes as the
+        // u16 halves (0x0c = constant 0) and v_dot2_u32_u16 applies the Q11 pair (c0 | c1 << 16)
+        upv[j][i] = k > 6;
+        selv[j][i] = (uint32_t)(upv[j][i] ? k - 4 : k) * 0x00010001u + 0x0c010c00u;
+      }
+    }
+    for (int dy0 = r0 + rsub; dy0 < r1; dy0 += 2 * rpp) {  // two rows per step: their loads are in flight together
+      ResizeTab ty[2];
+      bool liveR[2];
+      uint32_t ra[2][2][3], rb[2][2][3];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int dy = dy0 + q * rpp;
+        liveR[q] = lanes && dy < r1;
+        ty[q] = ytab[(unsigned)(liveR[q] ? dy : r0)];
       }
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int sy0 = min(max(ty[j].ofs, 0), sh - 1), sy1 = min(max(ty[j].ofs + 1, 0), sh - 1);
+      for (int q = 0; q < 2; q++) {
+        const int sy0 = min(max(ty[q].ofs, 0), sh - 1), sy1 = min(max(ty[q].ofs + 1, 0), sh - 1);
         const unsigned S0 = (unsigned)(sy0 * sstride), S1 = (unsigned)(sy1 * sstride);
-        // a dword beyond the row's last one is replaced by the last one and can only supply bytes whose weight is 0
-        const int base = (int)tA[j].x & ~3;
-        const unsigned o0 = (unsigned)base, o1 = (unsigned)min(base + 4, lim), o2 = (unsigned)min(base + 8, lim);
-        ra[j][0] = *reinterpret_cast<const uint32_t*>(src + (S0 + o0)); ra[j][1] = *reinterpret_cast<const uint32_t*>(src + (S0 + o1));
-        ra[j][2] = *reinterpret_cast<const uint32_t*>(src + (S0 + o2));
-        rb[j][0] = *reinterpret_cast<const uint32_t*>(src + (S1 + o0)); rb[j][1] = *reinterpret_cast<const uint32_t*>(src + (S1 + o1));
-        rb[j][2] = *reinterpret_cast<const uint32_t*>(src + (S1 + o2));
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          // a dword beyond the row's last one is replaced by the last one and can only supply bytes whose weight is 0
+          const int base = basev[j];
+          const unsigned o0 = (unsigned)base, o1 = (unsigned)min(base + 4, lim), o2 = (unsigned)min(base + 8, lim);
+          if (j < G) {
+            ra[q][j][0] = *reinterpret_cast<const uint32_t*>(src + (S0 + o0)); ra[q][j][1] = *reinterpret_cast<const uint32_t*>(src + (S0 + o1));
+            ra[q][j][2] = *reinterpret_cast<const uint32_t*>(src + (S0 + o2));
+            rb[q][j][0] = *reinterpret_cast<const uint32_t*>(src + (S1 + o0)); rb[q][j][1] = *reinterpret_cast<const uint32_t*>(src + (S1 + o1));
+            rb[q][j][2] = *reinterpret_cast<const uint32_t*>(src + (S1 + o2));
+          }
+        }
       }
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const uint32_t wy0 = ty[j].coef & 0xffff, wy1 = (uint32_t)ty[j].coef >> 16;
-        const int sxs[4] = {(int)tA[j].x, (int)tA[j].z, (int)tB[j].x, (int)tB[j].z};
-        const uint32_t cfs[4] = {tA[j].y, tA[j].w, tB[j].y, tB[j].w};
-        uint32_t packed = 0;
+      for (int q = 0; q < 2; q++) {
+        const int dy = dy0 + q * rpp;
+        const uint32_t wy0 = ty[q].coef & 0xffff, wy1 = (uint32_t)ty[q].coef >> 16;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int k = sxs[i] - (sxs[0] & ~3);  // 0..10: byte offset of the left tap inside the 12 staged bytes
-          // taps k, k+1 come from dwords (0,1) when k <= 6, else from dwords (1,2); v_perm_b32 picks the two bytes as the
-          // u16 halves (0x0c = constant 0) and v_dot2_u32_u16 applies the Q11 pair (c0 | c1 << 16)
-          const bool up = k > 6;
-          const uint32_t sel = (uint32_t)(up ? k - 4 : k) * 0x00010001u + 0x0c010c00u;
-          const uint32_t p0 = __builtin_amdgcn_perm(up ? ra[j][2] : ra[j][1], up ? ra[j][1] : ra[j][0], sel);
-          const uint32_t p1 = __builtin_amdgcn_perm(up ? rb[j][2] : rb[j][1], up ? rb[j][1] : rb[j][0], sel);
-          const uint32_t t0 = dot2u16(p0, cfs[i], 0u), t1 = dot2u16(p1, cfs[i], 0u);
-          uint32_t v = (((wy0 * (t0 >> 4)) >> 16) + ((wy1 * (t1 >> 4)) >> 16) + 2) >> 2;
-          v = min(v, 255u);
-          packed |= v << (8 * i);
+        for (int j = 0; j < 2; j++) {
+          if (j >= G) continue;
+          uint32_t packed = 0;
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const bool up = upv[j][i];
+            const uint32_t sel = selv[j][i];
+            const uint32_t p0 = __builtin_amdgcn_perm(up ? ra[q][j][2] : ra[q][j][1], up ? ra[q][j][1] : ra[q][j][0], sel);
+            const uint32_t p1 = __builtin_amdgcn_perm(up ? rb[q][j][2] : rb[q][j][1], up ? rb[q][j][1] : rb[q][j][0], sel);
+            const uint32_t t0 = dot2u16(p0, cfs[j][i], 0u), t1 = dot2u16(p1, cfs[j][i], 0u);
+            uint32_t v = (((wy0 * (t0 >> 4)) >> 16) + ((wy1 * (t1 >> 4)) >> 16) + 2) >> 2;
+            v = min(v, 255u);
+            packed |= v << (8 * i);
+          }
+          if (liveR[q] && haveG[j]) *reinterpret_cast<uint32_t*>(dst + (unsigned)(dy * dstride + (col * G + j) * 4)) = packed;
         }
-        if (live[j]) *reinterpret_cast<uint32_t*>(dst + (unsigned)(dyv[j] * dstride + gxv[j] * 4)) = packed;
-        gxv[j] += stepX;
-        dyv[j] += stepY;
-        if (gxv[j] >= ng) { gxv[j] -= ng; dyv[j]++; }
       }
     }
     // this band of level l is the source of the band of level l + 1 in the same workgroup: the barrier's workgroup-scope
