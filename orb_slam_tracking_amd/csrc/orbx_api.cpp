@@ -454,7 +454,7 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   // whole pyramid in one launch (k_pyramid_bands) when every level meets the dword path's preconditions and the batch
   // is large enough to fill the device with (bands x frames) workgroups; otherwise one launch per level
   bool banded = nl > 1 && a.aligned0 && n >= 32 && !getenv("ORBX_NO_BANDS");
-  for (int l = 1; l < nl && banded; l++) banded = g.L[l].resizeSpanOk && g.L[l].h < 32768;
+  for (int l = 1; l < nl && banded; l++) banded = g.L[l].resizeSpanOk && g.L[l].h < 32768 && g.L[l].w <= 2048;
   if (banded) {
     StageTimer tm(ctx, ORBX_STAGE_PYRAMID, si, st);
     const PyrBands pb = computePyrBands(ctx, n >= 64 ? 8 : 16);

@@ -130,8 +130,12 @@ __global__ __launch_bounds__(256) void k_pyramid_bands(const uint8_t* __restrict
     // band's rows, so the x table entries of its pixels are loaded ONCE per level and stay in registers (they were 40 of
     // the 64 bytes every item pulled through L1).  rpp rows are in flight per pass; G = 2 when a row has more than 128
     // groups keeps the workgroup's lanes busy (134 groups: 67 thread-columns x 3 rows = 201 of 256 lanes).
-    const int G = ng > 128 ? 2 : 1;
-    const int ngt = (ng + G - 1) / G;
+    // G (1 or 2) = whichever fills more of the 256 lanes with whole rows.  (The host takes this kernel only when every
+    // level is at most 2048 pixels wide, i.e. at most 256 thread-columns of two groups.)
+    const int ngt2 = (ng + 1) >> 1;
+    const int use1 = ng <= 256 ? ng * (256 / ng) : 0, use2 = ngt2 * (256 / ngt2);
+    const int G = use2 > use1 ? 2 : 1;
+    const int ngt = G == 2 ? ngt2 : ng;
     const int rpp = max(256 / ngt, 1);
     const int rsub = tid / ngt, col = tid - rsub * ngt;
     const bool lanes = rsub < rpp;

@@ -613,11 +613,13 @@ def test_random_geometries_batched(orbx, oracle):
     from orb_slam_tracking_amd import synth
     rng = np.random.default_rng(77)
     cap, compared = 500, 0
-    for trial in range(6):
+    for trial in range(7):
         w = int(rng.integers(60, 120)) * 4           # 4-aligned rows: the dword / banded paths
         h = int(rng.integers(200, 400))
         B = int(rng.choice([33, 40, 64, 70]))
         params = (500, float(rng.choice([1.2, 1.1, 1.3])), int(rng.choice([4, 6, 8])), 20, 7)
+        if trial == 6:  # a level wider than 2048 pixels: the batch takes the per-level pyramid launches, not k_pyramid_bands
+            w, h, B, params = 2560, 160, 33, (500, 1.2, 3, 20, 7)
         oe = oracle.Extractor(*params)
         try:
             e = orbx.ORBextractor(*params, max_width=w, max_height=h, max_batch=B)
@@ -646,4 +648,4 @@ def test_random_geometries_batched(orbx, oracle):
                 assert np.array_equal(e.image_pyramid(l, f), oe.level_image(l)), (w, h, B, params, f, l)
         compared += 1
         e.close()
-    assert compared >= 4
+    assert compared >= 5
