@@ -217,6 +217,9 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
 /* The device's literal replay of libstdc++ std::sort with the reference's compareNodes (cpp:684-696, 912) on n
  * (count, UL.x, id) int32 triples, in place. */
 int orbx_debug_std_sort(orbx_ctx* ctx, int32_t* triples, int n);
+/* The (cos, sin) pair the descriptor kernel uses for a keypoint angle in degrees (f64 evaluation rounded to f32,
+ * cpp:173-174), for n angles; host pointers. */
+int orbx_debug_sincos(orbx_ctx* ctx, const float* angle_deg, int n, float* cos_out, float* sin_out);
 
 #ifdef __cplusplus
 }

@@ -964,6 +964,9 @@ void orbo_sincos_deg(float angle_deg, float* c, float* s) {
   const float a = angle_deg * factorPI;
   *c = (float)std::cos((double)a); *s = (float)std::sin((double)a);
 }
+void orbo_sincos_deg_batch(const float* angle_deg, int n, float* c, float* s) {  // cpp:173-174 for many angles
+  for (int i = 0; i < n; i++) orbo_sincos_deg(angle_deg[i], &c[i], &s[i]);
+}
 int orbo_hamming(const uint8_t* a, const uint8_t* b) { return hamming256(a, b); }
 void orbo_pos_in_grid(const KP* k, int n, const int32_t* bounds4, int* px, int* py, int* ok) {
   Bounds b{bounds4[0], bounds4[1], bounds4[2], bounds4[3]};

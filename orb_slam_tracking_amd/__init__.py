@@ -107,6 +107,7 @@ def lib() -> ctypes.CDLL:
     L.orbx_debug_distribute.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32]
     L.orbx_debug_distribute_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32]
     L.orbx_debug_std_sort.argtypes = [vp, vp, i32]
+    L.orbx_debug_sincos.argtypes = [vp, vp, i32, vp, vp]
     _LIB = L
     return L
 
@@ -378,6 +379,12 @@ class ORBextractor:
         t = np.ascontiguousarray(triples, np.int32).reshape(-1, 3).copy()
         self._check(self._L.orbx_debug_std_sort(self._h, _ptr(t), len(t)))
         return t
+
+    def debug_sincos(self, angles_deg: np.ndarray):
+        a = np.ascontiguousarray(angles_deg, np.float32)
+        c, s = np.zeros(len(a), np.float32), np.zeros(len(a), np.float32)
+        self._check(self._L.orbx_debug_sincos(self._h, _ptr(a), len(a), _ptr(c), _ptr(s)))
+        return c, s
 
     def debug_candidates(self, frame: int, level: int) -> np.ndarray:
         n = self._check(self._L.orbx_debug_candidates(self._h, frame, level, None, 0))

@@ -41,6 +41,7 @@ size_t octScratchBytes(int nMax, int qMax);
 hipError_t launch_to_gray(hipStream_t st, int nFrames, const uint8_t* src, long long srcFrameStride, int sstride, int w, int h,
                           int channels, int rgb, uint8_t* dst, long long dstFrameStride, int dstride);
 hipError_t launch_check_model(hipStream_t st, int nModels, const ScoreArgs& a);
+hipError_t launch_debug_sincos(hipStream_t st, const float* angle, int n, float* c, float* s);
 hipError_t launch_undistort(hipStream_t st, int nFrames, const orbx_keypoint* in, const int* nkp, int capacity, const CamD& c,
                             orbx_keypoint* out);
 
@@ -1305,6 +1306,25 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
 }
 
 // runs the device replay of libstdc++'s std::sort on n (count, ulx, id) triples in place
+int orbx_debug_sincos(orbx_ctx* ctx, const float* angle_deg, int n, float* cos_out, float* sin_out) {
+  if (!ctx || n < 0 || (n > 0 && (!angle_deg || !cos_out || !sin_out))) return ORBX_E_BADARG;
+  if (n == 0) return ORBX_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  float* d = nullptr;
+  auto body = [&]() -> int {
+    HIPCHK(hipMalloc((void**)&d, (size_t)n * 3 * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(d, angle_deg, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(launch_debug_sincos(ctx->st, d, n, d + n, d + 2 * (size_t)n));
+    HIPCHK(hipMemcpyAsync(cos_out, d + n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(sin_out, d + 2 * (size_t)n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    return ORBX_OK;
+  };
+  const int rc = body();
+  if (d) (void)hipFree(d);
+  return rc;
+}
+
 int orbx_debug_std_sort(orbx_ctx* ctx, int32_t* triples, int n) {
   if (!ctx || n < 0 || (n > 0 && !triples)) return ORBX_E_BADARG;
   if (n == 0) return ORBX_OK;

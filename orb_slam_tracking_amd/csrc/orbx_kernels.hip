@@ -1607,6 +1607,22 @@ hipError_t launch_to_gray(hipStream_t st, int nFrames, const uint8_t* src, long 
   return hipGetLastError();
 }
 
+// test hook: the cos / sin pair of k_describe_patch for arbitrary angles (degrees)
+__global__ __launch_bounds__(256) void k_debug_sincos(const float* __restrict__ angle, int n, float* __restrict__ c, float* __restrict__ s) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float factorPI = (float)(3.14159265358979323846 / 180.f);
+  double sd, cd;
+  sincos((double)(angle[i] * factorPI), &sd, &cd);
+  c[i] = (float)cd;
+  s[i] = (float)sd;
+}
+hipError_t launch_debug_sincos(hipStream_t st, const float* angle, int n, float* c, float* s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_debug_sincos, dim3((n + 255) / 256), dim3(256), 0, st, angle, n, c, s);
+  return hipGetLastError();
+}
+
 hipError_t launch_check_model(hipStream_t st, int nModels, const ScoreArgs& a) {
   if (nModels <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_check_model, dim3(nModels), dim3(64), 0, st, a);

@@ -360,3 +360,14 @@ def scoring_case(seed=0, n=400, n_models=24):
         tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
         F21.append(Ki.T @ tx @ R @ Ki)
     return k1, k2, m12, H21.astype(np.float32), H12.astype(np.float32), np.stack(F21).astype(np.float32)
+
+
+def sincos_deg_batch(angles: np.ndarray):
+    """cos / sin of computeOrbDescriptor (cpp:173-174) for many angles: (float)cos((double)(angle * factorPI))."""
+    a = np.ascontiguousarray(angles, np.float32)
+    c, sn = np.zeros(len(a), np.float32), np.zeros(len(a), np.float32)
+    L = lib()
+    L.orbo_sincos_deg_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.orbo_sincos_deg_batch.restype = None
+    L.orbo_sincos_deg_batch(_p(a), len(a), _p(c), _p(sn))
+    return c, sn

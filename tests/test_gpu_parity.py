@@ -649,3 +649,28 @@ def test_random_geometries_batched(orbx, oracle):
         compared += 1
         e.close()
     assert compared >= 5
+
+
+def test_sincos_matches_libm(orbx, ext640, oracle):
+    """The descriptor's cos / sin (f64 evaluation of the f32 angle, rounded to f32, cpp:173-174): the device's f64 sincos and
+    the host libm agree after the rounding for every angle fastAtan2 can produce that is tried here -- all 360 * 2^7
+    multiples of 1/128 degree, the neighbourhoods of the multiples of 45 degrees float by float, and 3 million random
+    floats in [0, 360]."""
+    rng = np.random.default_rng(2)
+    parts = [np.arange(0, 360 * 128 + 1, dtype=np.float32) / np.float32(128)]
+    for m in range(0, 361, 45):
+        c = np.float32(m)
+        lo = c
+        vals = [c]
+        up = c
+        for _ in range(2000):
+            lo = np.nextafter(lo, np.float32(-1))
+            up = np.nextafter(up, np.float32(400))
+            vals += [lo, up]
+        parts.append(np.array([v for v in vals if 0 <= v <= 360], np.float32))
+    parts.append(rng.uniform(0, 360, 3_000_000).astype(np.float32))
+    a = np.concatenate(parts)
+    c, s = ext640.debug_sincos(a)
+    ec, es = oracle.sincos_deg_batch(a)
+    bad = np.nonzero((c != ec) | (s != es))[0]
+    assert len(bad) == 0, (len(bad), a[bad[:5]], c[bad[:5]], ec[bad[:5]], s[bad[:5]], es[bad[:5]])
