@@ -1,11 +1,12 @@
 // orbx_api.cpp — host side of liborbx: context, per-batch pipeline and the C ABI of include/orbx.h.
 //
-// Pipeline of one batch (B frames, all on one HIP stream):
-//   k_resize x (nlevels-1)  ->  k_fast (all cells of all levels of all frames)
-//   -> k_octree_* (quadtree selection, one workgroup per frame x level) -> k_sel_compact
-//   -> k_describe (orientation + blur + descriptors) -> results stay in HBM (device API) or D2H (host API)
-// and, for matching, k_match with one workgroup per frame pair.  No host round trip inside a batch: the host only
-// issues the launches and reads two error flags + the per-frame counts at the end.
+// Pipeline of one batch (a large batch is cut into two halves that run as independent chains on two HIP streams):
+//   k_pyramid_bands (or k_resize_dw x (nlevels-1))  ->  k_fast (all cells of all levels of all frames)
+//   -> k_octree_lds / k_octree_global (quadtree selection, one workgroup per frame x level) -> k_sel_compact
+//   -> k_describe_patch (orientation + blur + descriptors) -> results stay in HBM (device API) or D2H (host API)
+// and, for matching, k_match_jacobi (-> k_match_wave -> k_match for pairs it cannot take) with one workgroup per frame
+// pair.  No host round trip inside a batch: the host only issues the launches and reads two error flags + the per-frame
+// counts at the end.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -1,13 +1,18 @@
 // orbx_kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) for the ORB tracking hot path.
 //
-//   k_resize    pyramid level l from level l-1      (ORBextractor::ComputePyramid, cpp:1660-1713 -> cv::resize)
-//   k_fast      per-cell FAST-9-16 + in-cell NMS + threshold fallback
+//   k_pyramid_bands   the whole pyramid of a batch in one launch, row bands with halos (k_resize_dw / k_resize: one
+//                     level per launch, for small batches / unaligned input)
+//                                                    (ORBextractor::ComputePyramid, cpp:1660-1713 -> cv::resize)
+//   k_fast            per-cell FAST-9-16 + in-cell NMS + threshold fallback, survivors into per-cell segments
 //                                                    (ComputeKeyPointsOctTree cell loops, cpp:1078-1141 -> cv::FAST)
 //   k_describe_patch  IC-angle + 7x7 Gaussian (patch-local, v_dot4/v_dot2 fixed point) + steered BRIEF, one wave per
-//               keypoint                              (IC_Angle cpp:103-159, GaussianBlur cpp:1598-1606,
+//                     keypoint                       (IC_Angle cpp:103-159, GaussianBlur cpp:1598-1606,
 //                                                     computeOrbDescriptor cpp:169-228, assembly cpp:1557-1652)
-//   k_match     SearchForInitialization, one workgroup per frame pair
+//   k_match_jacobi / k_match_wave / k_match   SearchForInitialization, one workgroup per frame pair
 //                                                    (ORBmatcher.cpp:11-183, Frame.cpp:89-99,163-206, FORB.cpp:77-101)
+//   k_undistort, k_to_gray, k_check_model     the steps around the path (Frame.cpp:101-161, Converter.cpp:5-19,
+//                                                     Initializer.cpp:268-438)
+//   (the quadtree selection lives in orbx_octree_kernel.hip)
 //
 // All arithmetic is integer or uncontracted IEEE f32/f64 (compile with -ffp-contract=off) so the results are
 // bit-identical to the CPU restatement in oracle/.  No MFMA: there is no dense contraction on this path.
