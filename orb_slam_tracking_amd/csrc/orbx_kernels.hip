@@ -8,7 +8,7 @@
 //   k_describe_patch  IC-angle + 7x7 Gaussian (patch-local, v_dot4/v_dot2 fixed point) + steered BRIEF, one wave per
 //                     keypoint                       (IC_Angle cpp:103-159, GaussianBlur cpp:1598-1606,
 //                                                     computeOrbDescriptor cpp:169-228, assembly cpp:1557-1652)
-//   k_match_jacobi / k_match_wave / k_match   SearchForInitialization, one workgroup per frame pair
+//   k_match_jacobi (two instances) / k_match   SearchForInitialization, one workgroup per frame pair
 //                                                    (ORBmatcher.cpp:11-183, Frame.cpp:89-99,163-206, FORB.cpp:77-101)
 //   k_undistort, k_to_gray, k_check_model     the steps around the path (Frame.cpp:101-161, Converter.cpp:5-19,
 //                                                     Initializer.cpp:268-438)
@@ -18,6 +18,7 @@
 // bit-identical to the CPU restatement in oracle/.  No MFMA: there is no dense contraction on this path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 
 #include "../../include/orbx.h"
@@ -784,25 +785,32 @@ __device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const 
 // double-decrement quirk) follows from the final outcomes: a train belongs to its LAST claimant.
 // All threads walk the trains together, so train data are LDS broadcasts.
 // -------------------------------------------------------------------------------------------------
-#define MJ_CAP 256    // queries / trains per pair
-#define MJ_P 4        // threads per query: thread t works for query t % MJ_CAP on the trains e with e % MJ_P == t / MJ_CAP
-#define MJ_T (MJ_CAP * MJ_P)
+// Two instances (launch_match):
+//   <256, 4, 24, lists in LDS>     up to 256 octave-0 queries / eligible trains per pair, four threads per query;
+//   <512, 2, 64, lists in global>  up to 512 (frames of the 2 x nFeatures initialisation extractor), two threads per query,
+//                                  candidate lists in the pair's global scratch (L2-resident); takes only the pairs the first
+//                                  instance marked MATCH_PENDING.
+// MJ_CAP = queries / trains per pair, MJ_P = threads per query (thread t works for query t % MJ_CAP on the trains e with
+// e % MJ_P == t / MJ_CAP), MJ_CP = trains inside one query's window per part (a fuller window hands the pair on).
 #define MJ_K 4
 #define MJ_SWEEPS 64
-#define MJ_CP 24      // trains inside one query's window, per part (a fuller window hands the pair to the sequential kernels)
+#define MJ_LARGE_SCRATCH_INTS (2 * 64 * 512)  // candidate lists of the large instance, per pair
 
-__global__ __launch_bounds__(MJ_T) void k_match_jacobi(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
-                                                       const orbx_keypoint* __restrict__ kps,
-                                                       const uint8_t* __restrict__ desc, const int* __restrict__ nkp,
-                                                       const MatchParams mp, int* __restrict__ matches12,
-                                                       int* __restrict__ nmatchesOut, int* __restrict__ statsOut) {
+template <int MJ_CAP, int MJ_P, int MJ_CP, bool GLOBAL_LISTS>
+__global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
+                                                               const orbx_keypoint* __restrict__ kps,
+                                                               const uint8_t* __restrict__ desc, const int* __restrict__ nkp,
+                                                               const MatchParams mp, int* __restrict__ matches12,
+                                                               int* __restrict__ nmatchesOut, int* __restrict__ statsOut,
+                                                               int* __restrict__ scratch, long long scratchStride) {
+  constexpr int MJ_T = MJ_CAP * MJ_P;
   __shared__ float tX[MJ_CAP], tY[MJ_CAP], tAng[MJ_CAP];
   __shared__ uint32_t tDesc[8][MJ_CAP];
   __shared__ uint16_t tIdx[MJ_CAP];
   __shared__ uint8_t tCx[MJ_CAP], tCy[MJ_CAP];
   __shared__ int clCount[MJ_CAP], lastQ[MJ_CAP];
   __shared__ uint16_t clQ[MJ_CAP][MJ_K], clD[MJ_CAP][MJ_K];
-  __shared__ uint32_t candList[MJ_P * MJ_CP * MJ_CAP];  // [part][k][query]: dist << 8 | train slot
+  __shared__ uint32_t candLds[GLOBAL_LISTS ? 1 : MJ_P * MJ_CP * MJ_CAP];  // [part][k][query]: dist << 16 | train slot
   __shared__ uint32_t tOrd[MJ_CAP];                      // cell << 20 | F2 index: the reference's candidate order
   __shared__ unsigned long long pBest[MJ_P][MJ_CAP];     // per part: best key of the sweep
   __shared__ uint32_t pAux[MJ_P][MJ_CAP];                // per part: second-best distance (0xffff = none) | best train slot << 16
@@ -814,6 +822,8 @@ __global__ __launch_bounds__(MJ_T) void k_match_jacobi(const int* __restrict__ p
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int part = t / MJ_CAP, q = t - part * MJ_CAP;  // waves 0-3 = part 0, ...
   const int pair = blockIdx.x + mp.pair0;
+  if (GLOBAL_LISTS && nmatchesOut[pair] != MATCH_PENDING) return;  // already done by the first instance
+  uint32_t* const candList = GLOBAL_LISTS ? reinterpret_cast<uint32_t*>(scratch + (long long)pair * scratchStride) : candLds;
   const int fa = pairFirst[pair], fb = pairSecond[pair];
   const int n1 = nkp[fa], n2 = nkp[fb];
   const int cap = mp.capacity;
@@ -920,7 +930,7 @@ __global__ __launch_bounds__(MJ_T) void k_match_jacobi(const int* __restrict__ p
         int dist = 0;
 #pragma unroll
         for (int w = 0; w < 8; w++) dist += __popc(qd[w] ^ tDesc[w][e]);
-        if (nCand < MJ_CP) myList[nCand * MJ_CAP] = ((uint32_t)dist << 8) | (uint32_t)e;
+        if (nCand < MJ_CP) myList[nCand * MJ_CAP] = ((uint32_t)dist << 16) | (uint32_t)e;
         nCand++;
       }
     }
@@ -953,11 +963,11 @@ __global__ __launch_bounds__(MJ_T) void k_match_jacobi(const int* __restrict__ p
 #pragma unroll
       for (int j = 0; j < 4; j++) ce[j] = myList[min(k + j, MJ_CP - 1) * MJ_CAP];
 #pragma unroll
-      for (int j = 0; j < 4; j++) { cnt[j] = clCount[ce[j] & 255]; ord[j] = tOrd[ce[j] & 255]; }
+      for (int j = 0; j < 4; j++) { cnt[j] = clCount[ce[j] & 0xffff]; ord[j] = tOrd[ce[j] & 0xffff]; }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         if (k + j >= nCand) break;
-        const int e = ce[j] & 255, dist = (int)(ce[j] >> 8);
+        const int e = ce[j] & 0xffff, dist = (int)(ce[j] >> 16);
         // vMatchedDistance[e] as query q sees it: smallest distance of an earlier accepted query that chose e
         int md = INF_DIST;
         const int nc = min(cnt[j], MJ_K);
@@ -1072,213 +1082,14 @@ __global__ __launch_bounds__(MJ_T) void k_match_jacobi(const int* __restrict__ p
 }
 
 // -------------------------------------------------------------------------------------------------
-// k_match_wave: one WAVE per frame pair, everything the sequential query loop touches lives in LDS:
-// the octave-0 queries of F1 and the grid-eligible octave-0 trains of F2 (position, cell, angle, descriptor words
-// stored word-major so that lane e reading word w is bank-conflict free), vMatchedDistance, vnMatches21 and the
-// rotation bins.  No barriers inside the query loop (a single wave executes its LDS operations in order).
-// Pairs that do not fit (more than MW_CAP eligible trains / octave-0 queries, or n1 > MW_N1) are marked
-// MATCH_PENDING and done by the general kernel k_match right after.
+// k_match: the general kernel (any size; global scratch), for the pairs both k_match_jacobi instances handed on.
 // -------------------------------------------------------------------------------------------------
-#define MW_CAP 512
-#define MW_N1 4096
-
-__global__ __launch_bounds__(64) void k_match_wave(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
-                                                   const orbx_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
-                                                   const int* __restrict__ nkp, const MatchParams mp,
-                                                   int* __restrict__ matches12, int* __restrict__ nmatchesOut,
-                                                   int* __restrict__ statsOut) {
-  __shared__ float tX[MW_CAP], tY[MW_CAP], tAng[MW_CAP];
-  __shared__ uint32_t tDesc[8][MW_CAP];
-  __shared__ int tMd[MW_CAP], tM21[MW_CAP];
-  __shared__ uint16_t tIdx[MW_CAP], tCell[MW_CAP];
-  __shared__ float qX[MW_CAP], qY[MW_CAP], qAng[MW_CAP];
-  __shared__ uint32_t qDesc[MW_CAP][8];
-  __shared__ uint16_t qIdx[MW_CAP];
-  __shared__ uint8_t accBin[MW_N1];  // rotation bin per F1 index, 255 = not in rotHist
-  __shared__ int hist[HISTO_LENGTH];
-
-  const int lane = threadIdx.x;
-  const int pair = blockIdx.x + mp.pair0;
-  if (nmatchesOut[pair] != MATCH_PENDING) return;  // already done by k_match_jacobi
-  const int fa = pairFirst[pair], fb = pairSecond[pair];
-  const int n1 = nkp[fa], n2 = nkp[fb];
-  const int cap = mp.capacity;
-  const orbx_keypoint* k1 = kps + (long long)fa * cap;
-  const orbx_keypoint* k2 = kps + (long long)fb * cap;
-  const uint32_t* d1 = reinterpret_cast<const uint32_t*>(desc + (long long)fa * cap * 32);
-  const uint32_t* d2 = reinterpret_cast<const uint32_t*>(desc + (long long)fb * cap * 32);
-  int* m12 = matches12 + (long long)pair * cap;
-
-  const float wInv = (float)ORBX_GRID_COLS / (float)(mp.b.max_x - mp.b.min_x);  // Frame.cpp:46-47
-  const float hInv = (float)ORBX_GRID_ROWS / (float)(mp.b.max_y - mp.b.min_y);
-  const float fminX = (float)mp.b.min_x, fminY = (float)mp.b.min_y;
-
-  // ---- stage the eligible trains of F2 (index order kept) ----
-  int nT = 0;
-  bool fits = n1 <= MW_N1 && n2 <= 65535;
-  for (int j0 = 0; j0 < n2 && fits; j0 += 64) {
-    const int j = j0 + lane;
-    bool ok = false;
-    orbx_keypoint kp;
-    int cell = 0;
-    if (j < n2) {
-      kp = k2[j];
-      // Frame::PosInGrid (Frame.cpp:89-99) + the octave filter of GetFeaturesInArea (Frame.cpp:179,191)
-      const int px = (int)roundf((kp.x - fminX) * wInv), py = (int)roundf((kp.y - fminY) * hInv);
-      ok = kp.octave == 0 && px >= 0 && px < ORBX_GRID_COLS && py >= 0 && py < ORBX_GRID_ROWS;
-      cell = px * ORBX_GRID_ROWS + py;
-    }
-    const unsigned long long m = __ballot(ok);
-    const int pos = nT + __popcll(m & ((1ull << lane) - 1ull));
-    if (nT + __popcll(m) > MW_CAP) { fits = false; break; }
-    if (ok) {
-      tX[pos] = kp.x; tY[pos] = kp.y; tAng[pos] = kp.angle;
-      tIdx[pos] = (uint16_t)j; tCell[pos] = (uint16_t)cell;
-      tMd[pos] = INF_DIST; tM21[pos] = -1;
-#pragma unroll
-      for (int w = 0; w < 8; w++) tDesc[w][pos] = d2[(long long)j * 8 + w];
-    }
-    nT += __popcll(m);
-  }
-  // ---- stage the octave-0 queries of F1 ----
-  int nQ = 0;
-  for (int i0 = 0; i0 < n1 && fits; i0 += 64) {
-    const int i = i0 + lane;
-    bool ok = false;
-    orbx_keypoint kp;
-    if (i < n1) {
-      kp = k1[i];
-      ok = !(kp.octave > 0);  // ORBmatcher.cpp:38-39
-      accBin[i] = 255;
-      m12[i] = -1;
-    }
-    const unsigned long long m = __ballot(ok);
-    const int pos = nQ + __popcll(m & ((1ull << lane) - 1ull));
-    if (nQ + __popcll(m) > MW_CAP) { fits = false; break; }
-    if (ok) {
-      qX[pos] = kp.x; qY[pos] = kp.y; qAng[pos] = kp.angle; qIdx[pos] = (uint16_t)i;
-#pragma unroll
-      for (int w = 0; w < 8; w++) qDesc[pos][w] = d1[(long long)i * 8 + w];
-    }
-    nQ += __popcll(m);
-  }
-  if (!fits) {  // wave-uniform
-    if (lane == 0) nmatchesOut[pair] = MATCH_PENDING;
-    return;
-  }
-  if (lane < HISTO_LENGTH) hist[lane] = 0;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-
-  int nm = 0, badDist = 0, badRatio = 0, badOri = 0;
-  const float r = (float)mp.window;
-  const float factor = HISTO_LENGTH / 360.0f;
-  for (int q = 0; q < nQ; q++) {
-    const float x1 = qX[q], y1 = qY[q];
-    // cell window, Frame.cpp:167-177
-    const int minCX = max(0, (int)floorf((x1 - fminX - r) * wInv));
-    const int maxCX = min(ORBX_GRID_COLS - 1, (int)ceilf((x1 - fminX + r) * wInv));
-    const int minCY = max(0, (int)floorf((y1 - fminY - r) * hInv));
-    const int maxCY = min(ORBX_GRID_ROWS - 1, (int)ceilf((y1 - fminY + r) * hInv));
-    if (minCX >= ORBX_GRID_COLS || maxCX < 0 || minCY >= ORBX_GRID_ROWS || maxCY < 0) continue;
-    uint32_t qd[8];
-#pragma unroll
-    for (int w = 0; w < 8; w++) qd[w] = qDesc[q][w];
-    unsigned long long best = MATCH_NONE;  // dist << 32 | cell << 20 | train index
-    int second = INF_DIST, any = 0, bestE = -1;
-    for (int e = lane; e < nT; e += 64) {
-      const int c = tCell[e];
-      const int cx = c / ORBX_GRID_ROWS, cy = c - cx * ORBX_GRID_ROWS;
-      if (cx < minCX || cx > maxCX || cy < minCY || cy > maxCY) continue;
-      const float dx = tX[e] - x1, dy = tY[e] - y1;
-      if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
-      any = 1;
-      int dist = 0;
-#pragma unroll
-      for (int w = 0; w < 8; w++) dist += __popc(qd[w] ^ tDesc[w][e]);
-      if (tMd[e] <= dist) continue;  // ORBmatcher.cpp:67
-      const unsigned long long key = ((unsigned long long)dist << 32) | ((unsigned long long)c << 20) | (unsigned)tIdx[e];
-      if (key < best) {
-        second = min(second, (int)(best >> 32));
-        best = key;
-        bestE = e;
-      } else {
-        second = min(second, dist);
-      }
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      const unsigned long long ob = __shfl_xor(best, o);
-      const int os = __shfl_xor(second, o), oe = __shfl_xor(bestE, o);
-      any |= __shfl_xor(any, o);
-      const bool take = ob < best;
-      second = min(min(second, os), (int)((take ? best : ob) >> 32));
-      best = take ? ob : best;
-      bestE = take ? oe : bestE;
-    }
-    if (!any) continue;  // vIndices2.empty(), ORBmatcher.cpp:45
-    const int bestDist = (int)(best >> 32);
-    if (best == MATCH_NONE || bestDist > TH_LOW) { badDist++; continue; }
-    if ((float)bestDist > mp.nnratio * (float)second) { badRatio++; continue; }
-    // all lanes hold the same decision; lane 0 commits it
-    const int i1 = qIdx[q];
-    const int bestIdx2 = (int)(best & 0xFFFFF);
-    const int old = tM21[bestE];
-    if (old >= 0) nm--;
-    nm++;
-    int bin = -1;
-    if (mp.checkOri) {
-      float rot = qAng[q] - tAng[bestE];
-      if (rot < 0.0f) rot += 360.0f;
-      bin = (int)roundf(rot * factor);
-      if (bin == HISTO_LENGTH) bin = 0;
-      if (bin < 0 || bin >= HISTO_LENGTH) bin = -1;
-    }
-    if (lane == 0) {
-      if (old >= 0) m12[old] = -1;
-      m12[i1] = bestIdx2;
-      tM21[bestE] = i1;
-      tMd[bestE] = bestDist;
-      if (bin >= 0) { accBin[i1] = (uint8_t)bin; hist[bin]++; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-  }
-  // ---- rotation histogram: keep the three largest bins (ComputeThreeMaxima, ORBmatcher.cpp:152-183) ----
-  if (mp.checkOri) {
-    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-    for (int i = 0; i < HISTO_LENGTH; i++) {
-      const int s = hist[i];
-      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-      else if (s > max3) { max3 = s; ind3 = i; }
-    }
-    if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-    else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
-    int dropped = 0;
-    for (int i = lane; i < n1; i += 64) {
-      const int b = accBin[i];
-      if (b != 255 && b != ind1 && b != ind2 && b != ind3) {  // also hits queries whose match was stolen (quirk, :130-138)
-        m12[i] = -1;
-        dropped++;
-      }
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) dropped += __shfl_xor(dropped, o);
-    nm -= dropped;
-    badOri += dropped;
-  }
-  if (lane == 0) {
-    nmatchesOut[pair] = nm;
-    if (statsOut) { statsOut[pair * 3] = badDist; statsOut[pair * 3 + 1] = badRatio; statsOut[pair * 3 + 2] = badOri; }
-  }
-}
-
 __global__ __launch_bounds__(MATCH_T) void k_match(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
                                                    const orbx_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
                                                    const int* __restrict__ nkp, const MatchParams mp,
                                                    int* __restrict__ matches12, int* __restrict__ nmatchesOut,
-                                                   int* __restrict__ statsOut, int* __restrict__ scratch) {
+                                                   int* __restrict__ statsOut, int* __restrict__ scratch,
+                                                   long long scratchStride) {
   __shared__ unsigned long long sBest[MATCH_T / 64];
   __shared__ int sSecond[MATCH_T / 64], sAny[MATCH_T / 64];
   __shared__ int hist[HISTO_LENGTH];
@@ -1286,7 +1097,7 @@ __global__ __launch_bounds__(MATCH_T) void k_match(const int* __restrict__ pairF
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int pair = blockIdx.x + mp.pair0;
-  if (mp.onlyPending && nmatchesOut[pair] != MATCH_PENDING) return;  // already done by k_match_wave
+  if (mp.onlyPending && nmatchesOut[pair] != MATCH_PENDING) return;  // already done by k_match_jacobi
   const int fa = pairFirst[pair], fb = pairSecond[pair];
   const int n1 = nkp[fa], n2 = nkp[fb];
   const int cap = mp.capacity;
@@ -1295,7 +1106,7 @@ __global__ __launch_bounds__(MATCH_T) void k_match(const int* __restrict__ pairF
   const uint8_t* d1 = desc + (long long)fa * cap * 32;
   const uint8_t* d2 = desc + (long long)fb * cap * 32;
   int* m12 = matches12 + (long long)pair * cap;
-  int* md = scratch + (long long)pair * cap * 4;  // vMatchedDistance
+  int* md = scratch + (long long)pair * scratchStride;  // vMatchedDistance (the pair's scratch holds >= 4 * cap ints)
   int* m21 = md + cap;                            // vnMatches21
   int* accBin = m21 + cap;                        // rotation bin of every accepted query (rotHist membership)
   int* cell2 = accBin + cap;                      // F2 grid cell (cx*48+cy) of every eligible train, -1 otherwise
@@ -1699,14 +1510,16 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
   mp.capacity = capacity; mp.window = window; mp.nnratio = nnratio; mp.checkOri = checkOri; mp.b = b;
   mp.onlyPending = 1;
   mp.pair0 = pair0;
-  // small pairs (<= 256 octave-0 queries and eligible trains): parallel fixpoint sweeps, one thread per query;
-  // what it marks MATCH_PENDING goes to the sequential one-wave kernel (<= 512), and the rest to the general kernel
-  hipLaunchKernelGGL(k_match_jacobi, dim3(nPairs), dim3(MJ_T), 0, st, dFirst, dSecond, kps, desc, nkp, mp, matches12, nmatches,
-                     stats);
-  hipLaunchKernelGGL(k_match_wave, dim3(nPairs), dim3(64), 0, st, dFirst, dSecond, kps, desc, nkp, mp, matches12, nmatches,
-                     stats);
+  // pairs with <= 256 octave-0 queries and eligible trains: parallel fixpoint sweeps with the candidate lists in LDS; what
+  // it marks MATCH_PENDING goes to the instance for <= 512 (lists in the pair's global scratch), and the rest to the
+  // general kernel
+  const long long stride = std::max<long long>((long long)capacity * 4, MJ_LARGE_SCRATCH_INTS);  // = ensureMatchScratch
+  hipLaunchKernelGGL((k_match_jacobi<256, 4, 24, false>), dim3(nPairs), dim3(1024), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
+                     matches12, nmatches, stats, scratch, stride);
+  hipLaunchKernelGGL((k_match_jacobi<512, 2, 64, true>), dim3(nPairs), dim3(1024), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
+                     matches12, nmatches, stats, scratch, stride);
   hipLaunchKernelGGL(k_match, dim3(nPairs), dim3(MATCH_T), 0, st, dFirst, dSecond, kps, desc, nkp, mp, matches12, nmatches,
-                     stats, scratch);
+                     stats, scratch, stride);
   return hipGetLastError();
 }
 
