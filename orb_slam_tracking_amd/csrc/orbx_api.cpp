@@ -4,8 +4,8 @@
 //   k_pyramid_bands (or k_resize_dw x (nlevels-1))  ->  k_fast (all cells of all levels of all frames)
 //   -> k_octree_lds / k_octree_global (quadtree selection, one workgroup per frame x level) -> k_sel_compact
 //   -> k_describe_patch (orientation + blur + descriptors) -> results stay in HBM (device API) or D2H (host API)
-// and, for matching, k_match_jacobi (two instances, -> k_match for pairs they cannot take) with one workgroup per frame
-// pair.  No host round trip inside a batch: the host only issues the launches and reads two error flags + the per-frame
+// and, for matching, k_match_jacobi (one workgroup per frame pair) -> k_match_wide_lists -> k_match_wide_resolve for the
+// pairs beyond its tables.  No host round trip inside a batch: the host only issues the launches and reads two error flags + the per-frame
 // counts at the end.
 #include <hip/hip_runtime.h>
 
@@ -521,7 +521,7 @@ int issueMatch(orbx_ctx* ctx, int si, hipStream_t st, int pair0, int n, const Ma
   StageTimer tm(ctx, ORBX_STAGE_MATCH, si, st);
   HIPCHK(launch_match(st, n, ctx->dPairs, ctx->dPairs + m.nPairs, dKps, dDesc, dN, capacity, m.b, m.window, m.nnratio, m.checkOri,
                       m.dMatches12, m.dNmatches, m.dStats, ctx->dMatchScratch, pair0));
-  tm.stop(3);  // k_match_jacobi (two instances) + k_match (the latter two for pending pairs only)
+  tm.stop(3);  // k_match_jacobi + k_match_wide_lists + k_match_wide_resolve (the latter two for pending pairs only)
   return ORBX_OK;
 }
 
@@ -872,8 +872,8 @@ int orbx_download_pyramid(orbx_ctx* ctx, int frame, int level, int border, uint8
 }  // extern "C"
 namespace {
 int ensureMatchScratch(orbx_ctx* ctx, int nPairs, int capacity) {
-  // per pair: the general kernel's 4 * capacity ints, or the large k_match_jacobi instance's candidate lists (2 * 64 * 512)
-  const size_t need = (size_t)nPairs * std::max<size_t>((size_t)capacity * 4, (size_t)2 * 64 * 512);
+  // per pair: see matchScratchStride (orbx_device.h)
+  const size_t need = (size_t)nPairs * (size_t)matchScratchStride(capacity);
   if (need > ctx->matchScratchInts) {
     if (ctx->dMatchScratch) (void)hipFree(ctx->dMatchScratch);
     ctx->dMatchScratch = nullptr;

@@ -116,4 +116,19 @@ struct CamD {
   int32_t distorted, pad_;          // mDistCoef.at<float>(0) != 0 (Frame.cpp:103,138)
 };
 
+// ---- SearchForInitialization scratch (ints per pair; one place for the host allocation and the launches) ----
+// matchGeneral needs 4 * capacity; the wide path (k_match_wide_*) a header, one record per eligible train, the query index
+// list, the per-query candidate counts and MW_CP list entries per query, all for min(capacity, MW_CAP) queries / trains.
+constexpr int MW_CAP = 4096;  // octave-0 queries / eligible trains per pair the wide path takes
+constexpr int MW_CP = 128;    // candidates listed per query (a fuller window hands the pair to k_match)
+constexpr int MW_HDR = 16;    // [0] nQ, [1] nT, [2] 1 = too large for the wide path, [3] != 0 = a list overflowed
+inline int matchWideCap(int capacity) { return capacity < MW_CAP ? capacity : MW_CAP; }
+inline long long matchScratchStride(int capacity) {
+  const long long capl = matchWideCap(capacity);
+  long long s = (long long)capacity * 4;
+  const long long wide = MW_HDR + capl * (4 + 1 + 1) + capl * MW_CP;
+  if (s < wide) s = wide;
+  return (s + 3) & ~3LL;  // the train records are uint4
+}
+
 }  // namespace orbx

@@ -8,7 +8,8 @@
 //   k_describe_patch  IC-angle + 7x7 Gaussian (patch-local, v_dot4/v_dot2 fixed point) + steered BRIEF, one wave per
 //                     keypoint                       (IC_Angle cpp:103-159, GaussianBlur cpp:1598-1606,
 //                                                     computeOrbDescriptor cpp:169-228, assembly cpp:1557-1652)
-//   k_match_jacobi (two instances) / k_match   SearchForInitialization, one workgroup per frame pair
+//   k_match_jacobi / k_match_wide_lists / k_match_wide_resolve   SearchForInitialization: parallel fixpoint sweeps (one
+//                     workgroup per pair up to 256 queries; wide path up to 4096), the sequential loop for the rest
 //                                                    (ORBmatcher.cpp:11-183, Frame.cpp:89-99,163-206, FORB.cpp:77-101)
 //   k_undistort, k_to_gray, k_check_model     the steps around the path (Frame.cpp:101-161, Converter.cpp:5-19,
 //                                                     Initializer.cpp:268-438)
@@ -20,6 +21,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 #include "../../include/orbx.h"
 #include "orbx_device.h"
@@ -749,21 +751,21 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
 // Tie-breaking equals the reference's candidate order (GetFeaturesInArea: cell x outer, cell y inner, index):
 // the best candidate is the minimum of (distance, cellX*48+cellY, index).
 // =================================================================================================
-#define MATCH_T 256
 #define TH_LOW 50
 #define HISTO_LENGTH 30
 #define INF_DIST 0x7fffffff
 #define MATCH_NONE 0x7fffffffffffffffull
 
-#define MATCH_PENDING ((int)0x80000000)  // nmatches value meaning "left for the general kernel"
+#define MATCH_PENDING ((int)0x80000000)  // nmatches value meaning "handed on to the wide path"
 
 struct MatchParams {
   int capacity;
   int window;
   float nnratio;
   int checkOri;
-  int onlyPending;
+  int noGeneral;  // diagnostics: leave the pairs the parallel paths cannot take at MATCH_PENDING
   int pair0;  // first pair of this launch
+  int dmax;   // the wide path lists only candidates with a smaller distance (launch_match)
   orbx_bounds b;
 };
 
@@ -772,6 +774,81 @@ __device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const 
   return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
          __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
+
+#define MW_T 1024
+#define MW_R (MW_CAP / MW_T)
+#define MW_END 0xffff
+#define MW_SWEEPS 1024  // after sweep i the first i queries are final; in practice a handful of sweeps
+
+// matchWidePrep: first step of the wide path (see k_match_wide_lists / k_match_wide_resolve below), run by the workgroup
+// of k_match_jacobi that hands its pair on: ordered compaction of the octave-0 queries (F1 index) and of the eligible
+// trains (x, y, grid cell, cell << 20 | F2 index) into the pair's scratch, and matches12 = -1.  Every thread of the
+// workgroup must call it (it has barriers).
+template <int T>
+__device__ void matchWidePrep(const int pair, const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
+                              const orbx_keypoint* __restrict__ kps, const int* __restrict__ nkp, const MatchParams& mp,
+                              int* __restrict__ matches12, int* __restrict__ scratch, long long scratchStride, int capl) {
+  __shared__ int wq[T / 64], wt[T / 64];
+  __shared__ int sBaseQ, sBaseT;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int fa = pairFirst[pair], fb = pairSecond[pair];
+  const int n1 = nkp[fa], n2 = nkp[fb];
+  const int cap = mp.capacity;
+  const orbx_keypoint* k1 = kps + (long long)fa * cap;
+  const orbx_keypoint* k2 = kps + (long long)fb * cap;
+  int* m12 = matches12 + (long long)pair * cap;
+  int* S = scratch + (long long)pair * scratchStride;
+  uint4* trec = reinterpret_cast<uint4*>(S + MW_HDR);
+  int* qIdx = S + MW_HDR + 4 * capl;
+  const float wInv = (float)ORBX_GRID_COLS / (float)(mp.b.max_x - mp.b.min_x);  // Frame.cpp:46-47
+  const float hInv = (float)ORBX_GRID_ROWS / (float)(mp.b.max_y - mp.b.min_y);
+  const float fminX = (float)mp.b.min_x, fminY = (float)mp.b.min_y;
+  if (t == 0) { sBaseQ = 0; sBaseT = 0; }
+  __syncthreads();
+  const int n = max(n1, n2);
+  for (int i0 = 0; i0 < n; i0 += T) {
+    const int i = i0 + t;
+    bool okQ = false, okT = false;
+    float tx = 0.f, ty = 0.f;
+    int px = 0, py = 0;
+    if (i < n1) {
+      okQ = !(k1[i].octave > 0);  // ORBmatcher.cpp:38-39
+      m12[i] = -1;
+    }
+    if (i < n2) {
+      const orbx_keypoint kp = k2[i];
+      // Frame::PosInGrid (Frame.cpp:89-99) + the octave filter of GetFeaturesInArea (Frame.cpp:179,191)
+      px = (int)roundf((kp.x - fminX) * wInv);
+      py = (int)roundf((kp.y - fminY) * hInv);
+      okT = kp.octave == 0 && px >= 0 && px < ORBX_GRID_COLS && py >= 0 && py < ORBX_GRID_ROWS;
+      tx = kp.x; ty = kp.y;
+    }
+    const unsigned long long bq = __ballot(okQ), bt = __ballot(okT);
+    if (lane == 0) { wq[wave] = __popcll(bq); wt[wave] = __popcll(bt); }
+    __syncthreads();
+    int beforeQ = sBaseQ, beforeT = sBaseT;
+    for (int w2 = 0; w2 < wave; w2++) { beforeQ += wq[w2]; beforeT += wt[w2]; }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int posQ = beforeQ + __popcll(bq & below), posT = beforeT + __popcll(bt & below);
+    if (okQ && posQ < capl) qIdx[posQ] = i;
+    if (okT && posT < capl)
+      trec[posT] = make_uint4(__float_as_uint(tx), __float_as_uint(ty), (uint32_t)px | ((uint32_t)py << 8),
+                              ((uint32_t)(px * ORBX_GRID_ROWS + py) << 20) | (uint32_t)i);
+    __syncthreads();
+    if (t == 0) {
+      int tq = sBaseQ, tt = sBaseT;
+      for (int w2 = 0; w2 < T / 64; w2++) { tq += wq[w2]; tt += wt[w2]; }
+      sBaseQ = tq; sBaseT = tt;
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    S[0] = sBaseQ; S[1] = sBaseT;
+    S[2] = (sBaseQ > capl || sBaseT > capl || n2 > 0xfffff) ? 1 : 0;
+    S[3] = 0;
+  }
+}
+
 
 // -------------------------------------------------------------------------------------------------
 // k_match_jacobi: one workgroup per frame pair, ONE THREAD PER QUERY.
@@ -785,24 +862,19 @@ __device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const 
 // double-decrement quirk) follows from the final outcomes: a train belongs to its LAST claimant.
 // All threads walk the trains together, so train data are LDS broadcasts.
 // -------------------------------------------------------------------------------------------------
-// Two instances (launch_match):
-//   <256, 4, 24, lists in LDS>     up to 256 octave-0 queries / eligible trains per pair, four threads per query;
-//   <512, 2, 64, lists in global>  up to 512 (frames of the 2 x nFeatures initialisation extractor), two threads per query,
-//                                  candidate lists in the pair's global scratch (L2-resident); takes only the pairs the first
-//                                  instance marked MATCH_PENDING.
-// MJ_CAP = queries / trains per pair, MJ_P = threads per query (thread t works for query t % MJ_CAP on the trains e with
-// e % MJ_P == t / MJ_CAP), MJ_CP = trains inside one query's window per part (a fuller window hands the pair on).
+// Up to MJ_CAP (256) octave-0 queries / eligible trains per pair, MJ_P (4) threads per query (thread t works for query
+// t % MJ_CAP on the trains e with e % MJ_P == t / MJ_CAP), MJ_CP (24) trains inside one query's window per part; a
+// larger or fuller pair is marked MATCH_PENDING for the wide path below.
 #define MJ_K 4
 #define MJ_SWEEPS 64
-#define MJ_LARGE_SCRATCH_INTS (2 * 64 * 512)  // candidate lists of the large instance, per pair
 
-template <int MJ_CAP, int MJ_P, int MJ_CP, bool GLOBAL_LISTS>
+template <int MJ_CAP, int MJ_P, int MJ_CP>
 __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
                                                                const orbx_keypoint* __restrict__ kps,
                                                                const uint8_t* __restrict__ desc, const int* __restrict__ nkp,
                                                                const MatchParams mp, int* __restrict__ matches12,
                                                                int* __restrict__ nmatchesOut, int* __restrict__ statsOut,
-                                                               int* __restrict__ scratch, long long scratchStride) {
+                                                               int* __restrict__ scratch, long long scratchStride, int capl) {
   constexpr int MJ_T = MJ_CAP * MJ_P;
   __shared__ float tX[MJ_CAP], tY[MJ_CAP], tAng[MJ_CAP];
   __shared__ uint32_t tDesc[8][MJ_CAP];
@@ -810,7 +882,7 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
   __shared__ uint8_t tCx[MJ_CAP], tCy[MJ_CAP];
   __shared__ int clCount[MJ_CAP], lastQ[MJ_CAP];
   __shared__ uint16_t clQ[MJ_CAP][MJ_K], clD[MJ_CAP][MJ_K];
-  __shared__ uint32_t candLds[GLOBAL_LISTS ? 1 : MJ_P * MJ_CP * MJ_CAP];  // [part][k][query]: dist << 16 | train slot
+  __shared__ uint32_t candList[MJ_P * MJ_CP * MJ_CAP];  // [part][k][query]: dist << 16 | train slot
   __shared__ uint32_t tOrd[MJ_CAP];                      // cell << 20 | F2 index: the reference's candidate order
   __shared__ unsigned long long pBest[MJ_P][MJ_CAP];     // per part: best key of the sweep
   __shared__ uint32_t pAux[MJ_P][MJ_CAP];                // per part: second-best distance (0xffff = none) | best train slot << 16
@@ -822,8 +894,6 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int part = t / MJ_CAP, q = t - part * MJ_CAP;  // waves 0-3 = part 0, ...
   const int pair = blockIdx.x + mp.pair0;
-  if (GLOBAL_LISTS && nmatchesOut[pair] != MATCH_PENDING) return;  // already done by the first instance
-  uint32_t* const candList = GLOBAL_LISTS ? reinterpret_cast<uint32_t*>(scratch + (long long)pair * scratchStride) : candLds;
   const int fa = pairFirst[pair], fb = pairSecond[pair];
   const int n1 = nkp[fa], n2 = nkp[fb];
   const int cap = mp.capacity;
@@ -885,8 +955,9 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
     __syncthreads();
   }
   const int nQ = sBase, nT = sNT;
-  if (nQ > MJ_CAP || nT > MJ_CAP || sOverflow) {  // block-uniform: leave the pair to the sequential kernels
+  if (nQ > MJ_CAP || nT > MJ_CAP || sOverflow) {  // block-uniform: the pair goes to the wide path
     if (t == 0) nmatchesOut[pair] = MATCH_PENDING;
+    matchWidePrep<MJ_T>(pair, pairFirst, pairSecond, kps, nkp, mp, matches12, scratch, scratchStride, capl);
     return;
   }
   if (q < nQ) {  // every part loads its query
@@ -939,8 +1010,9 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
   pCnt[part][q] = (uint8_t)min(nCand, 255);
   if (t < nT) tOrd[t] = ((uint32_t)(tCx[t] * ORBX_GRID_ROWS + tCy[t]) << 20) | (uint32_t)tIdx[t];
   __syncthreads();
-  if (sOverflow) {  // a window too full for the lists: leave the pair to the sequential kernels
+  if (sOverflow) {  // a window too full for the lists: the pair goes to the wide path
     if (t == 0) nmatchesOut[pair] = MATCH_PENDING;
+    matchWidePrep<MJ_T>(pair, pairFirst, pairSecond, kps, nkp, mp, matches12, scratch, scratchStride, capl);
     return;
   }
   // a query has a candidate in its window iff some part listed one (vIndices2.empty() -> continue, ORBmatcher.cpp:46-47)
@@ -1032,6 +1104,7 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
   }
   if (!converged) {  // block-uniform (sChanged / sOverflow are read after barriers)
     if (t == 0) nmatchesOut[pair] = MATCH_PENDING;
+    matchWidePrep<MJ_T>(pair, pairFirst, pairSecond, kps, nkp, mp, matches12, scratch, scratchStride, capl);
     return;
   }
   // ---- final bookkeeping from the converged outcomes (part-0 threads hold them; the others have outcome 0) ----
@@ -1082,22 +1155,22 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
 }
 
 // -------------------------------------------------------------------------------------------------
-// k_match: the general kernel (any size; global scratch), for the pairs both k_match_jacobi instances handed on.
+// matchGeneral: the reference's loop as written - queries one after the other, the workgroup's threads share the trains
+// of one query (any size; vMatchedDistance, vnMatches21 and the rotation bins in the pair's global scratch).  Run by the
+// workgroup of k_match_wide_resolve for a pair the parallel paths cannot take.  Every thread must call it.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MATCH_T) void k_match(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
-                                                   const orbx_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
-                                                   const int* __restrict__ nkp, const MatchParams mp,
-                                                   int* __restrict__ matches12, int* __restrict__ nmatchesOut,
-                                                   int* __restrict__ statsOut, int* __restrict__ scratch,
-                                                   long long scratchStride) {
-  __shared__ unsigned long long sBest[MATCH_T / 64];
-  __shared__ int sSecond[MATCH_T / 64], sAny[MATCH_T / 64];
+template <int T>
+__device__ void matchGeneral(const int pair, const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
+                             const orbx_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
+                             const int* __restrict__ nkp, const MatchParams& mp, int* __restrict__ matches12,
+                             int* __restrict__ nmatchesOut, int* __restrict__ statsOut, int* __restrict__ scratch,
+                             long long scratchStride) {
+  __shared__ unsigned long long sBest[T / 64];
+  __shared__ int sSecond[T / 64], sAny[T / 64];
   __shared__ int hist[HISTO_LENGTH];
   __shared__ int sNm, sBadDist, sBadRatio, sBadOri, sKeep[3];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int pair = blockIdx.x + mp.pair0;
-  if (mp.onlyPending && nmatchesOut[pair] != MATCH_PENDING) return;  // already done by k_match_jacobi
   const int fa = pairFirst[pair], fb = pairSecond[pair];
   const int n1 = nkp[fa], n2 = nkp[fb];
   const int cap = mp.capacity;
@@ -1114,7 +1187,7 @@ __global__ __launch_bounds__(MATCH_T) void k_match(const int* __restrict__ pairF
   const float wInv = (float)ORBX_GRID_COLS / (float)(mp.b.max_x - mp.b.min_x);  // Frame.cpp:46-47
   const float hInv = (float)ORBX_GRID_ROWS / (float)(mp.b.max_y - mp.b.min_y);
   const float fminX = (float)mp.b.min_x, fminY = (float)mp.b.min_y;
-  for (int j = t; j < n2; j += MATCH_T) {
+  for (int j = t; j < n2; j += T) {
     md[j] = INF_DIST;
     m21[j] = -1;
     const orbx_keypoint kp = k2[j];
@@ -1123,7 +1196,7 @@ __global__ __launch_bounds__(MATCH_T) void k_match(const int* __restrict__ pairF
     const bool ok = kp.octave == 0 && px >= 0 && px < ORBX_GRID_COLS && py >= 0 && py < ORBX_GRID_ROWS;
     cell2[j] = ok ? px * ORBX_GRID_ROWS + py : -1;
   }
-  for (int i = t; i < n1; i += MATCH_T) {
+  for (int i = t; i < n1; i += T) {
     m12[i] = -1;
     accBin[i] = -1;
   }
@@ -1146,7 +1219,7 @@ __global__ __launch_bounds__(MATCH_T) void k_match(const int* __restrict__ pairF
     const uint4 q1 = reinterpret_cast<const uint4*>(d1 + (long long)i1 * 32)[1];
     unsigned long long best = MATCH_NONE;  // (dist << 32) | (cell << 20 | index)  -- index < 2^20
     int second = INF_DIST, any = 0;
-    for (int j = t; j < n2; j += MATCH_T) {
+    for (int j = t; j < n2; j += T) {
       const int c = cell2[j];
       if (c < 0) continue;
       const int cx = c / ORBX_GRID_ROWS, cy = c - cx * ORBX_GRID_ROWS;
@@ -1180,7 +1253,7 @@ __global__ __launch_bounds__(MATCH_T) void k_match(const int* __restrict__ pairF
     if (t == 0) {
       unsigned long long bb = sBest[0];
       int ss = sSecond[0], aa = sAny[0];
-      for (int w = 1; w < MATCH_T / 64; w++) {
+      for (int w = 1; w < T / 64; w++) {
         const unsigned long long ob = sBest[w];
         const unsigned long long lo = ob < bb ? ob : bb, hi = ob < bb ? bb : ob;
         ss = min(min(ss, sSecond[w]), (int)(hi >> 32));
@@ -1231,7 +1304,7 @@ __global__ __launch_bounds__(MATCH_T) void k_match(const int* __restrict__ pairF
     __syncthreads();
     const int i1k = sKeep[0], i2k = sKeep[1], i3k = sKeep[2];
     int dropped = 0;
-    for (int i = t; i < n1; i += MATCH_T) {
+    for (int i = t; i < n1; i += T) {
       const int b = accBin[i];
       if (b >= 0 && b != i1k && b != i2k && b != i3k) {  // also hits queries whose match was stolen (quirk, :130-138)
         m12[i] = -1;
@@ -1241,6 +1314,294 @@ __global__ __launch_bounds__(MATCH_T) void k_match(const int* __restrict__ pairF
     if (dropped) { atomicSub(&sNm, dropped); atomicAdd(&sBadOri, dropped); }
     __syncthreads();
   }
+  if (t == 0) {
+    nmatchesOut[pair] = sNm;
+    if (statsOut) { statsOut[pair * 3] = sBadDist; statsOut[pair * 3 + 1] = sBadRatio; statsOut[pair * 3 + 2] = sBadOri; }
+  }
+}
+
+
+// -------------------------------------------------------------------------------------------------
+// The wide path: the same fixpoint as k_match_jacobi for pairs with up to MW_CAP (4096) octave-0 queries / eligible
+// trains (the 1920x1080 / 4000-feature and 3840x2160 / 8000-feature configurations: ~870 and ~1740 per frame), cut into
+// three steps so that the expensive part - the window test of every (query, train) and the Hamming distances - is
+// spread over the whole GPU instead of one workgroup per pair:
+//   matchWidePrep         (above; run by k_match_jacobi's workgroup when it hands the pair on) compaction of the queries
+//                         and of the eligible trains into the pair's scratch
+//   k_match_wide_lists    one workgroup per 64 queries: lane = query, the four waves split the trains; a train record
+//                         and its descriptor are wave-uniform (scalar) loads; every in-window train is appended to the
+//                         query's candidate list (dist << 16 | train slot; the order inside a list is irrelevant)
+//   k_match_wide_resolve  one workgroup per pair: the sweeps and the final bookkeeping of k_match_jacobi, up to four
+//                         queries per thread, lists read from the scratch (L2); the claims of a sweep are one linked
+//                         list per train through its claimants (LDS), so any number of queries may claim a train
+// Only candidates with a distance below MatchParams::dmax are listed (see launch_match): a farther train can neither be
+// accepted nor make a nearer one fail the ratio test, so the lists stay short even when the window covers the frame
+// (the brute-force configurations).
+// A pair the path cannot take (more than MW_CAP queries or trains, more than MW_CP listed candidates of one query) is
+// matched by the same workgroup of k_match_wide_resolve with matchGeneral.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_match_wide_lists(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
+                                                         const orbx_keypoint* __restrict__ kps,
+                                                         const uint8_t* __restrict__ desc, const int* __restrict__ nkp,
+                                                         const MatchParams mp, const int* __restrict__ nmatchesOut,
+                                                         const int* __restrict__ scratchR, int* __restrict__ scratchW,
+                                                         long long scratchStride, int capl) {
+  __shared__ int cnt[64], anyIn[64];  // per query: candidates listed, and whether its window holds any train at all
+  const int t = threadIdx.x, lane = t & 63;
+  const int part = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int pair = blockIdx.y + mp.pair0;
+  if (nmatchesOut[pair] != MATCH_PENDING) return;
+  const int* S = scratchR + (long long)pair * scratchStride;  // read side: header [0..2], train records, query indices
+  if (S[2]) return;
+  const int nQ = S[0], nT = S[1];
+  const int q0 = blockIdx.x * 64;
+  if (q0 >= nQ) return;
+  const uint4* trec = reinterpret_cast<const uint4*>(S + MW_HDR);
+  const int* qIdx = S + MW_HDR + 4 * capl;
+  int* W = scratchW + (long long)pair * scratchStride;        // write side: header [3], counts, lists
+  int* cntOut = W + MW_HDR + 5 * capl;
+  uint32_t* lists = reinterpret_cast<uint32_t*>(W + MW_HDR + 6 * capl);
+  const int fa = pairFirst[pair], fb = pairSecond[pair];
+  const int cap = mp.capacity;
+  const orbx_keypoint* k1 = kps + (long long)fa * cap;
+  const uint32_t* d1 = reinterpret_cast<const uint32_t*>(desc + (long long)fa * cap * 32);
+  const uint32_t* d2 = reinterpret_cast<const uint32_t*>(desc + (long long)fb * cap * 32);
+  const float wInv = (float)ORBX_GRID_COLS / (float)(mp.b.max_x - mp.b.min_x);
+  const float hInv = (float)ORBX_GRID_ROWS / (float)(mp.b.max_y - mp.b.min_y);
+  const float fminX = (float)mp.b.min_x, fminY = (float)mp.b.min_y;
+  if (t < 64) { cnt[t] = 0; anyIn[t] = 0; }
+  __syncthreads();
+  const int q = q0 + lane;
+  const bool valid = q < nQ;
+  float qx = 0.f, qy = 0.f;
+  uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (valid) {
+    const int qi = qIdx[q];
+    qx = k1[qi].x; qy = k1[qi].y;
+    const uint4 a0 = reinterpret_cast<const uint4*>(d1 + (long long)qi * 8)[0];
+    const uint4 a1 = reinterpret_cast<const uint4*>(d1 + (long long)qi * 8)[1];
+    qd[0] = a0.x; qd[1] = a0.y; qd[2] = a0.z; qd[3] = a0.w; qd[4] = a1.x; qd[5] = a1.y; qd[6] = a1.z; qd[7] = a1.w;
+  }
+  // cell window of my query, Frame.cpp:167-177 (an empty window makes every test below fail)
+  const float r = (float)mp.window;
+  const int minCX = max(0, (int)floorf((qx - fminX - r) * wInv));
+  const int maxCX = min(ORBX_GRID_COLS - 1, (int)ceilf((qx - fminX + r) * wInv));
+  const int minCY = max(0, (int)floorf((qy - fminY - r) * hInv));
+  const int maxCY = min(ORBX_GRID_ROWS - 1, (int)ceilf((qy - fminY + r) * hInv));
+  const int chunk = (nT + 3) >> 2;
+  const int e0 = part * chunk, e1 = min(nT, e0 + chunk);
+  bool any = false;
+  for (int eb = e0; eb < e1; eb += 4) {  // four wave-uniform train records in flight
+    uint4 rec[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) rec[j] = trec[min(eb + j, e1 - 1)];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int e = eb + j;
+      if (e >= e1) break;
+      const int cx = (int)(rec[j].z & 0xff), cy = (int)(rec[j].z >> 8);
+      const float dx = __uint_as_float(rec[j].x) - qx, dy = __uint_as_float(rec[j].y) - qy;
+      const bool in = valid && cx >= minCX && cx <= maxCX && cy >= minCY && cy <= maxCY && fabsf(dx) < r && fabsf(dy) < r;
+      if (__ballot(in) == 0ull) continue;  // wave-uniform
+      const uint32_t* b = d2 + (long long)(rec[j].w & 0xfffff) * 8;  // wave-uniform address: scalar loads
+      const uint4 b0 = reinterpret_cast<const uint4*>(b)[0], b1 = reinterpret_cast<const uint4*>(b)[1];
+      if (in) {
+        const int dist = __popc(qd[0] ^ b0.x) + __popc(qd[1] ^ b0.y) + __popc(qd[2] ^ b0.z) + __popc(qd[3] ^ b0.w) +
+                         __popc(qd[4] ^ b1.x) + __popc(qd[5] ^ b1.y) + __popc(qd[6] ^ b1.z) + __popc(qd[7] ^ b1.w);
+        any = true;
+        if (dist < mp.dmax) {  // a farther train can neither be accepted nor fail the ratio test of a nearer one
+          const int slot = atomicAdd(&cnt[lane], 1);
+          if (slot < MW_CP) lists[(size_t)slot * capl + q] = ((uint32_t)dist << 16) | (uint32_t)e;
+        }
+      }
+    }
+  }
+  if (any) anyIn[lane] = 1;  // vIndices2 of the query is not empty (the four parts may all store the same 1)
+  __syncthreads();
+  if (t < 64 && valid) {
+    const int c = cnt[t];
+    if (c > MW_CP) atomicOr(&W[3], 1);
+    cntOut[q] = min(c, MW_CP) | (anyIn[t] << 16);
+  }
+}
+
+__global__ __launch_bounds__(MW_T) void k_match_wide_resolve(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
+                                                            const orbx_keypoint* __restrict__ kps,
+                                                            const uint8_t* __restrict__ desc, const int* __restrict__ nkp,
+                                                            const MatchParams mp, int* __restrict__ matches12,
+                                                            int* __restrict__ nmatchesOut, int* __restrict__ statsOut,
+                                                            int* scratch, long long scratchStride, int capl) {
+  extern __shared__ __align__(16) unsigned char mwLds[];
+  // claims of a sweep = one linked list per train through its claimant queries (any number of claimants)
+  int* head = reinterpret_cast<int*>(mwLds);                              // [capl] a claimant of the train, -1 = none; lastQ at the end
+  uint32_t* tOrd = reinterpret_cast<uint32_t*>(mwLds) + capl;             // [capl] cell << 20 | F2 index
+  uint16_t* nextQ = reinterpret_cast<uint16_t*>(mwLds + (size_t)capl * 8);  // [capl] next claimant of the same train, MW_END = none
+  uint16_t* outD = nextQ + capl;                                          // [capl] distance of the query's claim
+  __shared__ int hist[HISTO_LENGTH];
+  __shared__ int sNm, sBadDist, sBadRatio, sBadOri, sKeep[3];
+
+  const int t = threadIdx.x;
+  const int pair = blockIdx.x + mp.pair0;
+  if (nmatchesOut[pair] != MATCH_PENDING) return;
+  const int* S = scratch + (long long)pair * scratchStride;
+  if (S[2] | S[3]) {  // too large or a full list (block-uniform): the reference's loop as written
+    if (!mp.noGeneral)
+      matchGeneral<MW_T>(pair, pairFirst, pairSecond, kps, desc, nkp, mp, matches12, nmatchesOut, statsOut, scratch, scratchStride);
+    return;
+  }
+  const int nQ = S[0], nT = S[1];
+  const uint4* trec = reinterpret_cast<const uint4*>(S + MW_HDR);
+  const int* qIdx = S + MW_HDR + 4 * capl;
+  const int* cntIn = S + MW_HDR + 5 * capl;
+  const uint32_t* lists = reinterpret_cast<const uint32_t*>(S + MW_HDR + 6 * capl);
+  const int fa = pairFirst[pair], fb = pairSecond[pair];
+  const int cap = mp.capacity;
+  const orbx_keypoint* k1 = kps + (long long)fa * cap;
+  const orbx_keypoint* k2 = kps + (long long)fb * cap;
+  int* m12 = matches12 + (long long)pair * cap;
+
+  if (t == 0) { sNm = 0; sBadDist = 0; sBadRatio = 0; sBadOri = 0; }
+  if (t < HISTO_LENGTH) hist[t] = 0;
+  for (int e = t; e < nT; e += MW_T) { tOrd[e] = trec[e].w; head[e] = -1; }
+  int nCand[MW_R], outcome[MW_R], bestT[MW_R], bestD[MW_R];
+  bool hasCand[MW_R];
+#pragma unroll
+  for (int rr = 0; rr < MW_R; rr++) {
+    const int q = t + rr * MW_T;
+    const int c = q < nQ ? cntIn[q] : 0;
+    nCand[rr] = c & 0xffff;
+    hasCand[rr] = c != 0;
+    outcome[rr] = 0; bestT[rr] = -1; bestD[rr] = 0;
+  }
+  __syncthreads();
+  // outcome of a query: 0 = no candidate in the window, 1 = invalid by distance, 2 = invalid by ratio, 3 = accepted
+  bool converged = false;
+  for (int sweep = 0; sweep < MW_SWEEPS; sweep++) {
+    bool changed = false;
+#pragma unroll
+    for (int rr = 0; rr < MW_R; rr++) {
+      const int q = t + rr * MW_T;
+      const int nc = nCand[rr];
+      if (!hasCand[rr]) continue;  // vIndices2.empty() -> continue (ORBmatcher.cpp:46-47): outcome stays 0
+      const uint32_t* myList = lists + q;
+      unsigned long long best = MATCH_NONE;  // dist << 32 | cell << 20 | train index
+      int second = INF_DIST, bt = 0;
+      for (int k = 0; k < nc; k += 4) {
+        uint32_t ce[4], ord[4];
+        int hd[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) ce[j] = myList[(size_t)min(k + j, nc - 1) * capl];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { hd[j] = head[ce[j] & 0xffff]; ord[j] = tOrd[ce[j] & 0xffff]; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (k + j >= nc) break;
+          const int e = ce[j] & 0xffff, dist = (int)(ce[j] >> 16);
+          // vMatchedDistance[e] as query q sees it: smallest distance of an earlier accepted query that chose e
+          int md = INF_DIST;
+          for (int c = hd[j]; c >= 0;) {
+            if (c < q) md = min(md, (int)outD[c]);
+            const int nx = nextQ[c];
+            c = nx == MW_END ? -1 : nx;
+          }
+          if (md <= dist) continue;  // ORBmatcher.cpp:67
+          const unsigned long long key = ((unsigned long long)dist << 32) | ord[j];
+          if (key < best) {
+            second = min(second, (int)(best >> 32));
+            best = key;
+            bt = e;
+          } else {
+            second = min(second, dist);
+          }
+        }
+      }
+      int nOutcome, nBestT = -1, nBestD = 0;
+      const int bd = (int)(best >> 32);
+      if (best == MATCH_NONE || bd > TH_LOW) nOutcome = 1;
+      else if ((float)bd > mp.nnratio * (float)second) nOutcome = 2;
+      else { nOutcome = 3; nBestT = bt; nBestD = bd; }
+      changed |= nOutcome != outcome[rr] || nBestT != bestT[rr] || nBestD != bestD[rr];
+      outcome[rr] = nOutcome; bestT[rr] = nBestT; bestD[rr] = nBestD;
+    }
+    if (!__syncthreads_or(changed ? 1 : 0)) { converged = true; break; }  // also: every scan of the sweep is done
+    for (int e = t; e < nT; e += MW_T) head[e] = -1;
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < MW_R; rr++) {
+      if (outcome[rr] == 3) {
+        const int q = t + rr * MW_T;
+        outD[q] = (uint16_t)bestD[rr];
+        const int prev = atomicExch(&head[bestT[rr]], q);
+        nextQ[q] = prev < 0 ? (uint16_t)MW_END : (uint16_t)prev;
+      }
+    }
+    __syncthreads();
+  }
+  if (!converged) {  // block-uniform; cannot happen for nQ <= MW_SWEEPS (after sweep i the first i queries are final)
+    if (!mp.noGeneral)
+      matchGeneral<MW_T>(pair, pairFirst, pairSecond, kps, desc, nkp, mp, matches12, nmatchesOut, statsOut, scratch, scratchStride);
+    return;
+  }
+  // ---- final bookkeeping from the converged outcomes: a train belongs to its LAST claimant ----
+  int* lastQ = head;
+  for (int e = t; e < nT; e += MW_T) lastQ[e] = -1;
+  __syncthreads();
+  int bin[MW_R], nBadDist = 0, nBadRatio = 0;
+#pragma unroll
+  for (int rr = 0; rr < MW_R; rr++) {
+    const int q = t + rr * MW_T;
+    bin[rr] = -1;
+    if (outcome[rr] == 3) atomicMax(&lastQ[bestT[rr]], q);
+    nBadDist += outcome[rr] == 1;
+    nBadRatio += outcome[rr] == 2;
+    if (outcome[rr] == 3 && mp.checkOri) {
+      float rot = k1[qIdx[q]].angle - k2[tOrd[bestT[rr]] & 0xfffff].angle;
+      if (rot < 0.0f) rot += 360.0f;
+      int b = (int)roundf(rot * (HISTO_LENGTH / 360.0f));
+      if (b == HISTO_LENGTH) b = 0;
+      if (b < 0 || b >= HISTO_LENGTH) b = -1;
+      if (b >= 0) atomicAdd(&hist[b], 1);
+      bin[rr] = b;
+    }
+  }
+  if (nBadDist) atomicAdd(&sBadDist, nBadDist);
+  if (nBadRatio) atomicAdd(&sBadRatio, nBadRatio);
+  __syncthreads();
+  // nmatches before pruning = trains that ended up with a claimant (every steal took one match away again)
+  int owned = 0;
+  for (int e = t; e < nT; e += MW_T) owned += lastQ[e] >= 0;
+  if (owned) atomicAdd(&sNm, owned);
+#pragma unroll
+  for (int rr = 0; rr < MW_R; rr++) {
+    const int q = t + rr * MW_T;
+    if (outcome[rr] == 3 && lastQ[bestT[rr]] == q) m12[qIdx[q]] = (int)(tOrd[bestT[rr]] & 0xfffff);
+  }
+  if (mp.checkOri) {
+    if (t == 0) {  // ComputeThreeMaxima, ORBmatcher.cpp:152-183
+      int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+      for (int i = 0; i < HISTO_LENGTH; i++) {
+        const int s = hist[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+      }
+      if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+      else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+      sKeep[0] = ind1; sKeep[1] = ind2; sKeep[2] = ind3;
+    }
+    __syncthreads();
+    // every accepted query sits in rotHist, also one whose match was stolen later (double decrement, :130-138)
+    int dropped = 0;
+#pragma unroll
+    for (int rr = 0; rr < MW_R; rr++) {
+      if (bin[rr] >= 0 && bin[rr] != sKeep[0] && bin[rr] != sKeep[1] && bin[rr] != sKeep[2]) {
+        m12[qIdx[t + rr * MW_T]] = -1;
+        dropped++;
+      }
+    }
+    if (dropped) { atomicSub(&sNm, dropped); atomicAdd(&sBadOri, dropped); }
+  }
+  __syncthreads();
   if (t == 0) {
     nmatchesOut[pair] = sNm;
     if (statsOut) { statsOut[pair * 3] = sBadDist; statsOut[pair * 3 + 1] = sBadRatio; statsOut[pair * 3 + 2] = sBadOri; }
@@ -1508,18 +1869,26 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
   if (nPairs <= 0) return hipSuccess;
   MatchParams mp;
   mp.capacity = capacity; mp.window = window; mp.nnratio = nnratio; mp.checkOri = checkOri; mp.b = b;
-  mp.onlyPending = 1;
+  mp.noGeneral = getenv("ORBX_MATCH_NO_GENERAL") ? 1 : 0;  // tests: see which pairs the parallel paths complete
   mp.pair0 = pair0;
-  // pairs with <= 256 octave-0 queries and eligible trains: parallel fixpoint sweeps with the candidate lists in LDS; what
-  // it marks MATCH_PENDING goes to the instance for <= 512 (lists in the pair's global scratch), and the rest to the
-  // general kernel
-  const long long stride = std::max<long long>((long long)capacity * 4, MJ_LARGE_SCRATCH_INTS);  // = ensureMatchScratch
-  hipLaunchKernelGGL((k_match_jacobi<256, 4, 24, false>), dim3(nPairs), dim3(1024), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
-                     matches12, nmatches, stats, scratch, stride);
-  hipLaunchKernelGGL((k_match_jacobi<512, 2, 64, true>), dim3(nPairs), dim3(1024), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
-                     matches12, nmatches, stats, scratch, stride);
-  hipLaunchKernelGGL(k_match, dim3(nPairs), dim3(MATCH_T), 0, st, dFirst, dSecond, kps, desc, nkp, mp, matches12, nmatches,
-                     stats, scratch, stride);
+  // With bestDist <= TH_LOW required, a train at distance s can matter as best only if s <= TH_LOW and as second-best
+  // only if nnratio * s < TH_LOW (ORBmatcher.cpp:84-87: accepted iff bestDist <= nnratio * bestDist2 in f32, and f32
+  // multiplication is monotonic): the wide path lists the candidates below the first s that satisfies neither.
+  mp.dmax = TH_LOW + 1;
+  while (mp.dmax < 257 && !(nnratio * (float)mp.dmax >= (float)TH_LOW)) mp.dmax++;
+  // k_match_jacobi: pairs with <= 256 octave-0 queries and eligible trains, candidate lists and claims in LDS; a pair it
+  // cannot take is prepared there for the wide path (<= 4096; lists in the pair's scratch, built by k_match_wide_lists
+  // over the whole GPU, resolved by k_match_wide_resolve, which also runs the reference's sequential loop for what is
+  // left).  The two wide kernels return at once for the pairs that are already done.
+  const long long stride = matchScratchStride(capacity);  // = ensureMatchScratch
+  const int capl = matchWideCap(capacity);
+  const size_t lds = (size_t)capl * 12;  // head + tOrd + nextQ + outD: 48 KB at MW_CAP
+  hipLaunchKernelGGL((k_match_jacobi<256, 4, 24>), dim3(nPairs), dim3(1024), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
+                     matches12, nmatches, stats, scratch, stride, capl);
+  hipLaunchKernelGGL(k_match_wide_lists, dim3((capl + 63) / 64, nPairs), dim3(256), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
+                     nmatches, scratch, scratch, stride, capl);
+  hipLaunchKernelGGL(k_match_wide_resolve, dim3(nPairs), dim3(MW_T), lds, st, dFirst, dSecond, kps, desc, nkp, mp, matches12,
+                     nmatches, stats, scratch, stride, capl);
   return hipGetLastError();
 }
 

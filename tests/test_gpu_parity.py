@@ -171,6 +171,63 @@ def test_brute_force_match_configs(orbx, ext640, oracle):
         assert (m12 >= 0).sum() > n // 4
 
 
+def _flip_bits(rng, d, max_flips):
+    for i in range(len(d)):
+        for bit in rng.integers(0, 256, int(rng.integers(0, max_flips + 1))):
+            d[i, bit >> 3] ^= np.uint8(1 << (bit & 7))
+    return d
+
+
+def _clustered_desc_pair(orbx, rng, n, protos, flips, w, h, level0_share, jitter):
+    """Frame A: descriptors = prototypes with a few flipped bits (few prototypes -> many near-duplicates); frame B: a
+    permutation of most of A, moved by up to `jitter` px, with more flipped bits, other octaves and angles mixed in."""
+    k1 = np.zeros(n, orbx.KEYPOINT_DTYPE)
+    k1["x"] = rng.uniform(0, w - 1, n).astype(np.float32)
+    k1["y"] = rng.uniform(0, h - 1, n).astype(np.float32)
+    k1["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    k1["octave"] = np.where(rng.uniform(0, 1, n) < level0_share, 0, rng.integers(1, 8, n))
+    d1 = _flip_bits(rng, protos[rng.integers(0, len(protos), n)].copy(), flips)
+    perm = rng.permutation(n)[:n - 7]
+    k2 = k1[perm].copy()
+    k2["x"] = np.clip(k2["x"] + rng.uniform(-jitter, jitter, len(perm)), 0, w - 1).astype(np.float32)
+    k2["y"] = np.clip(k2["y"] + rng.uniform(-jitter, jitter, len(perm)), 0, h - 1).astype(np.float32)
+    k2["angle"] = ((k2["angle"] + 20 + rng.choice([0, 0, 0, 0, 90, 200], len(perm)) + rng.uniform(-3, 3, len(perm))) % 360)
+    k2["octave"] = np.where(rng.uniform(0, 1, len(perm)) < 0.9, k2["octave"], rng.integers(0, 3, len(perm)))
+    d2 = _flip_bits(rng, d1[perm].copy(), flips)
+    return k1, d1, k2, d2
+
+
+def test_wide_matcher_contention(orbx, ext640, oracle, monkeypatch):
+    """Pairs beyond the LDS instances (more than 512 octave-0 queries / eligible trains): descriptors drawn from few
+    prototypes, so trains are claimed by several queries, stolen and blocked, and the fixpoint needs several sweeps.
+    Every case must equal the oracle whichever kernel ends up taking it; the first cases must be taken by the wide path
+    itself (checked by switching the general kernel off)."""
+    rng = np.random.default_rng(17)
+    cases = (  # n, prototypes, max flipped bits, window, w, h, octave-0 share, ratio, checkOri, wide path must take it
+        (1500, 1500, 20, 300, 1920, 1080, 0.7, 0.9, True, True),
+        (3000, 900, 12, 150, 3840, 2160, 0.8, 0.9, True, True),      # ~3 near-duplicates per prototype
+        (4000, 4000, 25, 4096, 3840, 2160, 1.0, 0.9, True, True),    # brute force, 4000 x 4000
+        (2500, 2500, 25, 4096, 3840, 2160, 0.9, 0.6, False, False),  # ratio 0.6: longer lists
+        (1800, 150, 8, 4096, 1920, 1080, 0.9, 0.9, True, False),     # heavy contention: may overflow claims / lists
+        (2400, 200, 6, 400, 1280, 720, 0.9, 0.9, True, False),       # near-duplicates inside the windows
+        (4600, 4600, 40, 200, 3840, 2160, 1.0, 0.9, True, False),    # more than 4096 queries: the general kernel
+    )
+    for (n, npro, flips, win, w, h, share, ratio, ori, must) in cases:
+        protos = rng.integers(0, 256, (npro, 32), dtype=np.uint8)
+        k1, d1, k2, d2 = _clustered_desc_pair(orbx, rng, n, protos, flips, w, h, share, min(win, 300) / 3)
+        fa, fb = orbx.Frame.from_arrays(k1, d1, (0, w, 0, h)), orbx.Frame.from_arrays(k2, d2, (0, w, 0, h))
+        m = orbx.ORBmatcher(ratio, ori, extractor=ext640)
+        onm, om12, ost = oracle.match_init(k1, d1, k2, d2, (0, w, 0, h), win, ratio, ori)
+        nm, m12 = m.SearchForInitialization(fa, fb, win)
+        assert nm == onm and np.array_equal(m12, om12) and list(m.last_stats) == ost.tolist(), (n, npro, win)
+        if must:
+            assert onm > 50
+            monkeypatch.setenv("ORBX_MATCH_NO_GENERAL", "1")
+            nm2, m12b = m.SearchForInitialization(fa, fb, win)
+            monkeypatch.delenv("ORBX_MATCH_NO_GENERAL")
+            assert nm2 == onm and np.array_equal(m12b, om12), "the wide path handed the pair on: %r" % ((n, npro, win),)
+
+
 def test_match_edge_cases(orbx, ext640, oracle):
     KP = orbx.KEYPOINT_DTYPE
     empty = orbx.Frame.from_arrays(np.zeros(0, KP), np.zeros((0, 32), np.uint8), (0, 640, 0, 480))
