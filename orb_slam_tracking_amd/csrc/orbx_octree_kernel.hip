@@ -77,6 +77,7 @@ struct OctScratch {
   u64* xchg;          // LDS exchange buffer for the register sort when keys/nodes live in global memory, else nullptr
   uint32_t* parScr;   // OCT_PAR_SCR_FOR(parCap) dwords of LDS that are free during the partial pass (parallel std::sort replay)
   int parCap;         // largest array the parallel replay may take there (512 or 256 keys); larger ones use the one-lane replay
+  u64* sortTmp;       // [n] second key buffer of the radix sort (global-scratch units only, else nullptr)
 };
 
 __device__ __forceinline__ int divDepth(u64 a, u64 b) {  // first depth at which two path codes differ
@@ -214,6 +215,53 @@ __device__ __forceinline__ int blockScanExcl(int v, int tid, int* ws, int* total
   }
   *total = tot;
   return base + inc - v;
+}
+
+// Stable LSD radix sort of a[0 .. n) by the path code (bits 24 .. 24 + codeBits of the key), 4 bits per pass, for the
+// units whose keys live in global memory (more than OCT_SORT_LDS candidates: the in-memory bitonic network needs
+// log2(n)^2 / 2 barrier-separated sweeps, 120 at n = 32768).  The keys arrive ordered by their low 24 bits (the candidate
+// position grows with the index), so a stable sort by the code alone yields the full key order.  Thread t owns the
+// contiguous block [t * chunk, (t + 1) * chunk): per pass it counts its digits into cnt[digit][t], the 16 x 256 counters
+// are scanned digit-major, and the block is scattered in order.  A pass in which every key has the same digit is
+// skipped.  `cnt` = 4096 dwords of LDS, `ws` = 4 ints of LDS, b = second buffer of n keys.  Result in a.
+__device__ void radixSortCodes(u64* a, u64* b, int n, int tid, uint32_t* cnt, int* ws, int codeBits) {
+  const int chunk = (n + OCT_T - 1) / OCT_T;
+  const int lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+  u64* src = a;
+  u64* dst = b;
+  for (int shift = 24; shift < 24 + codeBits; shift += 4) {
+#pragma unroll
+    for (int d = 0; d < 16; d++) cnt[d * OCT_T + tid] = 0;
+    const int d0 = (int)((src[0] >> shift) & 15);
+    bool same = true;
+    for (int i = lo; i < hi; i++) {
+      const int d = (int)((src[i] >> shift) & 15);
+      same &= d == d0;
+      cnt[d * OCT_T + tid]++;
+    }
+    if (__syncthreads_and(same ? 1 : 0)) continue;  // (also the barrier after the counting)
+    // exclusive scan of the counters in (digit, thread) order: thread t owns entries [16 t, 16 t + 16)
+    uint32_t loc[16];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { loc[k] = cnt[16 * tid + k]; sum += (int)loc[k]; }
+    int total;
+    uint32_t run = (uint32_t)blockScanExcl(sum, tid, ws, &total);
+#pragma unroll
+    for (int k = 0; k < 16; k++) { cnt[16 * tid + k] = run; run += loc[k]; }
+    __syncthreads();
+    for (int i = lo; i < hi; i++) {
+      const u64 key = src[i];
+      const int d = (int)((key >> shift) & 15);
+      dst[cnt[d * OCT_T + tid]++] = key;
+    }
+    __syncthreads();
+    u64* t2 = src; src = dst; dst = t2;
+  }
+  if (src != a) {
+    for (int i = tid; i < n; i += OCT_T) a[i] = src[i];
+    __syncthreads();
+  }
 }
 
 // ---- literal replay of the PARTITION PHASE of libstdc++'s std::sort (bits/stl_algo.h: __introsort_loop) on packed
@@ -548,7 +596,12 @@ __device__ void octreeSelect(const OctScratch S, int n, const OctLevel L, int le
   if (tid < OCT_DEPTH + 2) { cntDiv[tid] = 0; cntAlone[tid] = 0; }
   __syncthreads();
   OCT_STAMP(1);
-  bitonicSort(S.keys, nPad, tid, S.xchg);
+  if (nPad > OCT_SORT_LDS && S.sortTmp && S.xchg) {
+    const int rootBits = L.nIni > 1 ? 32 - __builtin_clz((unsigned)(L.nIni - 1)) : 0;
+    radixSortCodes(S.keys, S.sortTmp, n, tid, reinterpret_cast<uint32_t*>(S.xchg), ws, 2 * OCT_DEPTH + rootBits);
+  } else {
+    bitonicSort(S.keys, nPad, tid, S.xchg);
+  }
   OCT_STAMP(2);
 
   // ---- 2. divergence depths, S_d (distinct depth-d prefixes), singles_d -----------------------------------------
@@ -886,6 +939,8 @@ __device__ void octreeGlobalUnit(const uint32_t* __restrict__ cand, const int* _
   S.nodeAlive = p; p += (size_t)(mCap + fCap + 8);
   p = (uint8_t*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
   uint32_t* candBuf = (uint32_t*)p;  // [nPad] positions of the unit's candidates
+  p += nPad * 4;
+  S.sortTmp = (u64*)p;               // [nPad] (p stays 16-byte aligned: nPad is a multiple of 256)
   S.segBase = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
   const int n = gatherCandidates(cellCount + (int64_t)f * P.nCellsTotal + P.lev[level].cellBase, P.lev[level].nCells,
                                  P.lev[level].segCap, candBuf, nMax, threadIdx.x, gws);
@@ -972,7 +1027,7 @@ size_t octScratchBytes(int nMax, int qMax) {
   size_t mPad = 256;
   while (mPad < mCap) mPad <<= 1;
   size_t b = nPad * 8 + mPad * 8 + (size_t)2 * qMax * 8 + nPad * 4 + (mCap + fCap) * 8 + (size_t)3 * qMax * 4 + 2 * (nPad + 8) +
-             2 * (mCap + fCap + 8) + 16 + nPad * 4 /* gathered candidates */;
+             2 * (mCap + fCap + 8) + 16 + nPad * 4 /* gathered candidates */ + nPad * 8 /* radix sort buffer */;
   return (b + 255) / 256 * 256;
 }
 
@@ -1013,17 +1068,19 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
   // workgroups are dispatched x-fastest: all frames of level 0 first, then level 1, ...  The units of the lowest levels
   // run longest (most candidates, largest quota), so this is longest-processing-time-first and keeps the tail short.
   dim3 grid(nFrames, P.nlevels, 1), block(OCT_T, 1, 1);
-  const bool lds = maxQuota <= 256;
-  // the LDS variant handles units it cannot take (more than 2048 candidates, node-table overflow) itself on global scratch
+  // the LDS variant handles the units it cannot take (more than NMAX candidates, quota above 256, node-table overflow)
+  // itself on global scratch, so it is launched whatever the largest quota is: the higher levels of a large configuration
+  // still fit.
   // nHint = largest candidate count of a unit in the previous batch (0 = unknown): with 6 % headroom below 1024 the
   // smaller instance runs four workgroups per CU instead of three; a unit that outgrows it is still handled correctly
   // (global scratch), only slower
   static const bool noSmall = getenv("ORBX_OCT_NO_SMALL") != nullptr;  // diagnostics: always the 2048-candidate instance
-  if (lds && nHint > 0 && nHint <= 960 && !noSmall)
+  if (maxQuota >= (1 << 30))  // test hook (orbx_debug_distribute_device variant 1): every unit on global scratch
+    hipLaunchKernelGGL(k_octree_global, grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, 1);
+  else if (nHint > 0 && nHint <= 960 && !noSmall)
     hipLaunchKernelGGL((k_octree_lds<1024, 256>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN);
-  else if (lds)
+  else
     hipLaunchKernelGGL((k_octree_lds<2048, 256>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN);
-  else hipLaunchKernelGGL(k_octree_global, grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, 1);
   return hipGetLastError();
 }
 

@@ -6,9 +6,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import orb_slam_tracking_amd as orbx
 from orb_slam_tracking_amd import synth
-B, cap, w, h = 32, 1000, 640, 480
+# usage: oct_stamps.py [width height nfeatures iniThFAST minThFAST batch]
+a = [int(x) for x in sys.argv[1:7]] + [640, 480, 1000, 20, 7, 32][len(sys.argv) - 1:]
+w, h, cap, ini, mn, B = a
 frames = synth.synth_frames(B, w, h, 1000)
-e = orbx.ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+e = orbx.ORBextractor(cap, 1.2, 8, ini, mn, max_width=w, max_height=h, max_batch=B)
 d_img = torch.from_numpy(frames).cuda()
 d_k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"); d_d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
 d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
