@@ -982,6 +982,7 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
   //      Hamming distance.  The order inside a list is irrelevant: the comparison key is a total order. ----
   uint32_t* const myList = candList + (size_t)part * MJ_CP * MJ_CAP + q;
   int nCand = 0;
+  bool anyIn = false;
   if (hasWindow) {
     for (int e0 = part; e0 < nT; e0 += 4 * MJ_P) {  // four trains per step: 16 independent LDS broadcasts in flight
       int cx[4], cy[4];
@@ -1001,13 +1002,15 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
         int dist = 0;
 #pragma unroll
         for (int w = 0; w < 8; w++) dist += __popc(qd[w] ^ tDesc[w][e]);
+        anyIn = true;
+        if (dist >= mp.dmax) continue;  // can neither be accepted nor fail the ratio test of a nearer train (launch_match)
         if (nCand < MJ_CP) myList[nCand * MJ_CAP] = ((uint32_t)dist << 16) | (uint32_t)e;
         nCand++;
       }
     }
     if (nCand > MJ_CP) sOverflow = 1;
   }
-  pCnt[part][q] = (uint8_t)min(nCand, 255);
+  pCnt[part][q] = (uint8_t)(min(nCand, 127) | (anyIn ? 0x80 : 0));  // bit 7: the part saw a train in the window
   if (t < nT) tOrd[t] = ((uint32_t)(tCx[t] * ORBX_GRID_ROWS + tCy[t]) << 20) | (uint32_t)tIdx[t];
   __syncthreads();
   if (sOverflow) {  // a window too full for the lists: the pair goes to the wide path
