@@ -139,6 +139,21 @@ int orbx_extract_match_batch_device(orbx_ctx* ctx, int n_frames, const uint8_t* 
                                     const int32_t* h_second, const orbx_bounds* bounds, int window_size, float nnratio,
                                     int check_orientation, int32_t* d_matches12, int32_t* d_nmatches, int32_t* d_stats);
 
+/* Stream-ordered form of the call above for callers that keep the device busy across batches (a tracker that prepares
+ * batch k+1 while batch k runs): issues the batch and returns.  At most two batches are in flight - a third call first
+ * waits for the oldest.  The outputs, counts and errors of a batch are valid once an orbx_wait_one / orbx_wait has covered
+ * it (an error of an earlier batch can also be returned by the call that has to wait for it); batches in flight together
+ * must be given different output arrays; the input frames must stay untouched until their batch has been waited for.
+ * Every other call on the context may be used in between (the synchronous ones simply queue behind). */
+int orbx_extract_match_batch_device_async(orbx_ctx* ctx, int n_frames, const uint8_t* d_imgs, int width, int height,
+                                          int stride, size_t frame_stride_bytes, orbx_keypoint* d_kps, uint8_t* d_desc32,
+                                          int capacity, int32_t* d_n_out, int n_pairs, const int32_t* h_first,
+                                          const int32_t* h_second, const orbx_bounds* bounds, int window_size,
+                                          float nnratio, int check_orientation, int32_t* d_matches12,
+                                          int32_t* d_nmatches, int32_t* d_stats);
+int orbx_wait_one(orbx_ctx* ctx); /* the oldest batch in flight (ORBX_OK if there is none) */
+int orbx_wait(orbx_ctx* ctx);     /* all batches in flight */
+
 /* ---- between extractor and matcher: Frame::UndistortKeyPoints / ComputeImageBounds ---------- */
 /* (SlamTypes/Frame.cpp:101-161)  The camera as the reference holds it: mK's four entries and
  * mDistCoef = (k1, k2, p1, p2), all CV_32F (Config/Settings.hpp:28-39). */
@@ -197,6 +212,8 @@ int orbx_check_fundamental(orbx_ctx* ctx, int n_models, const float* F21, const 
 /* enable: record hipEvents around every stage; accumulated device ms and launch counts since the
  * last reset are returned by orbx_profile_get (arrays of ORBX_STAGE_COUNT). */
 int orbx_profile_enable(orbx_ctx* ctx, int on);
+/* the same for a subset of the stages (bit s = ORBX_STAGE_s): every bracketed stage costs two event records on its stream */
+int orbx_profile_stages(orbx_ctx* ctx, unsigned stage_mask);
 int orbx_profile_reset(orbx_ctx* ctx);
 int orbx_profile_get(orbx_ctx* ctx, double* ms, int64_t* launches);
 

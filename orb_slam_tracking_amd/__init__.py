@@ -93,6 +93,11 @@ def lib() -> ctypes.CDLL:
                                                vp, vp, vp]
     L.orbx_extract_match_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, sz, vp, vp, i32, vp, i32, vp, vp,
                                                   ctypes.POINTER(_Bounds), i32, f32, i32, vp, vp, vp]
+    L.orbx_extract_match_batch_device_async.argtypes = [vp, i32, vp, i32, i32, i32, sz, vp, vp, i32, vp, i32, vp, vp,
+                                                  ctypes.POINTER(_Bounds), i32, f32, i32, vp, vp, vp]
+    L.orbx_wait_one.argtypes = [vp]
+    L.orbx_wait.argtypes = [vp]
+    L.orbx_profile_stages.argtypes = [vp, ctypes.c_uint]
     L.orbx_undistort_keypoints.argtypes = [vp, vp, i32, ctypes.POINTER(_Camera), vp]
     L.orbx_undistort_batch_device.argtypes = [vp, i32, vp, vp, i32, ctypes.POINTER(_Camera), vp]
     L.orbx_image_bounds.argtypes = [vp, ctypes.POINTER(_Camera), i32, i32, ctypes.POINTER(_Bounds)]
@@ -264,6 +269,31 @@ class ORBextractor:
                                                     _ptr(d_nmatches), _ptr(d_stats))
         self._check(r, "orbx_extract_match_batch_device")
 
+    def extract_match_batch_device_async(self, d_imgs, n_frames: int, width: int, height: int, stride: int, frame_stride: int,
+                                         d_kps, d_desc, d_n, first: np.ndarray, second: np.ndarray,
+                                         bounds: Tuple[int, int, int, int], d_matches12, d_nmatches, d_stats=None,
+                                         windowSize: int = 100, nnratio: float = 0.9, checkOri: bool = True,
+                                         capacity: Optional[int] = None) -> None:
+        """Stream-ordered form: issues the batch and returns; at most two batches in flight (``wait_one`` / ``wait``).
+        Batches in flight together need different output arrays."""
+        first = np.ascontiguousarray(first, np.int32)
+        second = np.ascontiguousarray(second, np.int32)
+        b = _Bounds(*[int(v) for v in bounds])
+        r = self._L.orbx_extract_match_batch_device_async(self._h, int(n_frames), _ptr(d_imgs), int(width), int(height),
+                                                          int(stride), int(frame_stride), _ptr(d_kps), _ptr(d_desc),
+                                                          int(capacity or self.capacity), _ptr(d_n), len(first), _ptr(first),
+                                                          _ptr(second), ctypes.byref(b), int(windowSize), float(nnratio),
+                                                          int(bool(checkOri)), _ptr(d_matches12), _ptr(d_nmatches), _ptr(d_stats))
+        self._check(r, "orbx_extract_match_batch_device_async")
+
+    def wait_one(self) -> None:
+        """Waits for the oldest batch in flight."""
+        self._check(self._L.orbx_wait_one(self._h), "orbx_wait_one")
+
+    def wait(self) -> None:
+        """Waits for every batch in flight."""
+        self._check(self._L.orbx_wait(self._h), "orbx_wait")
+
     # -- Converter::toGray (Utils/Converter.cpp:5-19) --------------------------------------------------
     def to_gray(self, image: np.ndarray, bRGB: bool = False) -> np.ndarray:
         """(h, w) or (h, w, 1) copies; (h, w, 3) is cvtColor(RGB2GRAY if bRGB else BGR2GRAY); else OrbxError (returns false upstream)."""
@@ -356,6 +386,13 @@ class ORBextractor:
     # -- measurement / test hooks ------------------------------------------------------------------
     def profile_enable(self, on: bool = True):
         self._L.orbx_profile_enable(self._h, int(on))
+
+    def profile_stages(self, stages) -> None:
+        """Bracket only the given stages (names of STAGES) with events."""
+        mask = 0
+        for name in stages:
+            mask |= 1 << STAGES.index(name)
+        self._L.orbx_profile_stages(self._h, mask)
 
     def profile_reset(self):
         self._L.orbx_profile_reset(self._h)

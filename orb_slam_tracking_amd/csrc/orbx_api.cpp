@@ -37,7 +37,8 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
 hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, const int* cellCount, const OctLaunch& P,
                          SelKp* selStage, int* nselLevel, uint8_t* scratch, int maxQuota, int* maxN, int nHint);
 hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage, const int* nselLevel, const OctLaunch& P,
-                              SelKp* sel, int* nsel, int selCap, int* err, int* maxN, int* hostMaxN);
+                              SelKp* sel, int* nsel, int* nselUser, int* hostNsel, int selCap, int* hostErr, int* maxN,
+                              int* hostMaxN);
 size_t octScratchBytes(int nMax, int qMax);
 hipError_t launch_to_gray(hipStream_t st, int nFrames, const uint8_t* src, long long srcFrameStride, int sstride, int w, int h,
                           int channels, int rgb, uint8_t* dst, long long dstFrameStride, int dstride);
@@ -98,7 +99,10 @@ struct orbx_ctx {
   int* dNselLevel = nullptr;
   uint8_t* dOctScratch = nullptr;
   size_t octScratchBytes = 0;
-  int* hFlags = nullptr;  // pinned: [0] candidate overflow, [1] selection error
+  int* hFlags = nullptr;  // pinned, written by k_sel_compact through hFlagsDev: [1] selection error ([0] unused)
+  int* hFlagsDev = nullptr;
+  int* hNselDev = nullptr;  // device view of hNsel: k_sel_compact stores the per-frame counts straight to the host
+  std::vector<int32_t> lastPairs;  // the pair list dPairs holds (first[], second[]): an unchanged list is not copied again
   uint8_t* dIn = nullptr;
   size_t inBytes = 0;
   orbx_keypoint* dKps = nullptr;
@@ -128,9 +132,14 @@ struct orbx_ctx {
   hipEvent_t evFork = nullptr, evJoin = nullptr;
 
   // profiling
-  bool prof = false;
-  hipEvent_t ev[2][ORBX_STAGE_COUNT][2]{};
-  bool used[2][ORBX_STAGE_COUNT]{};
+  unsigned profMask = 0;  // stages whose launches are bracketed by events (bit = ORBX_STAGE_*)
+  // [parity of the batch][stream slot][stage][begin/end]: two batches may be in flight (orbx_*_async)
+  hipEvent_t ev[2][2][ORBX_STAGE_COUNT][2]{};
+  bool used[2][2][ORBX_STAGE_COUNT]{};
+  hipEvent_t evDone[2]{};  // end of the batch with that parity, recorded on st
+  unsigned seqIssue = 0;   // batches issued so far
+  int pending = 0;         // issued and not yet waited for (0 .. 2)
+  int parity = 0;          // of the batch being issued
   double ms[ORBX_STAGE_COUNT]{};
   int64_t launches[ORBX_STAGE_COUNT]{};
 
@@ -377,25 +386,25 @@ struct StageTimer {
   orbx_ctx* c;
   int stage, si;
   hipStream_t st;
-  StageTimer(orbx_ctx* c_, int s, int si_, hipStream_t st_) : c(c_), stage(s), si(si_), st(st_) {
-    if (c->prof) (void)hipEventRecord(c->ev[si][s][0], st);
+  bool on;
+  StageTimer(orbx_ctx* c_, int s, int si_, hipStream_t st_) : c(c_), stage(s), si(si_), st(st_), on((c_->profMask >> s) & 1u) {
+    if (on) (void)hipEventRecord(c->ev[c->parity][si][s][0], st);
   }
   void stop(int nLaunches) {
-    if (c->prof) {
-      (void)hipEventRecord(c->ev[si][stage][1], st);
+    if (on) {
+      (void)hipEventRecord(c->ev[c->parity][si][stage][1], st);
       c->launches[stage] += nLaunches;
-      c->used[si][stage] = true;
+      c->used[c->parity][si][stage] = true;
     }
   }
 };
-void collectProfile(orbx_ctx* c) {
-  if (!c->prof) return;
+void collectProfile(orbx_ctx* c, int parity) {
   for (int si = 0; si < 2; si++)
     for (int s = 0; s < ORBX_STAGE_COUNT; s++) {
-      if (!c->used[si][s]) continue;
-      c->used[si][s] = false;
+      if (!c->used[parity][si][s]) continue;
+      c->used[parity][si][s] = false;
       float ms = 0;
-      if (hipEventElapsedTime(&ms, c->ev[si][s][0], c->ev[si][s][1]) == hipSuccess) c->ms[s] += ms;
+      if (hipEventElapsedTime(&ms, c->ev[parity][si][s][0], c->ev[parity][si][s][1]) == hipSuccess) c->ms[s] += ms;
     }
 }
 
@@ -414,6 +423,7 @@ struct ExtractArgs {
   orbx_keypoint* dKps;
   uint8_t* dDesc;
   int capacity;
+  int* dNuser;  // the caller's per-frame count array (device), or nullptr
 };
 
 // Row bands of k_pyramid_bands.  Band b owns rows [b*h/K, (b+1)*h/K) of every level and, on top of that, every row of
@@ -444,15 +454,16 @@ PyrBands computePyrBands(const orbx_ctx* ctx, int K) {
   return pb;
 }
 
-// issues every kernel of the extraction of frames [f0, f0 + n) on stream `st` (stream slot si); no synchronisation
-int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const ExtractArgs& a) {
+// issues the kernels of the extraction of frames [f0, f0 + n) on stream `st` (stream slot si), no synchronisation:
+// part 0 = pyramid + FAST, part 1 = selection + descriptors (two calls, so that the two half-batch chains can be issued
+// alternately and the second chain does not wait for the host to have issued all of the first)
+int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const ExtractArgs& a, int part) {
   Geom g = ctx->g;
   g.frame0 = f0;
   OctLaunch oct = ctx->oct;
   oct.frame0 = f0;
   const int nl = g.nlevels;
-  // per-cell candidate counts of these frames (k_fast writes the non-empty cells only)
-  HIPCHK(hipMemsetAsync(ctx->dCellCount + (size_t)f0 * g.nCellsTotal, 0, sizeof(int) * (size_t)n * g.nCellsTotal, st));
+  if (part == 0) {
   // whole pyramid in one launch (k_pyramid_bands) when every level meets the dword path's preconditions and the batch
   // is large enough to fill the device with (bands x frames) workgroups; otherwise one launch per level
   bool banded = nl > 1 && a.aligned0 && n >= 32 && !getenv("ORBX_NO_BANDS");
@@ -480,14 +491,16 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
     HIPCHK(launch_fast(st, n, a.dImg0, a.frameStride0, a.aligned0, ctx->dPyr, g, ctx->dCand, ctx->dCellCount));
     tm.stop(1);
   }
+  return ORBX_OK;
+  }  // part 0
   {  // selection stage: quadtree per (frame, level), then level-major compaction
     StageTimer tm(ctx, ORBX_STAGE_SELECT, si, st);
     // per-level candidate maxima of this stream slot: device accumulators + their pinned host mirror (read after the sync)
     int* dMax = ctx->dMaxN + si * ORBX_MAX_LEVELS;
     HIPCHK(launch_octree(st, n, ctx->dCand, ctx->dCellCount, oct, ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, ctx->maxQuota,
                          dMax, ctx->candHint));
-    HIPCHK(launch_sel_compact(st, n, ctx->dSelStage, ctx->dNselLevel, oct, ctx->dSel, ctx->dNsel, g.selCap, ctx->dOverflow + 1, dMax,
-                              ctx->hMaxNDev + si * ORBX_MAX_LEVELS));
+    HIPCHK(launch_sel_compact(st, n, ctx->dSelStage, ctx->dNselLevel, oct, ctx->dSel, ctx->dNsel, a.dNuser, ctx->hNselDev, g.selCap,
+                              ctx->hFlagsDev + 1, dMax, ctx->hMaxNDev + si * ORBX_MAX_LEVELS));
     ctx->maxSlotsUsed |= 1 << si;
     tm.stop(2);
   }
@@ -525,15 +538,70 @@ int issueMatch(orbx_ctx* ctx, int si, hipStream_t st, int pair0, int n, const Ma
   return ORBX_OK;
 }
 
+// Pair list -> dPairs (first[], then second[]).  Trackers match the same pairs batch after batch, so an unchanged list
+// is not copied again (two copy commands less at the head of the stream).
+int uploadPairs(orbx_ctx* ctx, int nPairs, const int32_t* hFirst, const int32_t* hSecond, hipStream_t st) {
+  std::vector<int32_t>& lp = ctx->lastPairs;
+  if ((int)lp.size() == 2 * nPairs && std::memcmp(lp.data(), hFirst, sizeof(int32_t) * nPairs) == 0 &&
+      std::memcmp(lp.data() + nPairs, hSecond, sizeof(int32_t) * nPairs) == 0)
+    return ORBX_OK;
+  lp.clear();  // (stays empty if a copy fails)
+  HIPCHK(hipMemcpyAsync(ctx->dPairs, hFirst, sizeof(int) * nPairs, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->dPairs + nPairs, hSecond, sizeof(int) * nPairs, hipMemcpyHostToDevice, st));
+  lp.assign(hFirst, hFirst + nPairs);
+  lp.insert(lp.end(), hSecond, hSecond + nPairs);
+  return ORBX_OK;
+}
+
+// Waits for the oldest batch in flight and does its host-side epilogue: stage times, the selection stage's instance hint
+// for the next batch, the (sticky) selection error flag.
+int waitOldest(orbx_ctx* ctx) {
+  if (ctx->pending <= 0) return ORBX_OK;
+  const int parity = (int)((ctx->seqIssue - (unsigned)ctx->pending) & 1u);
+  HIPCHK(hipEventSynchronize(ctx->evDone[parity]));
+  ctx->pending--;
+  collectProfile(ctx, parity);
+  {  // largest candidate count of a unit in the batches seen so far: picks the selection kernel's instance for the next one
+    int m = 0;
+    for (int q = 0; q < 2; q++)
+      if (ctx->maxSlotsUsed & (1 << q))
+        for (int l = 0; l < ctx->p.nlevels; l++) m = std::max(m, ctx->hMaxN[q * ORBX_MAX_LEVELS + l]);
+    ctx->candHint = m;
+    if (ctx->pending == 0) ctx->maxSlotsUsed = 0;
+  }
+  if (ctx->hFlags[1]) {  // raised by k_sel_compact through mapped host memory
+    ctx->hFlags[1] = 0;
+    ctx->err = "selection stage: more candidates or nodes than its scratch can hold";
+    return ORBX_E_CAPACITY;
+  }
+  return ORBX_OK;
+}
+int waitAll(orbx_ctx* ctx) {
+  int r = ORBX_OK;
+  while (ctx->pending > 0) {
+    const int q = waitOldest(ctx);
+    if (q == ORBX_E_HIP) return q;  // (pending may not have moved)
+    if (r == ORBX_OK) r = q;
+  }
+  return r;
+}
+
 // The whole extraction (and optionally the pair matching) of one batch.  d_img0: device pointer of frame 0 / level 0.
 // Large batches are issued as two half-batches on two streams so that the latency-bound stages of one half (quadtree
 // selection, matching) overlap the VALU-bound stages of the other (FAST, descriptors).
+// async: return once the batch is issued (at most two in flight; see orbx_extract_match_batch_device_async).
 int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int stride0, long long frameStride0,
-                orbx_keypoint* dKps, uint8_t* dDesc, int capacity, int* dNout, const MatchArgs* match) {
+                orbx_keypoint* dKps, uint8_t* dDesc, int capacity, int* dNout, const MatchArgs* match, bool async = false) {
   if (B <= 0) return ORBX_E_BADARG;
   if (B > ctx->maxB) { ctx->err = "batch larger than max_batch"; return ORBX_E_BADARG; }
   if (capacity < ctx->selCap) return ORBX_E_CAPACITY;
-  int r = ensureGeometry(ctx, w, h, stride0);
+  int r = ORBX_OK;
+  if (ctx->pending >= 2) {  // the events of this parity are still in use
+    r = waitOldest(ctx);
+    if (r != ORBX_OK) return r;
+  }
+  ctx->parity = (int)(ctx->seqIssue & 1u);
+  r = ensureGeometry(ctx, w, h, stride0);
   if (r != ORBX_OK) return r;
   hipStream_t st = ctx->st;
   ExtractArgs a;
@@ -548,10 +616,10 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
       if (match->hFirst[p] < 0 || match->hFirst[p] >= B || match->hSecond[p] < 0 || match->hSecond[p] >= B) return ORBX_E_BADARG;
     r = ensureMatchScratch(ctx, nPairs, capacity);
     if (r != ORBX_OK) return r;
-    HIPCHK(hipMemcpyAsync(ctx->dPairs, match->hFirst, sizeof(int) * nPairs, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(ctx->dPairs + nPairs, match->hSecond, sizeof(int) * nPairs, hipMemcpyHostToDevice, st));
+    r = uploadPairs(ctx, nPairs, match->hFirst, match->hSecond, st);
+    if (r != ORBX_OK) return r;
   }
-  HIPCHK(hipMemsetAsync(ctx->dOverflow, 0, sizeof(int) * 2, st));  // candidate-overflow + selection-error flags
+  a.dNuser = dNout;
 
   static const int splitMin = getenv("ORBX_NO_SPLIT") ? (1 << 30) : 16;
   const bool split = ctx->st2 != nullptr && B >= splitMin;
@@ -567,41 +635,35 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
   if (split) {
     HIPCHK(hipEventRecord(ctx->evFork, st));
     HIPCHK(hipStreamWaitEvent(ctx->st2, ctx->evFork, 0));
-    r = issueExtract(ctx, 0, st, 0, n0, a);
+    // the two chains are issued alternately: the device starts on the second while the host still issues the first
+    r = issueExtract(ctx, 0, st, 0, n0, a, 0);
     if (r != ORBX_OK) return r;
-    if (dNout) HIPCHK(hipMemcpyAsync(dNout, ctx->dNsel, sizeof(int) * n0, hipMemcpyDeviceToDevice, st));
+    r = issueExtract(ctx, 1, ctx->st2, n0, B - n0, a, 0);
+    if (r != ORBX_OK) return r;
+    r = issueExtract(ctx, 0, st, 0, n0, a, 1);
+    if (r != ORBX_OK) return r;
     if (nPairs > 0) { r = issueMatch(ctx, 0, st, 0, p0, *match, dKps, dDesc, dN, capacity); if (r != ORBX_OK) return r; }
-    r = issueExtract(ctx, 1, ctx->st2, n0, B - n0, a);
+    r = issueExtract(ctx, 1, ctx->st2, n0, B - n0, a, 1);
     if (r != ORBX_OK) return r;
-    if (dNout) HIPCHK(hipMemcpyAsync(dNout + n0, ctx->dNsel + n0, sizeof(int) * (B - n0), hipMemcpyDeviceToDevice, ctx->st2));
     if (nPairs > 0) { r = issueMatch(ctx, 1, ctx->st2, p0, p1 - p0, *match, dKps, dDesc, dN, capacity); if (r != ORBX_OK) return r; }
     HIPCHK(hipEventRecord(ctx->evJoin, ctx->st2));
     HIPCHK(hipStreamWaitEvent(st, ctx->evJoin, 0));
     if (nPairs > p1) { r = issueMatch(ctx, 0, st, p1, nPairs - p1, *match, dKps, dDesc, dN, capacity); if (r != ORBX_OK) return r; }
   } else {
-    r = issueExtract(ctx, 0, st, 0, B, a);
+    r = issueExtract(ctx, 0, st, 0, B, a, 0);
     if (r != ORBX_OK) return r;
-    if (dNout) HIPCHK(hipMemcpyAsync(dNout, ctx->dNsel, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
+    r = issueExtract(ctx, 0, st, 0, B, a, 1);
+    if (r != ORBX_OK) return r;
     if (nPairs > 0) { r = issueMatch(ctx, 0, st, 0, nPairs, *match, dKps, dDesc, dN, capacity); if (r != ORBX_OK) return r; }
   }
-  HIPCHK(hipMemcpyAsync(ctx->hNsel, ctx->dNsel, sizeof(int) * B, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(ctx->hFlags, ctx->dOverflow, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  collectProfile(ctx);
-  {  // largest candidate count of a unit in this batch: picks the selection kernel's instance for the next batch
-    int m = 0;
-    for (int q = 0; q < 2; q++)
-      if (ctx->maxSlotsUsed & (1 << q))
-        for (int l = 0; l < ctx->p.nlevels; l++) m = std::max(m, ctx->hMaxN[q * ORBX_MAX_LEVELS + l]);
-    ctx->candHint = m;
-    ctx->maxSlotsUsed = 0;
-  }
+  // (the per-frame counts and the error flag arrive in pinned host memory straight from k_sel_compact)
+  HIPCHK(hipEventRecord(ctx->evDone[ctx->parity], st));
+  ctx->seqIssue++;
+  ctx->pending++;
   ctx->lastImg0 = dImg0;
   ctx->lastFrameStride0 = frameStride0;
   ctx->lastB = B;
-  if (ctx->hFlags[0]) { ctx->err = "internal: candidate buffer overflow"; return ORBX_E_CAPACITY; }
-  if (ctx->hFlags[1]) { ctx->err = "selection stage: more candidates or nodes than its scratch can hold"; return ORBX_E_CAPACITY; }
-  return ORBX_OK;
+  return async ? ORBX_OK : waitAll(ctx);
 }
 
 }  // namespace
@@ -690,12 +752,18 @@ int orbx_create(const orbx_params* params, int device_id, int max_width, int max
   if (hipMemset(ctx->dMaxN, 0, 2 * ORBX_MAX_LEVELS * sizeof(int)) != hipSuccess) return fail(ORBX_E_HIP);
   ALLOCH(ctx->hMaxN, 2 * ORBX_MAX_LEVELS * sizeof(int));
   if (hipHostGetDevicePointer((void**)&ctx->hMaxNDev, ctx->hMaxN, 0) != hipSuccess) return fail(ORBX_E_HIP);
+  if (hipHostGetDevicePointer((void**)&ctx->hNselDev, ctx->hNsel, 0) != hipSuccess) return fail(ORBX_E_HIP);
+  if (hipHostGetDevicePointer((void**)&ctx->hFlagsDev, ctx->hFlags, 0) != hipSuccess) return fail(ORBX_E_HIP);
+  ctx->hFlags[0] = ctx->hFlags[1] = 0;
 #undef ALLOC
 #undef ALLOCH
   for (int si = 0; si < 2; si++)
     for (int s2 = 0; s2 < ORBX_STAGE_COUNT; s2++)
       for (int k = 0; k < 2; k++)
-        if (hipEventCreate(&ctx->ev[si][s2][k]) != hipSuccess) return fail(ORBX_E_HIP);
+        for (int par = 0; par < 2; par++)
+          if (hipEventCreate(&ctx->ev[par][si][s2][k]) != hipSuccess) return fail(ORBX_E_HIP);
+  for (int par = 0; par < 2; par++)
+    if (hipEventCreateWithFlags(&ctx->evDone[par], hipEventDisableTiming) != hipSuccess) return fail(ORBX_E_HIP);
   if (hipStreamCreateWithFlags(&ctx->st2, hipStreamNonBlocking) != hipSuccess) return fail(ORBX_E_HIP);
   if (hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming) != hipSuccess) return fail(ORBX_E_HIP);
   if (hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming) != hipSuccess) return fail(ORBX_E_HIP);
@@ -719,7 +787,10 @@ void orbx_destroy(orbx_ctx* ctx) {
   for (int si = 0; si < 2; si++)
     for (int s = 0; s < ORBX_STAGE_COUNT; s++)
       for (int k = 0; k < 2; k++)
-        if (ctx->ev[si][s][k]) (void)hipEventDestroy(ctx->ev[si][s][k]);
+        for (int par = 0; par < 2; par++)
+          if (ctx->ev[par][si][s][k]) (void)hipEventDestroy(ctx->ev[par][si][s][k]);
+  for (int par = 0; par < 2; par++)
+    if (ctx->evDone[par]) (void)hipEventDestroy(ctx->evDone[par]);
   if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
   if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
   if (ctx->st2) (void)hipStreamDestroy(ctx->st2);
@@ -884,6 +955,7 @@ int ensureMatchScratch(orbx_ctx* ctx, int nPairs, int capacity) {
   if ((size_t)nPairs > ctx->pairsCap) {
     if (ctx->dPairs) (void)hipFree(ctx->dPairs);
     ctx->dPairs = nullptr;
+    ctx->lastPairs.clear();
     ctx->pairsCap = 0;
     HIPCHK(hipMalloc((void**)&ctx->dPairs, (size_t)nPairs * 2 * sizeof(int)));
     ctx->pairsCap = nPairs;
@@ -929,25 +1001,29 @@ int orbx_match_init_batch_device(orbx_ctx* ctx, int n_pairs, const int32_t* h_fi
   if (bounds->max_x <= bounds->min_x || bounds->max_y <= bounds->min_y) return ORBX_E_BADARG;
   if (n_pairs == 0) return ORBX_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
-  int r = ensureMatchScratch(ctx, n_pairs, capacity);
+  int r = waitAll(ctx);  // batches issued with the _async call
   if (r != ORBX_OK) return r;
-  HIPCHK(hipMemcpyAsync(ctx->dPairs, h_first, sizeof(int) * n_pairs, hipMemcpyHostToDevice, ctx->st));
-  HIPCHK(hipMemcpyAsync(ctx->dPairs + n_pairs, h_second, sizeof(int) * n_pairs, hipMemcpyHostToDevice, ctx->st));
+  ctx->parity = (int)(ctx->seqIssue & 1u);
+  r = ensureMatchScratch(ctx, n_pairs, capacity);
+  if (r != ORBX_OK) return r;
+  r = uploadPairs(ctx, n_pairs, h_first, h_second, ctx->st);
+  if (r != ORBX_OK) return r;
   MatchArgs m;
   m.nPairs = n_pairs; m.b = *bounds; m.window = window_size; m.nnratio = nnratio; m.checkOri = check_orientation;
   m.dMatches12 = d_matches12; m.dNmatches = d_nmatches; m.dStats = d_stats;
   r = issueMatch(ctx, 0, ctx->st, 0, n_pairs, m, d_kps, d_desc32, d_n, capacity);
   if (r != ORBX_OK) return r;
   HIPCHK(hipStreamSynchronize(ctx->st));
-  collectProfile(ctx);
+  collectProfile(ctx, ctx->parity);
   return ORBX_OK;
 }
 
-int orbx_extract_match_batch_device(orbx_ctx* ctx, int n_frames, const uint8_t* d_imgs, int width, int height, int stride,
-                                    size_t frame_stride_bytes, orbx_keypoint* d_kps, uint8_t* d_desc32, int capacity,
-                                    int32_t* d_n_out, int n_pairs, const int32_t* h_first, const int32_t* h_second,
-                                    const orbx_bounds* bounds, int window_size, float nnratio, int check_orientation,
-                                    int32_t* d_matches12, int32_t* d_nmatches, int32_t* d_stats) {
+}  // extern "C"
+namespace {
+int extractMatch(orbx_ctx* ctx, int n_frames, const uint8_t* d_imgs, int width, int height, int stride,
+                 size_t frame_stride_bytes, orbx_keypoint* d_kps, uint8_t* d_desc32, int capacity, int32_t* d_n_out, int n_pairs,
+                 const int32_t* h_first, const int32_t* h_second, const orbx_bounds* bounds, int window_size, float nnratio,
+                 int check_orientation, int32_t* d_matches12, int32_t* d_nmatches, int32_t* d_stats, bool async) {
   if (!ctx) return ORBX_E_BADARG;
   if (!d_imgs || width <= 0 || height <= 0) return ORBX_E_EMPTY;
   if (!d_kps || !d_desc32 || !d_n_out || stride < width || n_pairs < 0) return ORBX_E_BADARG;
@@ -960,7 +1036,39 @@ int orbx_extract_match_batch_device(orbx_ctx* ctx, int n_frames, const uint8_t* 
   if (n_pairs > 0) { m.b = *bounds; m.window = window_size; m.nnratio = nnratio; m.checkOri = check_orientation; }
   m.dMatches12 = d_matches12; m.dNmatches = d_nmatches; m.dStats = d_stats;
   return extractCore(ctx, n_frames, d_imgs, width, height, stride, (long long)frame_stride_bytes, d_kps, d_desc32, capacity,
-                     d_n_out, &m);
+                     d_n_out, &m, async);
+}
+}  // namespace
+extern "C" {
+
+int orbx_extract_match_batch_device(orbx_ctx* ctx, int n_frames, const uint8_t* d_imgs, int width, int height, int stride,
+                                    size_t frame_stride_bytes, orbx_keypoint* d_kps, uint8_t* d_desc32, int capacity,
+                                    int32_t* d_n_out, int n_pairs, const int32_t* h_first, const int32_t* h_second,
+                                    const orbx_bounds* bounds, int window_size, float nnratio, int check_orientation,
+                                    int32_t* d_matches12, int32_t* d_nmatches, int32_t* d_stats) {
+  return extractMatch(ctx, n_frames, d_imgs, width, height, stride, frame_stride_bytes, d_kps, d_desc32, capacity, d_n_out, n_pairs,
+                      h_first, h_second, bounds, window_size, nnratio, check_orientation, d_matches12, d_nmatches, d_stats, false);
+}
+
+int orbx_extract_match_batch_device_async(orbx_ctx* ctx, int n_frames, const uint8_t* d_imgs, int width, int height, int stride,
+                                          size_t frame_stride_bytes, orbx_keypoint* d_kps, uint8_t* d_desc32, int capacity,
+                                          int32_t* d_n_out, int n_pairs, const int32_t* h_first, const int32_t* h_second,
+                                          const orbx_bounds* bounds, int window_size, float nnratio, int check_orientation,
+                                          int32_t* d_matches12, int32_t* d_nmatches, int32_t* d_stats) {
+  return extractMatch(ctx, n_frames, d_imgs, width, height, stride, frame_stride_bytes, d_kps, d_desc32, capacity, d_n_out, n_pairs,
+                      h_first, h_second, bounds, window_size, nnratio, check_orientation, d_matches12, d_nmatches, d_stats, true);
+}
+
+int orbx_wait_one(orbx_ctx* ctx) {
+  if (!ctx) return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  return waitOldest(ctx);
+}
+
+int orbx_wait(orbx_ctx* ctx) {
+  if (!ctx) return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  return waitAll(ctx);
 }
 
 int orbx_match_init(orbx_ctx* ctx, const orbx_keypoint* k1, const uint8_t* d1, int n1, const orbx_keypoint* k2, const uint8_t* d2,
@@ -1172,7 +1280,12 @@ int orbx_to_gray(orbx_ctx* ctx, const uint8_t* img, int width, int height, int s
 // ---- measurement hooks ------------------------------------------------------------------------
 int orbx_profile_enable(orbx_ctx* ctx, int on) {
   if (!ctx) return ORBX_E_BADARG;
-  ctx->prof = on != 0;
+  ctx->profMask = on ? (1u << ORBX_STAGE_COUNT) - 1u : 0u;
+  return ORBX_OK;
+}
+int orbx_profile_stages(orbx_ctx* ctx, unsigned stage_mask) {
+  if (!ctx) return ORBX_E_BADARG;
+  ctx->profMask = stage_mask & ((1u << ORBX_STAGE_COUNT) - 1u);
   return ORBX_OK;
 }
 int orbx_profile_reset(orbx_ctx* ctx) {

@@ -297,10 +297,18 @@ __global__ __launch_bounds__(FAST_T) void k_fast(const uint8_t* __restrict__ img
   // cell rectangle, cpp:1082-1103
   const int iniY = ORBX_MIN_BORDER + ci * L.hCell;
   const int iniX = ORBX_MIN_BORDER + cj * L.wCell;
-  if (iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6) return;
+  // every cell writes its counter (also 0), so the counters need no clearing between batches
+  int* const myCount = cellCount + (long long)f * g.nCellsTotal + cid;
+  if (iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6) {
+    if (t == 0) *myCount = 0;
+    return;
+  }
   const int maxY = min(iniY + L.hCell + 6, L.maxBY), maxX = min(iniX + L.wCell + 6, L.maxBX);
   const int cw = maxX - iniX, ch = maxY - iniY;
-  if (cw < 7 || ch < 7) return;  // cv::FAST finds nothing in an image this small
+  if (cw < 7 || ch < 7) {  // cv::FAST finds nothing in an image this small
+    if (t == 0) *myCount = 0;
+    return;
+  }
   const int iw = cw - 6, ih = ch - 6;
 
   const uint8_t* base;
@@ -439,8 +447,8 @@ __global__ __launch_bounds__(FAST_T) void k_fast(const uint8_t* __restrict__ img
   // counter: plain stores, no atomic and no barrier (a returning global atomic per cell kept the workgroup's slot
   // occupied for a memory round trip and serialised the cells of a level).  The selection stage gathers the segments.
   const int no = min(nOut, fl.outCap);  // nOut <= outCap = segCap: NMS survivors are never 8-neighbours
+  if (t == 0) *myCount = no;
   if (no > 0) {
-    if (t == 0) cellCount[(long long)f * g.nCellsTotal + cid] = no;
     uint32_t* dstc = cand + L.candOff + (long long)f * L.candCap + (long long)local * L.segCap;
     for (int e = t; e < no; e += FAST_T) dstc[e] = outl[e];
   }

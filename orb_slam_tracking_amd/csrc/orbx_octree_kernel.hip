@@ -159,10 +159,14 @@ size_t octScratchBytes(int nMax, int qMax) {
   return (b + 255) / 256 * 256;
 }
 
-// compacts the per-level staging lists of every frame into level-major order and writes the per-frame totals
+// compacts the per-level staging lists of every frame into level-major order and writes the per-frame totals: to the
+// context's array (k_describe_patch reads it), to the caller's array if there is one, and to the host (mapped pinned
+// memory), so that no copy command follows on the stream.  A unit the selection could not handle raises the host's error
+// flag the same way.
 __global__ __launch_bounds__(256) void k_sel_compact(const SelKp* __restrict__ selStage, const int* __restrict__ nselLevel,
                                                      const OctLaunch P, SelKp* __restrict__ sel, int* __restrict__ nsel,
-                                                     int selCap, int* __restrict__ err, int* __restrict__ maxN,
+                                                     int* __restrict__ nselUser, int* __restrict__ hostNsel, int selCap,
+                                                     int* __restrict__ hostErr, int* __restrict__ maxN,
                                                      int* __restrict__ hostMaxN) {
   const int f = blockIdx.x + P.frame0;
   // per-level candidate maxima of this launch go to pinned host memory and are reset for the next one
@@ -173,14 +177,18 @@ __global__ __launch_bounds__(256) void k_sel_compact(const SelKp* __restrict__ s
   __shared__ int off[ORBX_MAX_LEVELS + 1];
   if (threadIdx.x == 0) {
     int acc = 0;
+    bool bad = false;
     for (int l = 0; l < P.nlevels; l++) {
       off[l] = acc;
       const int c = nselLevel[f * P.nlevels + l];
-      if (c < 0) *err = 1;
+      bad |= c < 0;
       acc += max(c, 0);
     }
     off[P.nlevels] = acc;
     nsel[f] = acc;
+    if (nselUser) nselUser[f] = acc;
+    if (hostNsel) hostNsel[f] = acc;
+    if (bad) *hostErr = 1;
   }
   __syncthreads();
   for (int l = 0; l < P.nlevels; l++) {
@@ -219,8 +227,10 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
 }
 
 hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage, const int* nselLevel, const OctLaunch& P,
-                              SelKp* sel, int* nsel, int selCap, int* err, int* maxN, int* hostMaxN) {
-  hipLaunchKernelGGL(k_sel_compact, dim3(nFrames), dim3(256), 0, st, selStage, nselLevel, P, sel, nsel, selCap, err, maxN, hostMaxN);
+                              SelKp* sel, int* nsel, int* nselUser, int* hostNsel, int selCap, int* hostErr, int* maxN,
+                              int* hostMaxN) {
+  hipLaunchKernelGGL(k_sel_compact, dim3(nFrames), dim3(256), 0, st, selStage, nselLevel, P, sel, nsel, nselUser, hostNsel, selCap,
+                     hostErr, maxN, hostMaxN);
   return hipGetLastError();
 }
 

@@ -449,6 +449,61 @@ def test_fused_two_stream_batch(orbx, oracle):
     e.close()
 
 
+def test_async_batches_equal_sync(orbx):
+    """orbx_extract_match_batch_device_async: three batches issued back to back (two in flight, the third call waits for the
+    oldest) into alternating output sets give what the synchronous call gives; stage profiling survives the overlap."""
+    import torch
+    from orb_slam_tracking_amd import synth
+    B, cap, w, h = 32, 1000, 640, 480
+    e = orbx.ORBextractor(*CANON, max_width=w, max_height=h, max_batch=B)
+    first = np.arange(0, B, 2, dtype=np.int32)
+    imgs = [torch.from_numpy(synth.synth_frames(B, w, h, seed0=300 + 50 * i)).cuda() for i in range(3)]
+
+    def outs():
+        return dict(k=torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"), d=torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda"),
+                    n=torch.zeros(B, dtype=torch.int32, device="cuda"), m=torch.full(((B // 2) * cap,), -5, dtype=torch.int32, device="cuda"),
+                    nm=torch.zeros(B // 2, dtype=torch.int32, device="cuda"))
+    ref = []
+    for im in imgs:
+        o = outs()
+        e.extract_match_batch_device(im, B, w, h, w, w * h, o["k"], o["d"], o["n"], first, first + 1, (0, w, 0, h), o["m"], o["nm"],
+                                     None, 100, 0.9, True, cap)
+        ref.append({k: v.cpu().numpy().copy() for k, v in o.items()})
+    e.profile_enable(True)
+    e.profile_reset()
+    sets = [outs(), outs(), outs()]
+    for i, im in enumerate(imgs):
+        o = sets[i]
+        e.extract_match_batch_device_async(im, B, w, h, w, w * h, o["k"], o["d"], o["n"], first, first + 1, (0, w, 0, h), o["m"],
+                                           o["nm"], None, 100, 0.9, True, cap)
+    e.wait_one()
+    e.wait()
+    e.wait()  # nothing in flight: a no-op
+    prof = e.profile_get()
+    e.profile_enable(False)
+    assert all(prof[s][1] > 0 and prof[s][0] > 0 for s in ("pyramid", "fast", "select", "describe", "match"))
+    for i in range(3):
+        got = {k: v.cpu().numpy() for k, v in sets[i].items()}
+        n = got["n"]
+        assert np.array_equal(n, ref[i]["n"]) and np.array_equal(got["nm"], ref[i]["nm"])
+        kk, rk = got["k"].reshape(B, cap * 28), ref[i]["k"].reshape(B, cap * 28)
+        dd, rd = got["d"].reshape(B, cap * 32), ref[i]["d"].reshape(B, cap * 32)
+        mm, rm = got["m"].reshape(B // 2, cap), ref[i]["m"].reshape(B // 2, cap)
+        for f in range(B):
+            assert np.array_equal(kk[f, :n[f] * 28], rk[f, :n[f] * 28]) and np.array_equal(dd[f, :n[f] * 32], rd[f, :n[f] * 32])
+        for p_ in range(B // 2):
+            assert np.array_equal(mm[p_, :n[2 * p_]], rm[p_, :n[2 * p_]])
+    # a synchronous call right behind asynchronous ones
+    o = outs()
+    e.extract_match_batch_device_async(imgs[0], B, w, h, w, w * h, sets[0]["k"], sets[0]["d"], sets[0]["n"], first, first + 1,
+                                       (0, w, 0, h), sets[0]["m"], sets[0]["nm"], None, 100, 0.9, True, cap)
+    e.extract_match_batch_device(imgs[1], B, w, h, w, w * h, o["k"], o["d"], o["n"], first, first + 1, (0, w, 0, h), o["m"], o["nm"],
+                                 None, 100, 0.9, True, cap)
+    assert np.array_equal(o["n"].cpu().numpy(), ref[1]["n"]) and np.array_equal(o["nm"].cpu().numpy(), ref[1]["nm"])
+    assert np.array_equal(sets[0]["nm"].cpu().numpy(), ref[0]["nm"])
+    e.close()
+
+
 def test_cpp_shim_equals_oracle(orbx, oracle, tmp_path):
     """The reference's demo call sequence through the C++ drop-in classes (include/orbx_shim.hpp)."""
     import subprocess
