@@ -136,7 +136,9 @@ struct orbx_ctx {
   // [parity of the batch][stream slot][stage][begin/end]: two batches may be in flight (orbx_*_async)
   hipEvent_t ev[2][2][ORBX_STAGE_COUNT][2]{};
   bool used[2][2][ORBX_STAGE_COUNT]{};
-  hipEvent_t evDone[2]{};  // end of the batch with that parity, recorded on st
+  hipEvent_t evDone[2]{};   // end of the batch with that parity on st
+  hipEvent_t evDone2[2]{};  // ... and on st2 (only when the batch used it: done2Used)
+  bool done2Used[2]{};
   unsigned seqIssue = 0;   // batches issued so far
   int pending = 0;         // issued and not yet waited for (0 .. 2)
   int parity = 0;          // of the batch being issued
@@ -540,12 +542,17 @@ int issueMatch(orbx_ctx* ctx, int si, hipStream_t st, int pair0, int n, const Ma
 
 // Pair list -> dPairs (first[], then second[]).  Trackers match the same pairs batch after batch, so an unchanged list
 // is not copied again (two copy commands less at the head of the stream).
-int uploadPairs(orbx_ctx* ctx, int nPairs, const int32_t* hFirst, const int32_t* hSecond, hipStream_t st) {
+int waitAll(orbx_ctx* ctx);
+int uploadPairs(orbx_ctx* ctx, int nPairs, const int32_t* hFirst, const int32_t* hSecond, hipStream_t st, bool* copied) {
+  *copied = false;
   std::vector<int32_t>& lp = ctx->lastPairs;
   if ((int)lp.size() == 2 * nPairs && std::memcmp(lp.data(), hFirst, sizeof(int32_t) * nPairs) == 0 &&
       std::memcmp(lp.data() + nPairs, hSecond, sizeof(int32_t) * nPairs) == 0)
     return ORBX_OK;
+  int r = waitAll(ctx);  // batches in flight (either stream) may still read the list dPairs holds
+  if (r != ORBX_OK) return r;
   lp.clear();  // (stays empty if a copy fails)
+  *copied = true;
   HIPCHK(hipMemcpyAsync(ctx->dPairs, hFirst, sizeof(int) * nPairs, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(ctx->dPairs + nPairs, hSecond, sizeof(int) * nPairs, hipMemcpyHostToDevice, st));
   lp.assign(hFirst, hFirst + nPairs);
@@ -559,6 +566,7 @@ int waitOldest(orbx_ctx* ctx) {
   if (ctx->pending <= 0) return ORBX_OK;
   const int parity = (int)((ctx->seqIssue - (unsigned)ctx->pending) & 1u);
   HIPCHK(hipEventSynchronize(ctx->evDone[parity]));
+  if (ctx->done2Used[parity]) HIPCHK(hipEventSynchronize(ctx->evDone2[parity]));
   ctx->pending--;
   collectProfile(ctx, parity);
   {  // largest candidate count of a unit in the batches seen so far: picks the selection kernel's instance for the next one
@@ -600,6 +608,12 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
     r = waitOldest(ctx);
     if (r != ORBX_OK) return r;
   }
+  if (ctx->pending > 0 && !(w == ctx->curW && h == ctx->curH && stride0 == ctx->curStride0 && B == ctx->lastB)) {
+    // a new geometry rewrites tables the batches in flight read; another batch size moves the border between the halves
+    // of the internal buffers the two streams own
+    r = waitAll(ctx);
+    if (r != ORBX_OK) return r;
+  }
   ctx->parity = (int)(ctx->seqIssue & 1u);
   r = ensureGeometry(ctx, w, h, stride0);
   if (r != ORBX_OK) return r;
@@ -610,14 +624,16 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
   a.dKps = dKps; a.dDesc = dDesc; a.capacity = capacity;
   int* dN = dNout ? dNout : ctx->dNsel;
   const int nPairs = match ? match->nPairs : 0;
+  bool pairsCopied = false;
   if (nPairs > 0) {
     if (capacity >= (1 << 20)) return ORBX_E_BADARG;
     for (int p = 0; p < nPairs; p++)
       if (match->hFirst[p] < 0 || match->hFirst[p] >= B || match->hSecond[p] < 0 || match->hSecond[p] >= B) return ORBX_E_BADARG;
     r = ensureMatchScratch(ctx, nPairs, capacity);
     if (r != ORBX_OK) return r;
-    r = uploadPairs(ctx, nPairs, match->hFirst, match->hSecond, st);
+    r = uploadPairs(ctx, nPairs, match->hFirst, match->hSecond, st, &pairsCopied);
     if (r != ORBX_OK) return r;
+    ctx->parity = (int)(ctx->seqIssue & 1u);  // (uploadPairs may have waited)
   }
   a.dNuser = dNout;
 
@@ -632,9 +648,15 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
     p1 = p0;
     while (p1 < nPairs && match->hFirst[p1] >= n0 && match->hSecond[p1] >= n0) p1++;
   }
+  ctx->done2Used[ctx->parity] = split;
   if (split) {
-    HIPCHK(hipEventRecord(ctx->evFork, st));
-    HIPCHK(hipStreamWaitEvent(ctx->st2, ctx->evFork, 0));
+    // The two streams are independent pipelines (disjoint halves of every internal buffer): the second waits for the
+    // first only when the first carries something it needs (a new pair list, or work of another call of the context
+    // queued on st), the first for the second only when pairs straddle the halves.
+    if (pairsCopied || ctx->pending == 0 || !ctx->ownStream) {  // (a caller's stream may carry the producer of the frames)
+      HIPCHK(hipEventRecord(ctx->evFork, st));
+      HIPCHK(hipStreamWaitEvent(ctx->st2, ctx->evFork, 0));
+    }
     // the two chains are issued alternately: the device starts on the second while the host still issues the first
     r = issueExtract(ctx, 0, st, 0, n0, a, 0);
     if (r != ORBX_OK) return r;
@@ -646,9 +668,13 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
     r = issueExtract(ctx, 1, ctx->st2, n0, B - n0, a, 1);
     if (r != ORBX_OK) return r;
     if (nPairs > 0) { r = issueMatch(ctx, 1, ctx->st2, p0, p1 - p0, *match, dKps, dDesc, dN, capacity); if (r != ORBX_OK) return r; }
-    HIPCHK(hipEventRecord(ctx->evJoin, ctx->st2));
-    HIPCHK(hipStreamWaitEvent(st, ctx->evJoin, 0));
-    if (nPairs > p1) { r = issueMatch(ctx, 0, st, p1, nPairs - p1, *match, dKps, dDesc, dN, capacity); if (r != ORBX_OK) return r; }
+    if (nPairs > p1) {
+      HIPCHK(hipEventRecord(ctx->evJoin, ctx->st2));
+      HIPCHK(hipStreamWaitEvent(st, ctx->evJoin, 0));
+      r = issueMatch(ctx, 0, st, p1, nPairs - p1, *match, dKps, dDesc, dN, capacity);
+      if (r != ORBX_OK) return r;
+    }
+    HIPCHK(hipEventRecord(ctx->evDone2[ctx->parity], ctx->st2));
   } else {
     r = issueExtract(ctx, 0, st, 0, B, a, 0);
     if (r != ORBX_OK) return r;
@@ -763,7 +789,9 @@ int orbx_create(const orbx_params* params, int device_id, int max_width, int max
         for (int par = 0; par < 2; par++)
           if (hipEventCreate(&ctx->ev[par][si][s2][k]) != hipSuccess) return fail(ORBX_E_HIP);
   for (int par = 0; par < 2; par++)
-    if (hipEventCreateWithFlags(&ctx->evDone[par], hipEventDisableTiming) != hipSuccess) return fail(ORBX_E_HIP);
+    if (hipEventCreateWithFlags(&ctx->evDone[par], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->evDone2[par], hipEventDisableTiming) != hipSuccess)
+      return fail(ORBX_E_HIP);
   if (hipStreamCreateWithFlags(&ctx->st2, hipStreamNonBlocking) != hipSuccess) return fail(ORBX_E_HIP);
   if (hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming) != hipSuccess) return fail(ORBX_E_HIP);
   if (hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming) != hipSuccess) return fail(ORBX_E_HIP);
@@ -789,8 +817,10 @@ void orbx_destroy(orbx_ctx* ctx) {
       for (int k = 0; k < 2; k++)
         for (int par = 0; par < 2; par++)
           if (ctx->ev[par][si][s][k]) (void)hipEventDestroy(ctx->ev[par][si][s][k]);
-  for (int par = 0; par < 2; par++)
+  for (int par = 0; par < 2; par++) {
     if (ctx->evDone[par]) (void)hipEventDestroy(ctx->evDone[par]);
+    if (ctx->evDone2[par]) (void)hipEventDestroy(ctx->evDone2[par]);
+  }
   if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
   if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
   if (ctx->st2) (void)hipStreamDestroy(ctx->st2);
@@ -943,6 +973,10 @@ int orbx_download_pyramid(orbx_ctx* ctx, int frame, int level, int border, uint8
 }  // extern "C"
 namespace {
 int ensureMatchScratch(orbx_ctx* ctx, int nPairs, int capacity) {
+  if (ctx->pending > 0 && ((size_t)nPairs * (size_t)matchScratchStride(capacity) > ctx->matchScratchInts || (size_t)nPairs > ctx->pairsCap)) {
+    const int w = waitAll(ctx);  // the buffers about to be replaced are in use
+    if (w != ORBX_OK) return w;
+  }
   // per pair: see matchScratchStride (orbx_device.h)
   const size_t need = (size_t)nPairs * (size_t)matchScratchStride(capacity);
   if (need > ctx->matchScratchInts) {
@@ -1006,7 +1040,8 @@ int orbx_match_init_batch_device(orbx_ctx* ctx, int n_pairs, const int32_t* h_fi
   ctx->parity = (int)(ctx->seqIssue & 1u);
   r = ensureMatchScratch(ctx, n_pairs, capacity);
   if (r != ORBX_OK) return r;
-  r = uploadPairs(ctx, n_pairs, h_first, h_second, ctx->st);
+  bool copied = false;
+  r = uploadPairs(ctx, n_pairs, h_first, h_second, ctx->st, &copied);
   if (r != ORBX_OK) return r;
   MatchArgs m;
   m.nPairs = n_pairs; m.b = *bounds; m.window = window_size; m.nnratio = nnratio; m.checkOri = check_orientation;

@@ -501,6 +501,21 @@ def test_async_batches_equal_sync(orbx):
                                  None, 100, 0.9, True, cap)
     assert np.array_equal(o["n"].cpu().numpy(), ref[1]["n"]) and np.array_equal(o["nm"].cpu().numpy(), ref[1]["nm"])
     assert np.array_equal(sets[0]["nm"].cpu().numpy(), ref[0]["nm"])
+    # another batch size and another pair list behind a batch in flight (both make the context drain first)
+    B2 = 20
+    f2 = np.arange(1, B2, 2, dtype=np.int32)  # pairs (2k + 1, 2k): B matched against A
+    o1, o2 = outs(), outs()
+    e.extract_match_batch_device(imgs[2], B2, w, h, w, w * h, o1["k"], o1["d"], o1["n"], f2, f2 - 1, (0, w, 0, h), o1["m"], o1["nm"],
+                                 None, 100, 0.9, True, cap)
+    e.extract_match_batch_device_async(imgs[0], B, w, h, w, w * h, sets[1]["k"], sets[1]["d"], sets[1]["n"], first, first + 1,
+                                       (0, w, 0, h), sets[1]["m"], sets[1]["nm"], None, 100, 0.9, True, cap)
+    e.extract_match_batch_device_async(imgs[2], B2, w, h, w, w * h, o2["k"], o2["d"], o2["n"], f2, f2 - 1, (0, w, 0, h), o2["m"],
+                                       o2["nm"], None, 100, 0.9, True, cap)
+    e.wait()
+    assert np.array_equal(sets[1]["nm"].cpu().numpy(), ref[0]["nm"]) and np.array_equal(sets[1]["n"].cpu().numpy(), ref[0]["n"])
+    assert np.array_equal(o2["n"].cpu().numpy()[:B2], o1["n"].cpu().numpy()[:B2])
+    assert np.array_equal(o2["nm"].cpu().numpy()[:B2 // 2], o1["nm"].cpu().numpy()[:B2 // 2])
+    assert np.array_equal(o2["n"].cpu().numpy()[:B2], ref[2]["n"][:B2]) and o1["nm"].cpu().numpy()[:B2 // 2].sum() > 100
     e.close()
 
 
