@@ -19,6 +19,9 @@ first = np.arange(0, B, 2, dtype=np.int32)
 second = first + 1
 ref = None
 bad = 0
+scr = dict(k=torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"), d=torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda"),
+           n=torch.zeros(B, dtype=torch.int32, device="cuda"), m=torch.zeros((B // 2) * cap, dtype=torch.int32, device="cuda"),
+           nm=torch.zeros(B // 2, dtype=torch.int32, device="cuda"))
 for it in range(steps):
     d_k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
     d_d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
@@ -26,8 +29,15 @@ for it in range(steps):
     d_m = torch.zeros((B // 2) * cap, dtype=torch.int32, device="cuda")
     d_nm = torch.zeros(B // 2, dtype=torch.int32, device="cuda")
     d_st = torch.zeros(B // 2 * 3, dtype=torch.int32, device="cuda")
-    ext.extract_match_batch_device(d_img, B, W, H, W, W * H, d_k, d_d, d_n, first, second, (0, W, 0, H), d_m, d_nm, d_st, 100, 0.9,
-                                   True, cap)
+    if it % 3 == 2:  # every third pass through the stream-ordered call, behind a second batch in flight
+        ext.extract_match_batch_device_async(d_img, B, W, H, W, W * H, scr["k"], scr["d"], scr["n"], first, second, (0, W, 0, H),
+                                             scr["m"], scr["nm"], None, 100, 0.9, True, cap)
+        ext.extract_match_batch_device_async(d_img, B, W, H, W, W * H, d_k, d_d, d_n, first, second, (0, W, 0, H), d_m, d_nm, d_st,
+                                             100, 0.9, True, cap)
+        ext.wait()
+    else:
+        ext.extract_match_batch_device(d_img, B, W, H, W, W * H, d_k, d_d, d_n, first, second, (0, W, 0, H), d_m, d_nm, d_st, 100,
+                                       0.9, True, cap)
     n1 = d_n.cpu().numpy()
     cur = [d_k, d_d, d_n, d_nm, d_st]
     # matches12 rows are only defined up to the frame's keypoint count
