@@ -16,7 +16,7 @@ W, H, cap = 640, 480, 1000
 BYTES_PER_FRAME = 5742474  # DESIGN.md section 5 (SURVEY 8(d) stage-streaming model)
 frames = synth.synth_frames(256, W, H, seed0=1000)
 d_all = torch.from_numpy(frames).cuda()
-for B in (1, 2, 8, 32, 128, 256):
+for B in [int(x) for x in os.environ.get("SWEEP_B", "1,2,8,32,128,256").split(",")]:
     ext = orbx.ORBextractor(1000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B)
     first = np.arange(0, B - 1, 2, dtype=np.int32)
     npairs = len(first)
