@@ -347,7 +347,7 @@ size_t buildOctLaunch(const orbx_ctx* c, const Geom& g, OctLaunch* out) {
     P.selOff[l] = selOff;
     selOff += L.quota;
     P.scrNMax[l] = std::min(L.candMax, ORBX_OCT_MAX_CAND);
-    P.scrStride[l] = (int64_t)octScratchBytes(P.scrNMax[l], L.quota);
+    P.scrStride[l] = (int64_t)octScratchBytes(P.scrNMax[l], std::max(L.quota, O.nIni));  // = octreeGlobalUnit's qMax
     P.scrOff[l] = scr;
     scr += P.scrStride[l] * c->maxB;
   }
@@ -1413,7 +1413,7 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
   P.nCellsTotal = 1;
   P.candCap[0] = std::max(n, 1);
   P.scrNMax[0] = std::max(n, 1);
-  P.scrStride[0] = (int64_t)octScratchBytes(P.scrNMax[0], n_features);
+  P.scrStride[0] = (int64_t)octScratchBytes(P.scrNMax[0], std::max(n_features, O.nIni));  // = octreeGlobalUnit's qMax
   std::vector<uint32_t> packed((size_t)alignUp(std::max(n, 1), 4));
   for (int i = 0; i < n; i++) {
     const int x = (int)xyr[3 * i], y = (int)xyr[3 * i + 1], r = (int)xyr[3 * i + 2];

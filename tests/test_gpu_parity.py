@@ -393,6 +393,33 @@ def test_device_octree_random(orbx, ext640, oracle):
     assert done > 100
 
 
+def test_device_octree_small_quotas(orbx, ext640, oracle):
+    """Quotas of a few keypoints against many candidates (nfeatures = 30 leaves 11, 7, 5, 3, 2, 2 per level): the last,
+    partial pass then creates more multi-key children than the quota (up to N + 4), and with several roots (nIni > 1) the
+    first pass alone exceeds 4 N nodes.  Found by tools/fuzz_parity.py (714 x 634, (30, 1.5, 6, 4, 4))."""
+    rng = np.random.default_rng(23)
+    for it in range(90):
+        H = int(rng.integers(60, 500))
+        W = int(H * float(rng.choice([1.0, 1.2, 1.6, 2.4, 3.3, 4.4])))
+        n = int(rng.integers(20, min(W * H // 4, 700 if it % 3 else 9000)))
+        xyr = _rowmajor_cands(rng, W, H, n)
+        for N in (1, 2, 3, 5, 11, int(rng.integers(4, 40))):
+            exp = oracle.distribute(xyr, 16, 16 + W, 16, 16 + H, N)[:N]
+            for variant in (0, 1, 2):
+                got = ext640.debug_distribute_device(xyr, 16, 16 + W, 16, 16 + H, N, variant)
+                assert got.shape == exp.shape and np.array_equal(got, exp), (it, variant, W, H, n, N)
+    from orb_slam_tracking_amd import synth
+    params = (30, 1.5, 6, 4, 4)
+    fr = synth.synth_frames(2, 714, 634, 5133)
+    e = orbx.ORBextractor(*params, max_width=714, max_height=634, max_batch=2)
+    oe = oracle.Extractor(*params)
+    for f, (r, k, d) in zip(fr, e.extract_batch(fr)):
+        ro, ko, do = oe(f)
+        assert r == ro
+        _same(k, d, ko, do)
+    e.close()
+
+
 @pytest.mark.parametrize("shape", [(608, 448, 217), (720, 448, 434), (1888, 1048, 869), (3808, 2128, 1737), (147, 102, 60)])
 def test_device_octree_level_geometries(orbx, ext640, oracle, shape):
     W, H, N = shape
