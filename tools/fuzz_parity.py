@@ -2,7 +2,9 @@
 """Randomised parity campaign (longer than the test suite allows): random frame sizes, extractor parameters, image
 content (synthetic scenes, uniform noise, smooth gradients with sparse corners), batch sizes and matcher settings; the
 device path (host API, batched device API, fused extract + match, stream-ordered call) against the CPU oracle, bit for
-bit.  usage: fuzz_parity.py [trials] [seed].  Prints one line per trial and a summary; exits non-zero on a mismatch."""
+bit.  usage: fuzz_parity.py [trials] [seed] [mixed|big|batched]  (big: up to 4000 x 2200 and 10000 features; batched:
+33 .. 80 frames of 4-aligned width, i.e. the banded pyramid and the two stream pipelines).  Prints one line per trial and a
+summary; exits non-zero on a mismatch."""
 import os
 import sys
 import time
@@ -18,6 +20,7 @@ import oracle_lib as O  # noqa: E402
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+mode = sys.argv[3] if len(sys.argv) > 3 else "mixed"
 KP = orbx.KEYPOINT_DTYPE
 
 
@@ -63,7 +66,20 @@ for t in range(trials):
     mn = int(rng.integers(0, ini + 1))
     B = int(rng.choice([1, 2, 3, 6, 17, 34]))
     kind = str(rng.choice(["synth", "synth", "noise", "pairs_noise", "sparse"]))
-    if kind in ("noise", "pairs_noise") and w * h > 500000:
+    if mode == "big":
+        w, h = int(rng.integers(1300, 4000)), int(rng.integers(700, 2200))
+        nf = int(rng.choice([2000, 4000, 8000, 10000]))
+        B = int(rng.choice([1, 2, 4]))
+        kind = str(rng.choice(["synth", "synth", "synth", "pairs_noise"]))
+    elif mode == "batched":
+        w, h = int(rng.integers(40, 260)) * 4, int(rng.integers(100, 600))
+        B = int(rng.integers(33, 81))
+        nf = int(rng.choice([200, 500, 1000, 2000]))
+        while nlev > 1 and min(w, h) / sf ** (nlev - 1) < 75:
+            nlev -= 1
+    if kind in ("noise", "pairs_noise") and w * h > 500000 and mode != "big":
+        w, h = w // 2, h // 2
+    if kind == "pairs_noise" and mode == "big":
         w, h = w // 2, h // 2
     params = (nf, sf, nlev, ini, mn)
     tag = "trial %d: %dx%d B=%d %s params=%r" % (t, w, h, B, kind, params)
@@ -98,11 +114,11 @@ for t in range(trials):
         first = np.arange(0, B - 1, 2, dtype=np.int32)
         npairs = len(first)
         sets = []
-        for mode in range(2):
+        for use_async in range(2):
             o = dict(k=torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"), d=torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda"),
                      n=torch.zeros(B, dtype=torch.int32, device="cuda"), m=torch.zeros(npairs * cap, dtype=torch.int32, device="cuda"),
                      nm=torch.zeros(npairs, dtype=torch.int32, device="cuda"), st=torch.zeros(npairs * 3, dtype=torch.int32, device="cuda"))
-            f = e.extract_match_batch_device_async if mode else e.extract_match_batch_device
+            f = e.extract_match_batch_device_async if use_async else e.extract_match_batch_device
             f(d_img, B, w, h, w, w * h, o["k"], o["d"], o["n"], first, first + 1, (0, w, 0, h), o["m"], o["nm"], o["st"], win, ratio, ori, cap)
             sets.append(o)
         e.wait()
