@@ -121,6 +121,7 @@ def main():
     snaps = [torch.zeros(B, dtype=torch.int32, device=cdev) for _ in range(2)]
     pending = [None]
     nstep = [0]
+    ngathered = [0]  # batches whose counts have been gathered
 
     def finish_gather():
         if pending[0] is not None:
@@ -141,14 +142,15 @@ def main():
         ext.extract_match_batch_device_async(d_img, B, W, H, W, W * H, o["k"], o["d"], o["n"], first, second, (0, W, 0, H),
                                              o["m"], o["nm"], None, 100, 0.9, True, cap)
         nstep[0] = k + 1
-        if world > 1 and k > 0:
-            ext.wait_one()  # batch k - 1
+        if world > 1 and ngathered[0] < k:  # batch k - 1 is the oldest in flight: wait for it, gather its counts
+            ext.wait_one()
             gather_counts(k - 1)
+            ngathered[0] = k
 
     def barrier():
         ext.wait()  # every batch issued so far is complete
-        if world > 1 and nstep[0] > 0 and ngathered[0] < nstep[0]:
-            gather_counts(nstep[0] - 1)  # the last batch's counts
+        if world > 1 and ngathered[0] < nstep[0]:
+            gather_counts(nstep[0] - 1)  # the last batch's counts (the earlier ones were gathered in step())
             ngathered[0] = nstep[0]
         finish_gather()
         torch.cuda.synchronize()
@@ -156,7 +158,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ngathered = [0]
     # warmup: every stage bracketed by events -> per-stage device times and the dominant kernel
     ext.profile_enable(True)
     stage_steps = args.warmup
