@@ -33,7 +33,7 @@ hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const 
                                  orbx_keypoint* kps, uint8_t* desc, int capacity);
 hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int* dSecond, const orbx_keypoint* kps,
                         const uint8_t* desc, const int* nkp, int capacity, orbx_bounds b, int window, float nnratio, int checkOri,
-                        int* matches12, int* nmatches, int* stats, int* scratch, int pair0);
+                        int* matches12, int* nmatches, int* stats, int* scratch, int pair0, int wideMode, int* hostWide);
 hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, const int* cellCount, const OctLaunch& P,
                          SelKp* selStage, int* nselLevel, uint8_t* scratch, int maxQuota, int* maxN, int nHint);
 hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage, const int* nselLevel, const OctLaunch& P,
@@ -102,6 +102,25 @@ struct orbx_ctx {
   int* hFlags = nullptr;  // pinned, written by k_sel_compact through hFlagsDev: [1] selection error ([0] unused)
   int* hFlagsDev = nullptr;
   int* hNselDev = nullptr;  // device view of hNsel: k_sel_compact stores the per-frame counts straight to the host
+  // The wide matcher kernels are issued with a batch only while batches need them (k_match_jacobi raises hWide[parity]
+  // when it hands a pair on); a batch that needed them without having them gets them at its wait (late, prep included).
+  int* hWide = nullptr;     // pinned [2]
+  int* hWideDev = nullptr;
+  bool wideExpected = true;
+  int wideIdle = 0;         // consecutive batches that had the wide kernels and did not need them
+  bool wideLaunched[2]{};
+  struct LateMatch {
+    bool valid = false;
+    int nPairs = 0, capacity = 0, window = 0, checkOri = 0;
+    float nnratio = 0;
+    orbx_bounds b{};
+    const orbx_keypoint* dKps = nullptr;
+    const uint8_t* dDesc = nullptr;
+    const int* dN = nullptr;
+    int32_t* dMatches12 = nullptr;
+    int32_t* dNmatches = nullptr;
+    int32_t* dStats = nullptr;
+  } late[2];
   std::vector<int32_t> lastPairs;  // the pair list dPairs holds (first[], second[]): an unchanged list is not copied again
   uint8_t* dIn = nullptr;
   size_t inBytes = 0;
@@ -534,9 +553,46 @@ int issueMatch(orbx_ctx* ctx, int si, hipStream_t st, int pair0, int n, const Ma
                const uint8_t* dDesc, const int* dN, int capacity) {
   if (n <= 0) return ORBX_OK;
   StageTimer tm(ctx, ORBX_STAGE_MATCH, si, st);
+  const int wide = ctx->wideLaunched[ctx->parity] ? 1 : 0;
   HIPCHK(launch_match(st, n, ctx->dPairs, ctx->dPairs + m.nPairs, dKps, dDesc, dN, capacity, m.b, m.window, m.nnratio, m.checkOri,
-                      m.dMatches12, m.dNmatches, m.dStats, ctx->dMatchScratch, pair0));
-  tm.stop(3);  // k_match_jacobi + k_match_wide_lists + k_match_wide_resolve (the latter two for pending pairs only)
+                      m.dMatches12, m.dNmatches, m.dStats, ctx->dMatchScratch, pair0, wide, ctx->hWideDev + ctx->parity));
+  tm.stop(wide ? 3 : 1);  // k_match_jacobi (+ k_match_wide_lists + k_match_wide_resolve, for pending pairs only)
+  return ORBX_OK;
+}
+
+// Before the matching of the batch being issued (ctx->parity): decide whether its wide kernels go with it, and keep what
+// a late launch would need.
+void armMatch(orbx_ctx* ctx, const MatchArgs& m, const orbx_keypoint* dKps, const uint8_t* dDesc, const int* dN, int capacity) {
+  const int par = ctx->parity;
+  ctx->hWide[par] = 0;  // (the previous batch of this parity has been waited for)
+  ctx->wideLaunched[par] = ctx->wideExpected;
+  orbx_ctx::LateMatch& L = ctx->late[par];
+  L.valid = true;
+  L.nPairs = m.nPairs; L.capacity = capacity; L.window = m.window; L.checkOri = m.checkOri; L.nnratio = m.nnratio; L.b = m.b;
+  L.dKps = dKps; L.dDesc = dDesc; L.dN = dN;
+  L.dMatches12 = m.dMatches12; L.dNmatches = m.dNmatches; L.dStats = m.dStats;
+}
+
+// After the batch of `parity` has completed: if k_match_jacobi handed pairs on and the wide kernels were not issued with
+// the batch, run them now (device drained first: later batches may be using the pairs' scratch), and adapt the expectation.
+int settleMatch(orbx_ctx* ctx, int parity) {
+  orbx_ctx::LateMatch& L = ctx->late[parity];
+  if (!L.valid) return ORBX_OK;
+  L.valid = false;
+  const bool needed = ctx->hWide[parity] != 0;
+  if (needed && !ctx->wideLaunched[parity]) {
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    if (ctx->st2) HIPCHK(hipStreamSynchronize(ctx->st2));
+    HIPCHK(launch_match(ctx->st, L.nPairs, ctx->dPairs, ctx->dPairs + L.nPairs, L.dKps, L.dDesc, L.dN, L.capacity, L.b, L.window,
+                        L.nnratio, L.checkOri, L.dMatches12, L.dNmatches, L.dStats, ctx->dMatchScratch, 0, 2, ctx->hWideDev + parity));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+  }
+  if (needed) {
+    ctx->wideExpected = true;
+    ctx->wideIdle = 0;
+  } else if (ctx->wideLaunched[parity] && ++ctx->wideIdle >= 3) {
+    ctx->wideExpected = false;  // three batches in a row carried the wide kernels for nothing
+  }
   return ORBX_OK;
 }
 
@@ -568,6 +624,10 @@ int waitOldest(orbx_ctx* ctx) {
   HIPCHK(hipEventSynchronize(ctx->evDone[parity]));
   if (ctx->done2Used[parity]) HIPCHK(hipEventSynchronize(ctx->evDone2[parity]));
   ctx->pending--;
+  {
+    const int sm = settleMatch(ctx, parity);
+    if (sm != ORBX_OK) return sm;
+  }
   collectProfile(ctx, parity);
   {  // largest candidate count of a unit in the batches seen so far: picks the selection kernel's instance for the next one
     int m = 0;
@@ -636,6 +696,8 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
     ctx->parity = (int)(ctx->seqIssue & 1u);  // (uploadPairs may have waited)
   }
   a.dNuser = dNout;
+  ctx->late[ctx->parity].valid = false;
+  if (nPairs > 0) armMatch(ctx, *match, dKps, dDesc, dN, capacity);
 
   static const int splitMin = getenv("ORBX_NO_SPLIT") ? (1 << 30) : 16;
   const bool split = ctx->st2 != nullptr && B >= splitMin;
@@ -780,6 +842,9 @@ int orbx_create(const orbx_params* params, int device_id, int max_width, int max
   if (hipHostGetDevicePointer((void**)&ctx->hMaxNDev, ctx->hMaxN, 0) != hipSuccess) return fail(ORBX_E_HIP);
   if (hipHostGetDevicePointer((void**)&ctx->hNselDev, ctx->hNsel, 0) != hipSuccess) return fail(ORBX_E_HIP);
   if (hipHostGetDevicePointer((void**)&ctx->hFlagsDev, ctx->hFlags, 0) != hipSuccess) return fail(ORBX_E_HIP);
+  if (hipHostMalloc((void**)&ctx->hWide, 16, hipHostMallocDefault) != hipSuccess) return fail(ORBX_E_HIP);
+  ctx->hWide[0] = ctx->hWide[1] = 0;
+  if (hipHostGetDevicePointer((void**)&ctx->hWideDev, ctx->hWide, 0) != hipSuccess) return fail(ORBX_E_HIP);
   ctx->hFlags[0] = ctx->hFlags[1] = 0;
 #undef ALLOC
 #undef ALLOCH
@@ -808,7 +873,7 @@ void orbx_destroy(orbx_ctx* ctx) {
                  ctx->dMi, ctx->dColor, ctx->dScore};
   for (void* p : dev)
     if (p) (void)hipFree(p);
-  void* host[] = {ctx->hNsel, ctx->hFlags, ctx->hMaxN};
+  void* host[] = {ctx->hNsel, ctx->hFlags, ctx->hMaxN, ctx->hWide};
   for (void* p : host)
     if (p) (void)hipHostFree(p);
   if (ctx->st2) (void)hipStreamSynchronize(ctx->st2);
@@ -1046,11 +1111,13 @@ int orbx_match_init_batch_device(orbx_ctx* ctx, int n_pairs, const int32_t* h_fi
   MatchArgs m;
   m.nPairs = n_pairs; m.b = *bounds; m.window = window_size; m.nnratio = nnratio; m.checkOri = check_orientation;
   m.dMatches12 = d_matches12; m.dNmatches = d_nmatches; m.dStats = d_stats;
+  armMatch(ctx, m, d_kps, d_desc32, d_n, capacity);
   r = issueMatch(ctx, 0, ctx->st, 0, n_pairs, m, d_kps, d_desc32, d_n, capacity);
   if (r != ORBX_OK) return r;
   HIPCHK(hipStreamSynchronize(ctx->st));
+  r = settleMatch(ctx, ctx->parity);  // (runs the wide kernels now if the batch turned out to need them)
   collectProfile(ctx, ctx->parity);
-  return ORBX_OK;
+  return r;
 }
 
 }  // extern "C"

@@ -882,7 +882,8 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
                                                                const uint8_t* __restrict__ desc, const int* __restrict__ nkp,
                                                                const MatchParams mp, int* __restrict__ matches12,
                                                                int* __restrict__ nmatchesOut, int* __restrict__ statsOut,
-                                                               int* __restrict__ scratch, long long scratchStride, int capl) {
+                                                               int* __restrict__ scratch, long long scratchStride, int capl,
+                                                               int* __restrict__ hostWide) {
   constexpr int MJ_T = MJ_CAP * MJ_P;
   __shared__ float tX[MJ_CAP], tY[MJ_CAP], tAng[MJ_CAP];
   __shared__ uint32_t tDesc[8][MJ_CAP];
@@ -964,7 +965,7 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
   }
   const int nQ = sBase, nT = sNT;
   if (nQ > MJ_CAP || nT > MJ_CAP || sOverflow) {  // block-uniform: the pair goes to the wide path
-    if (t == 0) nmatchesOut[pair] = MATCH_PENDING;
+    if (t == 0) { nmatchesOut[pair] = MATCH_PENDING; *hostWide = 1; }  // (mapped host memory: the batch needs the wide path)
     matchWidePrep<MJ_T>(pair, pairFirst, pairSecond, kps, nkp, mp, matches12, scratch, scratchStride, capl);
     return;
   }
@@ -1022,7 +1023,7 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
   if (t < nT) tOrd[t] = ((uint32_t)(tCx[t] * ORBX_GRID_ROWS + tCy[t]) << 20) | (uint32_t)tIdx[t];
   __syncthreads();
   if (sOverflow) {  // a window too full for the lists: the pair goes to the wide path
-    if (t == 0) nmatchesOut[pair] = MATCH_PENDING;
+    if (t == 0) { nmatchesOut[pair] = MATCH_PENDING; *hostWide = 1; }  // (mapped host memory: the batch needs the wide path)
     matchWidePrep<MJ_T>(pair, pairFirst, pairSecond, kps, nkp, mp, matches12, scratch, scratchStride, capl);
     return;
   }
@@ -1114,7 +1115,7 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
     if (sOverflow) break;
   }
   if (!converged) {  // block-uniform (sChanged / sOverflow are read after barriers)
-    if (t == 0) nmatchesOut[pair] = MATCH_PENDING;
+    if (t == 0) { nmatchesOut[pair] = MATCH_PENDING; *hostWide = 1; }  // (mapped host memory: the batch needs the wide path)
     matchWidePrep<MJ_T>(pair, pairFirst, pairSecond, kps, nkp, mp, matches12, scratch, scratchStride, capl);
     return;
   }
@@ -1351,6 +1352,18 @@ __device__ void matchGeneral(const int pair, const int* __restrict__ pairFirst, 
 // A pair the path cannot take (more than MW_CAP queries or trains, more than MW_CP listed candidates of one query) is
 // matched by the same workgroup of k_match_wide_resolve with matchGeneral.
 // -------------------------------------------------------------------------------------------------
+// matchWidePrep as a kernel of its own: only for a batch whose wide kernels were not issued with it (launch_match,
+// wideMode 2) - the scratch of its pending pairs may have been reused by a later batch in the meantime.
+__global__ __launch_bounds__(MW_T) void k_match_wide_prep(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
+                                                         const orbx_keypoint* __restrict__ kps, const int* __restrict__ nkp,
+                                                         const MatchParams mp, int* __restrict__ matches12,
+                                                         const int* __restrict__ nmatchesOut, int* __restrict__ scratch,
+                                                         long long scratchStride, int capl) {
+  const int pair = blockIdx.x + mp.pair0;
+  if (nmatchesOut[pair] != MATCH_PENDING) return;
+  matchWidePrep<MW_T>(pair, pairFirst, pairSecond, kps, nkp, mp, matches12, scratch, scratchStride, capl);
+}
+
 __global__ __launch_bounds__(256) void k_match_wide_lists(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
                                                          const orbx_keypoint* __restrict__ kps,
                                                          const uint8_t* __restrict__ desc, const int* __restrict__ nkp,
@@ -1876,7 +1889,9 @@ hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const 
 
 hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int* dSecond, const orbx_keypoint* kps,
                         const uint8_t* desc, const int* nkp, int capacity, orbx_bounds b, int window, float nnratio, int checkOri,
-                        int* matches12, int* nmatches, int* stats, int* scratch, int pair0) {
+                        int* matches12, int* nmatches, int* stats, int* scratch, int pair0, int wideMode, int* hostWide) {
+  // wideMode 1: k_match_jacobi and the wide kernels behind it; 0: k_match_jacobi only (the caller expects no pair to need the
+  // wide path and checks *hostWide afterwards); 2: the wide path alone, prep included, for the pairs still pending
   if (nPairs <= 0) return hipSuccess;
   MatchParams mp;
   mp.capacity = capacity; mp.window = window; mp.nnratio = nnratio; mp.checkOri = checkOri; mp.b = b;
@@ -1894,12 +1909,18 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
   const long long stride = matchScratchStride(capacity);  // = ensureMatchScratch
   const int capl = matchWideCap(capacity);
   const size_t lds = (size_t)capl * 12;  // head + tOrd + nextQ + outD: 48 KB at MW_CAP
-  hipLaunchKernelGGL((k_match_jacobi<256, 4, 24>), dim3(nPairs), dim3(1024), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
-                     matches12, nmatches, stats, scratch, stride, capl);
-  hipLaunchKernelGGL(k_match_wide_lists, dim3((capl + 63) / 64, nPairs), dim3(256), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
-                     nmatches, scratch, scratch, stride, capl);
-  hipLaunchKernelGGL(k_match_wide_resolve, dim3(nPairs), dim3(MW_T), lds, st, dFirst, dSecond, kps, desc, nkp, mp, matches12,
-                     nmatches, stats, scratch, stride, capl);
+  if (wideMode != 2)
+    hipLaunchKernelGGL((k_match_jacobi<256, 4, 24>), dim3(nPairs), dim3(1024), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
+                       matches12, nmatches, stats, scratch, stride, capl, hostWide);
+  if (wideMode == 2)
+    hipLaunchKernelGGL(k_match_wide_prep, dim3(nPairs), dim3(MW_T), 0, st, dFirst, dSecond, kps, nkp, mp, matches12, nmatches,
+                       scratch, stride, capl);
+  if (wideMode != 0) {
+    hipLaunchKernelGGL(k_match_wide_lists, dim3((capl + 63) / 64, nPairs), dim3(256), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
+                       nmatches, scratch, scratch, stride, capl);
+    hipLaunchKernelGGL(k_match_wide_resolve, dim3(nPairs), dim3(MW_T), lds, st, dFirst, dSecond, kps, desc, nkp, mp, matches12,
+                       nmatches, stats, scratch, stride, capl);
+  }
   return hipGetLastError();
 }
 

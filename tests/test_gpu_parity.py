@@ -546,6 +546,59 @@ def test_async_batches_equal_sync(orbx):
     e.close()
 
 
+def test_wide_matcher_issued_late(orbx, oracle):
+    """The wide matcher kernels travel with a batch only while batches need them.  After a run of batches that did not (few
+    keypoints), batches that do get them at their wait - also stream-ordered, two in flight - and then with the batch again."""
+    import torch
+    from orb_slam_tracking_amd import synth
+    params = (2000, 1.2, 2, 20, 7)  # two levels: ~1100 octave-0 keypoints per frame -> beyond k_match_jacobi's tables
+    B, cap, w, h = 32, 2000, 640, 480
+    e = orbx.ORBextractor(*params, max_width=w, max_height=h, max_batch=B)
+    oe = oracle.Extractor(*params)
+    rich = synth.synth_frames(B, w, h, seed0=4200)
+    flat = np.full((B, h, w), 90, np.uint8)
+    flat[:, 100:140, 200:260] = 200  # one rectangle: a handful of corners
+    d_rich, d_flat = torch.from_numpy(rich).cuda(), torch.from_numpy(flat).cuda()
+    first = np.arange(0, B, 2, dtype=np.int32)
+
+    def outs():
+        return dict(k=torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"), d=torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda"),
+                    n=torch.zeros(B, dtype=torch.int32, device="cuda"), m=torch.zeros((B // 2) * cap, dtype=torch.int32, device="cuda"),
+                    nm=torch.zeros(B // 2, dtype=torch.int32, device="cuda"), st=torch.zeros(B // 2 * 3, dtype=torch.int32, device="cuda"))
+
+    def run(img, o, async_):
+        f = e.extract_match_batch_device_async if async_ else e.extract_match_batch_device
+        f(img, B, w, h, w, w * h, o["k"], o["d"], o["n"], first, first + 1, (0, w, 0, h), o["m"], o["nm"], o["st"], 100, 0.9, True, cap)
+    # expected results of the rich batch from the oracle (pairs 0 and B/2 - 1 and one in the second half)
+    exp = {}
+    for p_ in (0, B // 4, B // 2 - 1):
+        a, b = oe(rich[2 * p_]), oe(rich[2 * p_ + 1])
+        exp[p_] = oracle.match_init(a[1], a[2], b[1], b[2], (0, w, 0, h), 100, 0.9, True)
+        assert (a[1]["octave"] == 0).sum() > 600
+
+    def check(o):
+        nm, st = o["nm"].cpu().numpy(), o["st"].cpu().numpy().reshape(-1, 3)
+        mm = o["m"].cpu().numpy().reshape(B // 2, cap)
+        for p_, (onm, om12, ost) in exp.items():
+            assert nm[p_] == onm and np.array_equal(mm[p_, :len(om12)], om12) and st[p_].tolist() == ost.tolist(), p_
+    o = outs()
+    run(d_rich, o, False)   # a fresh context issues the wide kernels with the batch
+    check(o)
+    scratch = outs()
+    for _ in range(10):     # ten batches that need nothing: the context stops issuing them
+        run(d_flat, scratch, False)
+    o1, o2 = outs(), outs()
+    run(d_rich, o1, True)   # two rich batches in flight without the wide kernels: both completed at their waits
+    run(d_rich, o2, True)
+    e.wait()
+    check(o1)
+    check(o2)
+    o3 = outs()
+    run(d_rich, o3, False)  # and with the batch again
+    check(o3)
+    e.close()
+
+
 def test_cpp_shim_equals_oracle(orbx, oracle, tmp_path):
     """The reference's demo call sequence through the C++ drop-in classes (include/orbx_shim.hpp)."""
     import subprocess
