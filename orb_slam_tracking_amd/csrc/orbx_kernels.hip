@@ -800,8 +800,8 @@ __device__ void matchWidePrep(const int pair, const int* __restrict__ pairFirst,
   __shared__ int sBaseQ, sBaseT;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fa = pairFirst[pair], fb = pairSecond[pair];
-  const int n1 = nkp[fa], n2 = nkp[fb];
   const int cap = mp.capacity;
+  const int n1 = min(max(nkp[fa], 0), cap), n2 = min(max(nkp[fb], 0), cap);  // (a count beyond the frame's slots is clamped)
   const orbx_keypoint* k1 = kps + (long long)fa * cap;
   const orbx_keypoint* k2 = kps + (long long)fb * cap;
   int* m12 = matches12 + (long long)pair * cap;
@@ -905,8 +905,8 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
   const int part = t / MJ_CAP, q = t - part * MJ_CAP;  // waves 0-3 = part 0, ...
   const int pair = blockIdx.x + mp.pair0;
   const int fa = pairFirst[pair], fb = pairSecond[pair];
-  const int n1 = nkp[fa], n2 = nkp[fb];
   const int cap = mp.capacity;
+  const int n1 = min(max(nkp[fa], 0), cap), n2 = min(max(nkp[fb], 0), cap);  // (a count beyond the frame's slots is clamped)
   const orbx_keypoint* k1 = kps + (long long)fa * cap;
   const orbx_keypoint* k2 = kps + (long long)fb * cap;
   const uint32_t* d1 = reinterpret_cast<const uint32_t*>(desc + (long long)fa * cap * 32);
@@ -1185,8 +1185,8 @@ __device__ void matchGeneral(const int pair, const int* __restrict__ pairFirst, 
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fa = pairFirst[pair], fb = pairSecond[pair];
-  const int n1 = nkp[fa], n2 = nkp[fb];
   const int cap = mp.capacity;
+  const int n1 = min(max(nkp[fa], 0), cap), n2 = min(max(nkp[fb], 0), cap);  // (a count beyond the frame's slots is clamped)
   const orbx_keypoint* k1 = kps + (long long)fa * cap;
   const orbx_keypoint* k2 = kps + (long long)fb * cap;
   const uint8_t* d1 = desc + (long long)fa * cap * 32;
