@@ -2,7 +2,7 @@
 """Randomised parity campaign (longer than the test suite allows): random frame sizes, extractor parameters, image
 content (synthetic scenes, uniform noise, smooth gradients with sparse corners), batch sizes and matcher settings; the
 device path (host API, batched device API, fused extract + match, stream-ordered call) against the CPU oracle, bit for
-bit.  usage: fuzz_parity.py [trials] [seed] [mixed|big|batched]  (big: up to 4000 x 2200 and 10000 features; batched:
+bit.  usage: fuzz_parity.py [trials] [seed] [mixed|big|batched|stateful]  (stateful: one context, many different calls; big: up to 4000 x 2200 and 10000 features; batched:
 33 .. 80 frames of 4-aligned width, i.e. the banded pyramid and the two stream pipelines).  Prints one line per trial and a
 summary; exits non-zero on a mismatch."""
 import os
@@ -49,6 +49,102 @@ def images(kind, B, w, h, seed):
 def same(k, d, ko, do):
     return len(k) == len(ko) and k.tobytes() == np.ascontiguousarray(ko, KP).tobytes() and np.array_equal(d, do)
 
+
+def stateful(trials):
+    """One context, many calls: frame size, batch size, image content, pair list and call form change from call to call
+    (geometry switches, selection-instance hint, cached pair list, wide-matcher expectation, batches in flight)."""
+    bad = 0
+    t0 = time.time()
+    for c in range(trials):
+        nlev = int(rng.integers(1, 7))
+        params = (int(rng.choice([300, 1000, 2500])), float(rng.choice([1.2, 1.3])) if nlev > 1 else 1.0, nlev,
+                  int(rng.integers(5, 30)), int(rng.integers(0, 6)))
+        MW, MH, MB = 900, 700, 36
+        e = orbx.ORBextractor(*params, max_width=MW, max_height=MH, max_batch=MB)
+        oe = O.Extractor(*params)
+        cap = params[0] + 64
+        sets = [dict(k=torch.zeros(MB * cap * 28, dtype=torch.uint8, device="cuda"), d=torch.zeros(MB * cap * 32, dtype=torch.uint8, device="cuda"),
+                     n=torch.zeros(MB, dtype=torch.int32, device="cuda"), m=torch.zeros((MB // 2) * cap, dtype=torch.int32, device="cuda"),
+                     nm=torch.zeros(MB // 2, dtype=torch.int32, device="cuda"), st=torch.zeros(MB // 2 * 3, dtype=torch.int32, device="cuda"))
+                for _ in range(2)]
+        pend = []  # (set index, frames, w, h, B, first, second, win, ratio, ori)
+
+        def verify(item):
+            si, fr, w, h, B, first, second, win, ratio, ori = item
+            o = sets[si]
+            n = o["n"].cpu().numpy()
+            kk = o["k"].cpu().numpy().view(KP).reshape(-1, cap)
+            dd = o["d"].cpu().numpy().reshape(-1, cap, 32)
+            mm = o["m"].cpu().numpy().reshape(-1, cap)
+            nm = o["nm"].cpu().numpy()
+            st = o["st"].cpu().numpy().reshape(-1, 3)
+            ora = [oe(f, cap=cap) for f in fr]
+            ok = True
+            for f_ in range(B):
+                ok &= n[f_] == len(ora[f_][1]) and same(kk[f_, :n[f_]], dd[f_, :n[f_]], ora[f_][1], ora[f_][2])
+            for p in range(len(first)):
+                a, b = ora[first[p]], ora[second[p]]
+                onm, om12, ost = O.match_init(a[1], a[2], b[1], b[2], (0, w, 0, h), win, ratio, ori)
+                ok &= nm[p] == onm and np.array_equal(mm[p, :len(om12)], om12) and st[p].tolist() == ost.tolist()
+            return ok
+        ok = True
+        ncalls = 0
+        for call in range(14):
+            w = int(rng.integers(60, MW // 4)) * 4 if rng.uniform() < 0.6 else int(rng.integers(240, MW))
+            h = int(rng.integers(200, MH))
+            while min(w, h) / params[1] ** (params[2] - 1) < 80:
+                w, h = w + 40, h + 40
+            w, h = min(w, MW), min(h, MH)
+            B = int(rng.choice([2, 4, 16, 33, 36]))
+            kind = str(rng.choice(["synth", "synth", "pairs_noise", "sparse"]))
+            fr = images(kind, B, w, h, 7000 + 100 * c + call)
+            form = int(rng.integers(0, 3))
+            first = np.arange(0, B - 1, 2, dtype=np.int32)
+            second = first + 1
+            if form == 1:
+                first, second = second.copy(), first.copy()
+            elif form == 2:
+                first, second = first[: max(1, len(first) // 2)], second[: max(1, len(first) // 2)]
+            win = int(rng.choice([50, 100, 4096]))
+            ratio = float(rng.choice([0.9, 0.7]))
+            ori = bool(rng.integers(0, 2))
+            use_async = bool(rng.integers(0, 2))
+            si = call & 1
+            if len(pend) == 2 or (pend and not use_async) or any(it[0] == si for it in pend):  # check before the set is reused
+                e.wait()
+                for it in pend:
+                    ok &= verify(it)
+                pend = []
+            d_img = torch.from_numpy(fr).cuda()
+            o = sets[si]
+            f = e.extract_match_batch_device_async if use_async else e.extract_match_batch_device
+            try:
+                f(d_img, B, w, h, w, w * h, o["k"], o["d"], o["n"], first, second, (0, w, 0, h), o["m"], o["nm"], o["st"], win, ratio, ori, cap)
+            except orbx.OrbxError as err:
+                if err.code == orbx.E_TOOSMALL:
+                    continue
+                raise
+            ncalls += 1
+            item = (si, fr, w, h, B, first, second, win, ratio, ori)
+            if use_async:
+                pend.append(item)
+                item[1].flags.writeable = False
+                keep = d_img  # noqa: F841  (the frames must outlive the batch)
+                sets[si]["img"] = d_img
+            else:
+                ok &= verify(item)
+        e.wait()
+        for it in pend:
+            ok &= verify(it)
+        print("context %d: params=%r, %d calls ->" % (c, params, ncalls), "ok" if ok else "MISMATCH", flush=True)
+        bad += not ok
+        e.close()
+    print("FUZZ %s: %d contexts (stateful), %d mismatching, %.0f s" % ("OK" if bad == 0 else "FAILED", trials, bad, time.time() - t0))
+    sys.exit(1 if bad else 0)
+
+
+if mode == "stateful":
+    stateful(trials)
 
 bad = skipped = 0
 t_start = time.time()
