@@ -607,12 +607,16 @@ int uploadPairs(orbx_ctx* ctx, int nPairs, const int32_t* hFirst, const int32_t*
     return ORBX_OK;
   int r = waitAll(ctx);  // batches in flight (either stream) may still read the list dPairs holds
   if (r != ORBX_OK) return r;
-  lp.clear();  // (stays empty if a copy fails)
-  *copied = true;
-  HIPCHK(hipMemcpyAsync(ctx->dPairs, hFirst, sizeof(int) * nPairs, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(ctx->dPairs + nPairs, hSecond, sizeof(int) * nPairs, hipMemcpyHostToDevice, st));
+  // the copy reads the context's own copy of the list, which stays put until the next change (the caller's arrays may be
+  // gone by the time a stream-ordered call's copy runs)
   lp.assign(hFirst, hFirst + nPairs);
   lp.insert(lp.end(), hSecond, hSecond + nPairs);
+  *copied = true;
+  if (hipMemcpyAsync(ctx->dPairs, lp.data(), sizeof(int) * 2 * nPairs, hipMemcpyHostToDevice, st) != hipSuccess) {
+    lp.clear();
+    ctx->err = "hipMemcpyAsync (pair list)";
+    return ORBX_E_HIP;
+  }
   return ORBX_OK;
 }
 
