@@ -61,9 +61,12 @@ typedef struct orbx_match_stats {
 typedef struct orbx_ctx orbx_ctx;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
-/* Creates a context on `device_id` able to process batches of up to `max_batch` frames of up to
- * max_width x max_height pixels.  `stream` is an optional hipStream_t (as void*) the caller wants
- * the work issued on (e.g. torch's current stream); NULL = the ctx creates its own.
+/* Creates a context on `device_id` sized for batches of up to `max_batch` frames of up to
+ * max_width x max_height pixels.  The sizes are an initial reservation, not a limit: like
+ * ORBextractor::operator() (cpp:1531-1545), every extraction entry point takes any frame size, and a call
+ * that brings a larger frame or batch drains what is in flight and re-allocates the context's buffers
+ * (a one-off cost of milliseconds; results are unaffected).  `stream` is an optional hipStream_t (as
+ * void*) the caller wants the work issued on (e.g. torch's current stream); NULL = the ctx creates its own.
  * Replaces ORBextractor::ORBextractor (cpp:492-595); scaleFactor==1 with nlevels>1 returns
  * ORBX_E_BADARG instead of exit(1) (cpp:502-505). */
 int orbx_create(const orbx_params* params, int device_id, int max_width, int max_height, int max_batch,
@@ -154,6 +157,16 @@ int orbx_extract_match_batch_device_async(orbx_ctx* ctx, int n_frames, const uin
 int orbx_wait_one(orbx_ctx* ctx); /* the oldest batch in flight (ORBX_OK if there is none) */
 int orbx_wait(orbx_ctx* ctx);     /* all batches in flight */
 
+/* Stream ordering against a caller's stream.  The context issues its work on its own HIP streams, which nothing
+ * orders against the stream the caller produces frames / consumes results on (e.g. torch's current stream):
+ *   orbx_order_after(ctx, s):  work issued on ctx from now on starts after everything queued on `s` so far
+ *                              (call it between producing the frames on `s` and the device-resident entry points);
+ *   orbx_order_before(ctx, s): work queued on `s` from now on starts after everything issued on ctx so far
+ *                              (for a consumer that reads the outputs of an _async batch without a host-side wait).
+ * `s` is a hipStream_t as void* (NULL = the legacy default stream).  Both only record / wait on events. */
+int orbx_order_after(orbx_ctx* ctx, void* stream);
+int orbx_order_before(orbx_ctx* ctx, void* stream);
+
 /* ---- between extractor and matcher: Frame::UndistortKeyPoints / ComputeImageBounds ---------- */
 /* (SlamTypes/Frame.cpp:101-161)  The camera as the reference holds it: mK's four entries and
  * mDistCoef = (k1, k2, p1, p2), all CV_32F (Config/Settings.hpp:28-39). */
@@ -222,10 +235,7 @@ int orbx_profile_get(orbx_ctx* ctx, double* ms, int64_t* launches);
  * into the reference's order (cell row, cell col, y, x): xyr = (x, y, response) triples relative to
  * (minBorderX, minBorderY) like vToDistributeKeys (cpp:1134-1137).  Returns the count. */
 int orbx_debug_candidates(orbx_ctx* ctx, int frame, int level, float* xyr, int cap);
-/* quadtree selection alone: DistributeOctTree (cpp:698-1011) on caller-supplied candidates. */
-int orbx_debug_distribute(const float* xyr, int n, int min_x, int max_x, int min_y, int max_y, int n_features,
-                          float* out_xyr, int cap);
-/* The same selection on the device (the kernels the pipeline uses).  Candidates must be given in row-major (y, x)
+/* The quadtree selection alone, DistributeOctTree (cpp:698-1011), on the device (the kernels the pipeline uses).  Candidates must be given in row-major (y, x)
  * order with integer coordinates in [0, 4095] relative to (min_x, min_y) and integer responses in [0, 255].
  * variant 0 = LDS-resident kernel (redoing a unit that does not fit on global scratch), variant 1 = global-scratch kernel
  * only, variant 2 = the smaller LDS instance (<= 1024 candidates) that the pipeline picks when the previous batch allows. */

@@ -97,6 +97,8 @@ def lib() -> ctypes.CDLL:
                                                   ctypes.POINTER(_Bounds), i32, f32, i32, vp, vp, vp]
     L.orbx_wait_one.argtypes = [vp]
     L.orbx_wait.argtypes = [vp]
+    L.orbx_order_after.argtypes = [vp, vp]
+    L.orbx_order_before.argtypes = [vp, vp]
     L.orbx_profile_stages.argtypes = [vp, ctypes.c_uint]
     L.orbx_undistort_keypoints.argtypes = [vp, vp, i32, ctypes.POINTER(_Camera), vp]
     L.orbx_undistort_batch_device.argtypes = [vp, i32, vp, vp, i32, ctypes.POINTER(_Camera), vp]
@@ -109,7 +111,6 @@ def lib() -> ctypes.CDLL:
     L.orbx_profile_reset.argtypes = [vp]
     L.orbx_profile_get.argtypes = [vp, vp, vp]
     L.orbx_debug_candidates.argtypes = [vp, i32, i32, vp, i32]
-    L.orbx_debug_distribute.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32]
     L.orbx_debug_distribute_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32]
     L.orbx_debug_std_sort.argtypes = [vp, vp, i32]
     L.orbx_debug_sincos.argtypes = [vp, vp, i32, vp, vp]
@@ -125,6 +126,16 @@ def _ptr(a) -> ctypes.c_void_p:
     if hasattr(a, "data_ptr"):  # torch tensor
         return ctypes.c_void_p(a.data_ptr())
     return ctypes.c_void_p(int(a))
+
+
+def _torch_stream(*arrays):
+    """The current torch stream (as an int handle) if any of the arguments is a torch CUDA tensor, else None: work
+    issued on the context's own HIP streams must start after what torch has queued for those tensors."""
+    for a in arrays:
+        if a is not None and hasattr(a, "data_ptr") and getattr(a, "is_cuda", False):
+            import torch
+            return int(torch.cuda.current_stream(a.device).cuda_stream)
+    return None
 
 
 class ORBextractor:
@@ -148,6 +159,7 @@ class ORBextractor:
         q = np.zeros(self.nlevels, np.int32)
         self._L.orbx_get_tables(self._h, None, None, None, None, _ptr(q))
         self.capacity = max(int(q.sum()), 1)
+        self.order_with_torch = True  # device-resident calls given torch tensors are ordered behind torch's current stream
 
     # -- lifetime ------------------------------------------------------------------------------
     def close(self):
@@ -160,6 +172,22 @@ class ORBextractor:
             self.close()
         except Exception:
             pass
+
+    def order_after(self, stream: Optional[int]) -> None:
+        """Work issued on this context from now on starts after everything queued on `stream` (hipStream_t handle)."""
+        self._check(self._L.orbx_order_after(self._h, ctypes.c_void_p(stream or 0)), "orbx_order_after")
+
+    def order_before(self, stream: Optional[int]) -> None:
+        """Work queued on `stream` from now on starts after everything issued on this context so far."""
+        self._check(self._L.orbx_order_before(self._h, ctypes.c_void_p(stream or 0)), "orbx_order_before")
+
+    def _order_torch(self, *arrays) -> None:
+        # torch tensors in: the producer of the frames (and the last reader of the output arrays) runs on torch's current
+        # stream, which the context's private streams know nothing about
+        if self.order_with_torch:
+            s = _torch_stream(*arrays)
+            if s is not None:
+                self.order_after(s)
 
     def _check(self, r: int, what: str = "") -> int:
         if r < 0:
@@ -236,6 +264,7 @@ class ORBextractor:
     def extract_batch_device(self, d_imgs, n_frames: int, width: int, height: int, stride: int, frame_stride: int,
                              d_kps, d_desc, d_n, capacity: Optional[int] = None) -> None:
         """Frames resident in HBM in, keypoints/descriptors/counts resident in HBM out (device pointers or torch tensors)."""
+        self._order_torch(d_imgs, d_kps, d_desc, d_n)
         r = self._L.orbx_extract_batch_device(self._h, int(n_frames), _ptr(d_imgs), int(width), int(height), int(stride),
                                               int(frame_stride), _ptr(d_kps), _ptr(d_desc), int(capacity or self.capacity),
                                               _ptr(d_n))
@@ -247,6 +276,7 @@ class ORBextractor:
         first = np.ascontiguousarray(first, np.int32)
         second = np.ascontiguousarray(second, np.int32)
         b = _Bounds(*[int(v) for v in bounds])
+        self._order_torch(d_kps, d_desc, d_n, d_matches12, d_nmatches, d_stats)
         r = self._L.orbx_match_init_batch_device(self._h, len(first), _ptr(first), _ptr(second), _ptr(d_kps), _ptr(d_desc),
                                                  _ptr(d_n), int(capacity or self.capacity), ctypes.byref(b), int(windowSize),
                                                  float(nnratio), int(bool(checkOri)), _ptr(d_matches12), _ptr(d_nmatches),
@@ -262,6 +292,7 @@ class ORBextractor:
         first = np.ascontiguousarray(first, np.int32)
         second = np.ascontiguousarray(second, np.int32)
         b = _Bounds(*[int(v) for v in bounds])
+        self._order_torch(d_imgs, d_kps, d_desc, d_n, d_matches12, d_nmatches, d_stats)
         r = self._L.orbx_extract_match_batch_device(self._h, int(n_frames), _ptr(d_imgs), int(width), int(height), int(stride),
                                                     int(frame_stride), _ptr(d_kps), _ptr(d_desc), int(capacity or self.capacity),
                                                     _ptr(d_n), len(first), _ptr(first), _ptr(second), ctypes.byref(b),
@@ -279,6 +310,7 @@ class ORBextractor:
         first = np.ascontiguousarray(first, np.int32)
         second = np.ascontiguousarray(second, np.int32)
         b = _Bounds(*[int(v) for v in bounds])
+        self._order_torch(d_imgs, d_kps, d_desc, d_n, d_matches12, d_nmatches, d_stats)
         r = self._L.orbx_extract_match_batch_device_async(self._h, int(n_frames), _ptr(d_imgs), int(width), int(height),
                                                           int(stride), int(frame_stride), _ptr(d_kps), _ptr(d_desc),
                                                           int(capacity or self.capacity), _ptr(d_n), len(first), _ptr(first),
@@ -311,6 +343,7 @@ class ORBextractor:
 
     def to_gray_batch_device(self, d_src, n_frames: int, width: int, height: int, stride: int, frame_stride: int, channels: int,
                              bRGB: bool, d_gray, gray_stride: int, gray_frame_stride: int) -> None:
+        self._order_torch(d_src, d_gray)
         self._check(self._L.orbx_to_gray_batch_device(self._h, int(n_frames), _ptr(d_src), int(width), int(height), int(stride),
                                                       int(frame_stride), int(channels), int(bool(bRGB)), _ptr(d_gray),
                                                       int(gray_stride), int(gray_frame_stride)), "orbx_to_gray_batch_device")
@@ -328,6 +361,7 @@ class ORBextractor:
     def undistort_batch_device(self, n_frames: int, d_kps, d_n, camera: Sequence[float], d_kps_un,
                                capacity: Optional[int] = None) -> None:
         cam = _Camera(*[float(v) for v in camera])
+        self._order_torch(d_kps, d_n, d_kps_un)
         self._check(self._L.orbx_undistort_batch_device(self._h, int(n_frames), _ptr(d_kps), _ptr(d_n),
                                                         int(capacity or self.capacity), ctypes.byref(cam), _ptr(d_kps_un)),
                     "orbx_undistort_batch_device")
@@ -428,16 +462,6 @@ class ORBextractor:
         out = np.zeros((max(n, 1), 3), np.float32)
         self._check(self._L.orbx_debug_candidates(self._h, frame, level, _ptr(out), n))
         return out[:n]
-
-
-def debug_distribute(xyr: np.ndarray, min_x: int, max_x: int, min_y: int, max_y: int, n_features: int) -> np.ndarray:
-    """DistributeOctTree alone (host stage of liborbx; test hook)."""
-    xyr = np.ascontiguousarray(xyr, np.float32).reshape(-1, 3)
-    out = np.zeros((len(xyr) + 8, 3), np.float32)
-    r = lib().orbx_debug_distribute(_ptr(xyr), len(xyr), min_x, max_x, min_y, max_y, n_features, _ptr(out), len(out))
-    if r < 0:
-        raise OrbxError(r, "orbx_debug_distribute")
-    return out[:r]
 
 
 def camera_from(K, distCoef) -> Tuple[float, ...]:

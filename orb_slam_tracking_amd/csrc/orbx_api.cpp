@@ -17,7 +17,6 @@
 #include <vector>
 
 #include "orbx_device.h"
-#include "orbx_internal.h"
 
 namespace orbx {
 
@@ -99,7 +98,7 @@ struct orbx_ctx {
   int* dNselLevel = nullptr;
   uint8_t* dOctScratch = nullptr;
   size_t octScratchBytes = 0;
-  int* hFlags = nullptr;  // pinned, written by k_sel_compact through hFlagsDev: [1] selection error ([0] unused)
+  int* hFlags = nullptr;  // pinned [2], written by k_sel_compact through hFlagsDev: selection error of the batch in flight with that parity
   int* hFlagsDev = nullptr;
   int* hNselDev = nullptr;  // device view of hNsel: k_sel_compact stores the per-frame counts straight to the host
   // The wide matcher kernels are issued with a batch only while batches need them (k_match_jacobi raises hWide[parity]
@@ -149,6 +148,7 @@ struct orbx_ctx {
 
   hipStream_t st2 = nullptr;  // second stream: half-batches overlap (extractCore)
   hipEvent_t evFork = nullptr, evJoin = nullptr;
+  hipEvent_t evOrder = nullptr;  // orbx_order_after / orbx_order_before: the caller's stream <-> the context's streams
 
   // profiling
   unsigned profMask = 0;  // stages whose launches are bracketed by events (bit = ORBX_STAGE_*)
@@ -375,14 +375,136 @@ size_t buildOctLaunch(const orbx_ctx* c, const Geom& g, OctLaunch* out) {
   return (size_t)scr;
 }
 
+// Every buffer whose size follows from (maxW, maxH, maxB): allocated at orbx_create and again by growTo when a call brings
+// a larger frame or batch (ORBextractor::operator() takes any image, cpp:1531-1545).  Streams, events and the lazily sized
+// matcher / staging buffers are not touched.
+void freeAll(orbx_ctx* ctx) {
+  void* dev[] = {ctx->dPyr, ctx->dCand, ctx->dCandCount, ctx->dCellCount, ctx->dMaxN, ctx->dTab, ctx->dSel, ctx->dNsel, ctx->dSelStage,
+                 ctx->dNselLevel, ctx->dOctScratch, ctx->dIn, ctx->dKps, ctx->dDesc};
+  for (void* p : dev)
+    if (p) (void)hipFree(p);
+  void* host[] = {ctx->hNsel, ctx->hFlags, ctx->hMaxN, ctx->hWide};
+  for (void* p : host)
+    if (p) (void)hipHostFree(p);
+  ctx->dPyr = nullptr; ctx->dCand = nullptr; ctx->dCandCount = nullptr; ctx->dCellCount = nullptr; ctx->dMaxN = nullptr;
+  ctx->dTab = nullptr; ctx->dSel = nullptr; ctx->dNsel = nullptr; ctx->dSelStage = nullptr; ctx->dNselLevel = nullptr;
+  ctx->dOctScratch = nullptr; ctx->dIn = nullptr; ctx->dKps = nullptr; ctx->dDesc = nullptr;
+  ctx->hNsel = nullptr; ctx->hFlags = nullptr; ctx->hMaxN = nullptr; ctx->hWide = nullptr;
+  ctx->hNselDev = nullptr; ctx->hFlagsDev = nullptr; ctx->hMaxNDev = nullptr; ctx->hWideDev = nullptr;
+  ctx->curW = ctx->curH = ctx->curStride0 = 0;  // the tables on the device are gone with dTab
+  ctx->lastB = 0;
+  ctx->lastImg0 = nullptr;
+}
+
+int allocAll(orbx_ctx* ctx) {
+  const int max_width = ctx->maxW, max_height = ctx->maxH, max_batch = ctx->maxB;
+  Geom g;
+  std::vector<ResizeTab> tab;
+  int r = buildGeometry(ctx, max_width, max_height, alignUp(max_width, 64), &g, &tab);
+  if (r != ORBX_OK) return r;
+  Sizes s = sizesOf(ctx, g, tab.size());
+  // row strides grow by at most 63 bytes and tables by a few entries for smaller frames: keep headroom
+  ctx->pyrBytes = s.pyrBytes + (size_t)64 * max_height * ctx->p.nlevels * max_batch + 4096;
+  {
+    // per-level bound of cells * segCap that holds for every frame size up to max_width x max_height:
+    // cells * ceil(wCell / 2) * ceil(hCell / 2) <= (width / 2 + nCols + 1) * (height / 2 + nRows + 1)
+    size_t bound = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+      const size_t wd = (size_t)(g.L[l].maxBX - ORBX_MIN_BORDER), ht = (size_t)(g.L[l].maxBY - ORBX_MIN_BORDER);
+      bound += ((wd / 2 + wd / 35 + 2) * (ht / 2 + ht / 35 + 2) + 4 * (wd / 35 + 1) * (ht / 35 + 1)) * (size_t)max_batch;
+    }
+    ctx->candEntries = std::max(s.candEntries, bound) + 1024;
+    ctx->cellCountEntries = (size_t)g.nCellsTotal * max_batch + 1024;
+  }
+  ctx->tabEntries = s.tabEntries + 64 * ctx->p.nlevels;
+  const size_t B = (size_t)max_batch, nl = (size_t)ctx->p.nlevels;
+  const size_t cap = (size_t)std::max(ctx->selCap, 1);
+  ctx->inBytes = (size_t)alignUp(max_width, 64) * max_height * B;
+#define ALLOC(ptr, bytes)                                                                         \
+  if (hipMalloc((void**)&(ptr), std::max<size_t>((bytes), 16)) != hipSuccess) {                  \
+    ctx->err = "hipMalloc failed for " #ptr " (context sizing: max_width x max_height x max_batch)"; \
+    return ORBX_E_HIP;                                                                            \
+  }
+#define ALLOCH(ptr, bytes)                                                                        \
+  if (hipHostMalloc((void**)&(ptr), std::max<size_t>((bytes), 16), hipHostMallocDefault) != hipSuccess) return ORBX_E_HIP
+  ALLOC(ctx->dPyr, ctx->pyrBytes);
+  ALLOC(ctx->dCand, ctx->candEntries * 4);
+  ALLOC(ctx->dCandCount, (B * nl + 2) * sizeof(int));
+  ALLOC(ctx->dCellCount, ctx->cellCountEntries * sizeof(int));
+  ctx->dOverflow = ctx->dCandCount + B * nl;  // (unused tail kept for layout compatibility)
+  ALLOC(ctx->dTab, ctx->tabEntries * sizeof(ResizeTab));
+  ALLOC(ctx->dSel, B * cap * sizeof(SelKp));
+  ALLOC(ctx->dNsel, B * sizeof(int));
+  ALLOC(ctx->dSelStage, B * cap * sizeof(SelKp));
+  ALLOC(ctx->dNselLevel, B * nl * sizeof(int));
+  {
+    OctLaunch oct;
+    ctx->octScratchBytes = buildOctLaunch(ctx, g, &oct) + 4096;
+    ctx->maxQuota = 0;
+    for (int q : ctx->quota) ctx->maxQuota = std::max(ctx->maxQuota, q);
+  }
+  ALLOC(ctx->dOctScratch, ctx->octScratchBytes);
+  ALLOC(ctx->dIn, ctx->inBytes);
+  ALLOC(ctx->dKps, B * cap * sizeof(orbx_keypoint));
+  ALLOC(ctx->dDesc, B * cap * 32);
+  ALLOCH(ctx->hNsel, B * sizeof(int));
+  ALLOCH(ctx->hFlags, 2 * sizeof(int));
+  ALLOC(ctx->dMaxN, 2 * ORBX_MAX_LEVELS * sizeof(int));
+  if (hipMemset(ctx->dMaxN, 0, 2 * ORBX_MAX_LEVELS * sizeof(int)) != hipSuccess) return ORBX_E_HIP;
+  ALLOCH(ctx->hMaxN, 2 * ORBX_MAX_LEVELS * sizeof(int));
+  if (hipHostGetDevicePointer((void**)&ctx->hMaxNDev, ctx->hMaxN, 0) != hipSuccess) return ORBX_E_HIP;
+  if (hipHostGetDevicePointer((void**)&ctx->hNselDev, ctx->hNsel, 0) != hipSuccess) return ORBX_E_HIP;
+  if (hipHostGetDevicePointer((void**)&ctx->hFlagsDev, ctx->hFlags, 0) != hipSuccess) return ORBX_E_HIP;
+  ALLOCH(ctx->hWide, 16);
+  ctx->hWide[0] = ctx->hWide[1] = 0;
+  if (hipHostGetDevicePointer((void**)&ctx->hWideDev, ctx->hWide, 0) != hipSuccess) return ORBX_E_HIP;
+  ctx->hFlags[0] = ctx->hFlags[1] = 0;
+  for (int i = 0; i < 2 * ORBX_MAX_LEVELS; i++) ctx->hMaxN[i] = 0;
+  ctx->candHint = 0;
+  ctx->maxSlotsUsed = 0;
+#undef ALLOC
+#undef ALLOCH
+  return ORBX_OK;
+}
+
+// A call brought a larger frame or batch than the context was sized for: everything in flight is drained, the size
+// dependent buffers are released and allocated again for the new maxima (never smaller than before).
+int waitAll(orbx_ctx* ctx);
+int growTo(orbx_ctx* ctx, int w, int h, int B) {
+  int r = waitAll(ctx);
+  if (r == ORBX_E_HIP) return r;
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  if (ctx->st2) HIPCHK(hipStreamSynchronize(ctx->st2));
+  const int oldW = ctx->maxW, oldH = ctx->maxH, oldB = ctx->maxB;
+  freeAll(ctx);
+  ctx->maxW = std::max(oldW, w);
+  ctx->maxH = std::max(oldH, h);
+  ctx->maxB = std::max(oldB, B);
+  r = allocAll(ctx);
+  if (r != ORBX_OK) {  // (e.g. out of device memory) fall back to the old sizing so that the context stays usable
+    freeAll(ctx);
+    ctx->maxW = oldW; ctx->maxH = oldH; ctx->maxB = oldB;
+    const std::string why = ctx->err;
+    if (allocAll(ctx) != ORBX_OK) { ctx->err = "context could not be re-allocated after a failed growth"; return ORBX_E_HIP; }
+    ctx->err = "context growth failed: " + why;
+    return r;
+  }
+  return ORBX_OK;
+}
+
 int ensureGeometry(orbx_ctx* ctx, int w, int h, int stride0) {
   if (w == ctx->curW && h == ctx->curH && stride0 == ctx->curStride0) return ORBX_OK;
   if (w <= 0 || h <= 0) return ORBX_E_EMPTY;
-  if (w > ctx->maxW || h > ctx->maxH) { ctx->err = "frame larger than the context's max_width/max_height"; return ORBX_E_BADARG; }
   Geom g;
   std::vector<ResizeTab> tab;
-  int r = buildGeometry(ctx, w, h, stride0, &g, &tab);
+  int r = buildGeometry(ctx, w, h, stride0, &g, &tab);  // (before any growth: a frame the path cannot take must not cost one)
   if (r != ORBX_OK) return r;
+  if (w > ctx->maxW || h > ctx->maxH) {  // operator() accepts any image (cpp:1531-1545): the context grows
+    r = growTo(ctx, w, h, ctx->maxB);
+    if (r != ORBX_OK) return r;
+    r = buildGeometry(ctx, w, h, stride0, &g, &tab);  // (offsets depend on maxB only, but keep one source of truth)
+    if (r != ORBX_OK) return r;
+  }
   Sizes s = sizesOf(ctx, g, tab.size());
   OctLaunch oct;
   const size_t octBytes = buildOctLaunch(ctx, g, &oct);
@@ -521,7 +643,7 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
     HIPCHK(launch_octree(st, n, ctx->dCand, ctx->dCellCount, oct, ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, ctx->maxQuota,
                          dMax, ctx->candHint));
     HIPCHK(launch_sel_compact(st, n, ctx->dSelStage, ctx->dNselLevel, oct, ctx->dSel, ctx->dNsel, a.dNuser, ctx->hNselDev, g.selCap,
-                              ctx->hFlagsDev + 1, dMax, ctx->hMaxNDev + si * ORBX_MAX_LEVELS));
+                              ctx->hFlagsDev + ctx->parity, dMax, ctx->hMaxNDev + si * ORBX_MAX_LEVELS));
     ctx->maxSlotsUsed |= 1 << si;
     tm.stop(2);
   }
@@ -641,8 +763,8 @@ int waitOldest(orbx_ctx* ctx) {
     ctx->candHint = m;
     if (ctx->pending == 0) ctx->maxSlotsUsed = 0;
   }
-  if (ctx->hFlags[1]) {  // raised by k_sel_compact through mapped host memory
-    ctx->hFlags[1] = 0;
+  if (ctx->hFlags[parity]) {  // raised by this batch's k_sel_compact through mapped host memory (one slot per parity: the
+    ctx->hFlags[parity] = 0;   // other batch in flight reports into its own)
     ctx->err = "selection stage: more candidates or nodes than its scratch can hold";
     return ORBX_E_CAPACITY;
   }
@@ -665,9 +787,12 @@ int waitAll(orbx_ctx* ctx) {
 int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int stride0, long long frameStride0,
                 orbx_keypoint* dKps, uint8_t* dDesc, int capacity, int* dNout, const MatchArgs* match, bool async = false) {
   if (B <= 0) return ORBX_E_BADARG;
-  if (B > ctx->maxB) { ctx->err = "batch larger than max_batch"; return ORBX_E_BADARG; }
   if (capacity < ctx->selCap) return ORBX_E_CAPACITY;
   int r = ORBX_OK;
+  if (B > ctx->maxB) {  // a larger batch than the context was sized for: it grows (everything in flight is drained first)
+    r = growTo(ctx, ctx->maxW, ctx->maxH, B);
+    if (r != ORBX_OK) return r;
+  }
   if (ctx->pending >= 2) {  // the events of this parity are still in use
     r = waitOldest(ctx);
     if (r != ORBX_OK) return r;
@@ -681,6 +806,7 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
   ctx->parity = (int)(ctx->seqIssue & 1u);
   r = ensureGeometry(ctx, w, h, stride0);
   if (r != ORBX_OK) return r;
+  ctx->parity = (int)(ctx->seqIssue & 1u);  // (a growth waits for the batches in flight)
   hipStream_t st = ctx->st;
   ExtractArgs a;
   a.dImg0 = dImg0; a.stride0 = stride0; a.frameStride0 = frameStride0;
@@ -715,41 +841,60 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
     while (p1 < nPairs && match->hFirst[p1] >= n0 && match->hSecond[p1] >= n0) p1++;
   }
   ctx->done2Used[ctx->parity] = split;
-  if (split) {
-    // The two streams are independent pipelines (disjoint halves of every internal buffer): the second waits for the
-    // first only when the first carries something it needs (a new pair list, or work of another call of the context
-    // queued on st), the first for the second only when pairs straddle the halves.
-    if (pairsCopied || ctx->pending == 0 || !ctx->ownStream) {  // (a caller's stream may carry the producer of the frames)
-      HIPCHK(hipEventRecord(ctx->evFork, st));
-      HIPCHK(hipStreamWaitEvent(ctx->st2, ctx->evFork, 0));
+  // Everything below queues work; a failure in the middle must not leave launches in flight behind an error return (the
+  // next call would reuse their buffers and events), so the issue is one unit with one exit.
+  auto issue = [&]() -> int {
+    int q = ORBX_OK;
+    if (split) {
+      // The two streams are independent pipelines (disjoint halves of every internal buffer).  The second stream waits for
+      // the first whenever the first may carry something the second depends on: the producer of the frames (a copy into
+      // dIn queued by the host-pointer entry points, work of any synchronous call, a caller's stream), a new pair list or
+      // new tables.  Only a stream-ordered (_async) call on the context's own stream with another batch in flight and an
+      // unchanged pair list skips the fork: nothing but the previous batches sits on st then (every other entry point
+      // drains the batches in flight first), and the frames are the caller's own resident array.
+      const bool needFork = !async || pairsCopied || ctx->pending == 0 || !ctx->ownStream;
+      if (needFork) {
+        HIPCHK(hipEventRecord(ctx->evFork, st));
+        HIPCHK(hipStreamWaitEvent(ctx->st2, ctx->evFork, 0));
+      }
+      // the two chains are issued alternately: the device starts on the second while the host still issues the first
+      if ((q = issueExtract(ctx, 0, st, 0, n0, a, 0)) != ORBX_OK) return q;
+      if ((q = issueExtract(ctx, 1, ctx->st2, n0, B - n0, a, 0)) != ORBX_OK) return q;
+      if ((q = issueExtract(ctx, 0, st, 0, n0, a, 1)) != ORBX_OK) return q;
+      if (nPairs > 0 && (q = issueMatch(ctx, 0, st, 0, p0, *match, dKps, dDesc, dN, capacity)) != ORBX_OK) return q;
+      if ((q = issueExtract(ctx, 1, ctx->st2, n0, B - n0, a, 1)) != ORBX_OK) return q;
+      if (nPairs > 0 && (q = issueMatch(ctx, 1, ctx->st2, p0, p1 - p0, *match, dKps, dDesc, dN, capacity)) != ORBX_OK) return q;
+      if (nPairs > p1) {
+        HIPCHK(hipEventRecord(ctx->evJoin, ctx->st2));
+        HIPCHK(hipStreamWaitEvent(st, ctx->evJoin, 0));
+        if ((q = issueMatch(ctx, 0, st, p1, nPairs - p1, *match, dKps, dDesc, dN, capacity)) != ORBX_OK) return q;
+      }
+      HIPCHK(hipEventRecord(ctx->evDone2[ctx->parity], ctx->st2));
+    } else {
+      if ((q = issueExtract(ctx, 0, st, 0, B, a, 0)) != ORBX_OK) return q;
+      if ((q = issueExtract(ctx, 0, st, 0, B, a, 1)) != ORBX_OK) return q;
+      if (nPairs > 0 && (q = issueMatch(ctx, 0, st, 0, nPairs, *match, dKps, dDesc, dN, capacity)) != ORBX_OK) return q;
     }
-    // the two chains are issued alternately: the device starts on the second while the host still issues the first
-    r = issueExtract(ctx, 0, st, 0, n0, a, 0);
-    if (r != ORBX_OK) return r;
-    r = issueExtract(ctx, 1, ctx->st2, n0, B - n0, a, 0);
-    if (r != ORBX_OK) return r;
-    r = issueExtract(ctx, 0, st, 0, n0, a, 1);
-    if (r != ORBX_OK) return r;
-    if (nPairs > 0) { r = issueMatch(ctx, 0, st, 0, p0, *match, dKps, dDesc, dN, capacity); if (r != ORBX_OK) return r; }
-    r = issueExtract(ctx, 1, ctx->st2, n0, B - n0, a, 1);
-    if (r != ORBX_OK) return r;
-    if (nPairs > 0) { r = issueMatch(ctx, 1, ctx->st2, p0, p1 - p0, *match, dKps, dDesc, dN, capacity); if (r != ORBX_OK) return r; }
-    if (nPairs > p1) {
-      HIPCHK(hipEventRecord(ctx->evJoin, ctx->st2));
-      HIPCHK(hipStreamWaitEvent(st, ctx->evJoin, 0));
-      r = issueMatch(ctx, 0, st, p1, nPairs - p1, *match, dKps, dDesc, dN, capacity);
-      if (r != ORBX_OK) return r;
-    }
-    HIPCHK(hipEventRecord(ctx->evDone2[ctx->parity], ctx->st2));
-  } else {
-    r = issueExtract(ctx, 0, st, 0, B, a, 0);
-    if (r != ORBX_OK) return r;
-    r = issueExtract(ctx, 0, st, 0, B, a, 1);
-    if (r != ORBX_OK) return r;
-    if (nPairs > 0) { r = issueMatch(ctx, 0, st, 0, nPairs, *match, dKps, dDesc, dN, capacity); if (r != ORBX_OK) return r; }
+    // (the per-frame counts and the error flag arrive in pinned host memory straight from k_sel_compact)
+    HIPCHK(hipEventRecord(ctx->evDone[ctx->parity], st));
+    return ORBX_OK;
+  };
+  r = issue();
+  if (r != ORBX_OK) {
+    // part of the batch may be queued: drain both streams in-process, forget what was armed for it, and make the next
+    // call upload the pair list again if this call's upload is the one that may have failed
+    const std::string why = ctx->err;
+    (void)hipStreamSynchronize(st);
+    if (ctx->st2) (void)hipStreamSynchronize(ctx->st2);
+    ctx->late[ctx->parity].valid = false;
+    ctx->hWide[ctx->parity] = 0;
+    ctx->hFlags[ctx->parity] = 0;
+    for (int si = 0; si < 2; si++)
+      for (int s2 = 0; s2 < ORBX_STAGE_COUNT; s2++) ctx->used[ctx->parity][si][s2] = false;
+    if (pairsCopied) ctx->lastPairs.clear();
+    ctx->err = why;
+    return r;
   }
-  // (the per-frame counts and the error flag arrive in pinned host memory straight from k_sel_compact)
-  HIPCHK(hipEventRecord(ctx->evDone[ctx->parity], st));
   ctx->seqIssue++;
   ctx->pending++;
   ctx->lastImg0 = dImg0;
@@ -792,66 +937,10 @@ int orbx_create(const orbx_params* params, int device_id, int max_width, int max
     if (hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess) return fail(ORBX_E_HIP);
     ctx->ownStream = true;
   }
-  Geom g;
-  std::vector<ResizeTab> tab;
-  int r = buildGeometry(ctx, max_width, max_height, alignUp(max_width, 64), &g, &tab);
-  if (r != ORBX_OK) return fail(r);
-  Sizes s = sizesOf(ctx, g, tab.size());
-  // row strides grow by at most 63 bytes and tables by a few entries for smaller frames: keep headroom
-  ctx->pyrBytes = s.pyrBytes + (size_t)64 * max_height * ctx->p.nlevels * max_batch + 4096;
   {
-    // per-level bound of cells * segCap that holds for every frame size up to max_width x max_height:
-    // cells * ceil(wCell / 2) * ceil(hCell / 2) <= (width / 2 + nCols + 1) * (height / 2 + nRows + 1)
-    size_t bound = 0;
-    for (int l = 0; l < g.nlevels; l++) {
-      const size_t wd = (size_t)(g.L[l].maxBX - ORBX_MIN_BORDER), ht = (size_t)(g.L[l].maxBY - ORBX_MIN_BORDER);
-      bound += ((wd / 2 + wd / 35 + 2) * (ht / 2 + ht / 35 + 2) + 4 * (wd / 35 + 1) * (ht / 35 + 1)) * (size_t)max_batch;
-    }
-    ctx->candEntries = std::max(s.candEntries, bound) + 1024;
-    ctx->cellCountEntries = (size_t)g.nCellsTotal * max_batch + 1024;
+    const int r = allocAll(ctx);
+    if (r != ORBX_OK) return fail(r);
   }
-  ctx->tabEntries = s.tabEntries + 64 * ctx->p.nlevels;
-  const size_t B = (size_t)max_batch, nl = (size_t)ctx->p.nlevels;
-  const size_t cap = (size_t)std::max(ctx->selCap, 1);
-  ctx->inBytes = (size_t)alignUp(max_width, 64) * max_height * B;
-#define ALLOC(ptr, bytes)                                                      \
-  if (hipMalloc((void**)&(ptr), std::max<size_t>((bytes), 16)) != hipSuccess) return fail(ORBX_E_HIP)
-#define ALLOCH(ptr, bytes)                                                     \
-  if (hipHostMalloc((void**)&(ptr), std::max<size_t>((bytes), 16), hipHostMallocDefault) != hipSuccess) return fail(ORBX_E_HIP)
-  ALLOC(ctx->dPyr, ctx->pyrBytes);
-  ALLOC(ctx->dCand, ctx->candEntries * 4);
-  ALLOC(ctx->dCandCount, (B * nl + 2) * sizeof(int));
-  ALLOC(ctx->dCellCount, ctx->cellCountEntries * sizeof(int));
-  ctx->dOverflow = ctx->dCandCount + B * nl;  // [0] candidate overflow, [1] selection error
-  ALLOC(ctx->dTab, ctx->tabEntries * sizeof(ResizeTab));
-  ALLOC(ctx->dSel, B * cap * sizeof(SelKp));
-  ALLOC(ctx->dNsel, B * sizeof(int));
-  ALLOC(ctx->dSelStage, B * cap * sizeof(SelKp));
-  ALLOC(ctx->dNselLevel, B * nl * sizeof(int));
-  {
-    OctLaunch oct;
-    ctx->octScratchBytes = buildOctLaunch(ctx, g, &oct) + 4096;
-    ctx->maxQuota = 0;
-    for (int q : ctx->quota) ctx->maxQuota = std::max(ctx->maxQuota, q);
-  }
-  ALLOC(ctx->dOctScratch, ctx->octScratchBytes);
-  ALLOC(ctx->dIn, ctx->inBytes);
-  ALLOC(ctx->dKps, B * cap * sizeof(orbx_keypoint));
-  ALLOC(ctx->dDesc, B * cap * 32);
-  ALLOCH(ctx->hNsel, B * sizeof(int));
-  ALLOCH(ctx->hFlags, 2 * sizeof(int));
-  ALLOC(ctx->dMaxN, 2 * ORBX_MAX_LEVELS * sizeof(int));
-  if (hipMemset(ctx->dMaxN, 0, 2 * ORBX_MAX_LEVELS * sizeof(int)) != hipSuccess) return fail(ORBX_E_HIP);
-  ALLOCH(ctx->hMaxN, 2 * ORBX_MAX_LEVELS * sizeof(int));
-  if (hipHostGetDevicePointer((void**)&ctx->hMaxNDev, ctx->hMaxN, 0) != hipSuccess) return fail(ORBX_E_HIP);
-  if (hipHostGetDevicePointer((void**)&ctx->hNselDev, ctx->hNsel, 0) != hipSuccess) return fail(ORBX_E_HIP);
-  if (hipHostGetDevicePointer((void**)&ctx->hFlagsDev, ctx->hFlags, 0) != hipSuccess) return fail(ORBX_E_HIP);
-  if (hipHostMalloc((void**)&ctx->hWide, 16, hipHostMallocDefault) != hipSuccess) return fail(ORBX_E_HIP);
-  ctx->hWide[0] = ctx->hWide[1] = 0;
-  if (hipHostGetDevicePointer((void**)&ctx->hWideDev, ctx->hWide, 0) != hipSuccess) return fail(ORBX_E_HIP);
-  ctx->hFlags[0] = ctx->hFlags[1] = 0;
-#undef ALLOC
-#undef ALLOCH
   for (int si = 0; si < 2; si++)
     for (int s2 = 0; s2 < ORBX_STAGE_COUNT; s2++)
       for (int k = 0; k < 2; k++)
@@ -864,6 +953,7 @@ int orbx_create(const orbx_params* params, int device_id, int max_width, int max
   if (hipStreamCreateWithFlags(&ctx->st2, hipStreamNonBlocking) != hipSuccess) return fail(ORBX_E_HIP);
   if (hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming) != hipSuccess) return fail(ORBX_E_HIP);
   if (hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming) != hipSuccess) return fail(ORBX_E_HIP);
+  if (hipEventCreateWithFlags(&ctx->evOrder, hipEventDisableTiming) != hipSuccess) return fail(ORBX_E_HIP);
   *out = ctx;
   return ORBX_OK;
 }
@@ -872,15 +962,11 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->st) (void)hipStreamSynchronize(ctx->st);
-  void* dev[] = {ctx->dPyr, ctx->dCand, ctx->dCandCount, ctx->dCellCount, ctx->dMaxN, ctx->dTab, ctx->dSel, ctx->dNsel, ctx->dSelStage, ctx->dNselLevel,
-                 ctx->dOctScratch, ctx->dIn, ctx->dKps, ctx->dDesc, ctx->dMatchScratch, ctx->dPairs, ctx->dMk, ctx->dMd,
-                 ctx->dMi, ctx->dColor, ctx->dScore};
+  if (ctx->st2) (void)hipStreamSynchronize(ctx->st2);
+  freeAll(ctx);
+  void* dev[] = {ctx->dMatchScratch, ctx->dPairs, ctx->dMk, ctx->dMd, ctx->dMi, ctx->dColor, ctx->dScore};
   for (void* p : dev)
     if (p) (void)hipFree(p);
-  void* host[] = {ctx->hNsel, ctx->hFlags, ctx->hMaxN, ctx->hWide};
-  for (void* p : host)
-    if (p) (void)hipHostFree(p);
-  if (ctx->st2) (void)hipStreamSynchronize(ctx->st2);
   for (int si = 0; si < 2; si++)
     for (int s = 0; s < ORBX_STAGE_COUNT; s++)
       for (int k = 0; k < 2; k++)
@@ -892,6 +978,7 @@ void orbx_destroy(orbx_ctx* ctx) {
   }
   if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
   if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
+  if (ctx->evOrder) (void)hipEventDestroy(ctx->evOrder);
   if (ctx->st2) (void)hipStreamDestroy(ctx->st2);
   if (ctx->ownStream && ctx->st) (void)hipStreamDestroy(ctx->st);
   delete ctx;
@@ -938,7 +1025,13 @@ int orbx_extract_batch(orbx_ctx* ctx, int n_frames, const uint8_t* imgs, int wid
   if (!kps || !desc32 || !n_out || stride < width || n_frames < 1) return ORBX_E_BADARG;
   if (capacity < ctx->selCap) return ORBX_E_CAPACITY;
   if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
-  if (width > ctx->maxW || height > ctx->maxH) { ctx->err = "frame larger than the context's max_width/max_height"; return ORBX_E_BADARG; }
+  if (width > ctx->maxW || height > ctx->maxH) {  // operator() takes any image (cpp:1531-1545): grow before staging the frames
+    Geom gChk;
+    int rg = buildGeometry(ctx, width, height, alignUp(width, 64), &gChk, nullptr);
+    if (rg != ORBX_OK) return rg;
+    rg = growTo(ctx, width, height, ctx->maxB);
+    if (rg != ORBX_OK) return rg;
+  }
   const int dstride = alignUp(width, 64);
   const size_t dfs = (size_t)dstride * height;
   const int cap = std::max(ctx->selCap, 1);
@@ -1011,6 +1104,10 @@ int orbx_level_size(const orbx_ctx* ctx, int level, int* width, int* height) {
 int orbx_download_pyramid(orbx_ctx* ctx, int frame, int level, int border, uint8_t* dst, int dst_stride) {
   if (!ctx || !dst || level < 0 || level >= ctx->p.nlevels || frame < 0 || frame >= ctx->lastB || border < 0) return ORBX_E_BADARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  {  // stream-ordered batches may still be writing the pyramid on either stream
+    const int w = waitAll(ctx);
+    if (w == ORBX_E_HIP) return w;
+  }
   const LevelGeom& L = ctx->g.L[level];
   if (dst_stride < L.w + 2 * border) return ORBX_E_BADARG;
   const uint8_t* src = level == 0 ? ctx->lastImg0 + (long long)frame * ctx->lastFrameStride0
@@ -1175,6 +1272,33 @@ int orbx_wait(orbx_ctx* ctx) {
   if (!ctx) return ORBX_E_BADARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
   return waitAll(ctx);
+}
+
+// Stream ordering against a caller's stream (e.g. torch's current stream): the context works on its own two streams.
+int orbx_order_after(orbx_ctx* ctx, void* stream) {
+  if (!ctx) return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  hipStream_t s = (hipStream_t)stream;
+  if (s == ctx->st) return ORBX_OK;
+  HIPCHK(hipEventRecord(ctx->evOrder, s));
+  HIPCHK(hipStreamWaitEvent(ctx->st, ctx->evOrder, 0));
+  if (ctx->st2) HIPCHK(hipStreamWaitEvent(ctx->st2, ctx->evOrder, 0));
+  return ORBX_OK;
+}
+
+int orbx_order_before(orbx_ctx* ctx, void* stream) {
+  if (!ctx) return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  hipStream_t s = (hipStream_t)stream;
+  if (s != ctx->st) {
+    HIPCHK(hipEventRecord(ctx->evOrder, ctx->st));
+    HIPCHK(hipStreamWaitEvent(s, ctx->evOrder, 0));
+  }
+  if (ctx->st2) {
+    HIPCHK(hipEventRecord(ctx->evOrder, ctx->st2));
+    HIPCHK(hipStreamWaitEvent(s, ctx->evOrder, 0));
+  }
+  return ORBX_OK;
 }
 
 int orbx_match_init(orbx_ctx* ctx, const orbx_keypoint* k1, const uint8_t* d1, int n1, const orbx_keypoint* k2, const uint8_t* d2,
@@ -1412,6 +1536,10 @@ int orbx_profile_get(orbx_ctx* ctx, double* ms, int64_t* launches) {
 int orbx_debug_candidates(orbx_ctx* ctx, int frame, int level, float* xyr, int cap) {
   if (!ctx || frame < 0 || frame >= ctx->lastB || level < 0 || level >= ctx->p.nlevels) return ORBX_E_BADARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  {
+    const int w = waitAll(ctx);
+    if (w == ORBX_E_HIP) return w;
+  }
   const LevelGeom& L = ctx->g.L[level];
   // gather the cells' segments (k_fast writes every cell's survivors into the cell's own segment)
   const int nCells = L.nCols * L.nRows;
@@ -1433,22 +1561,6 @@ int orbx_debug_candidates(orbx_ctx* ctx, int frame, int level, float* xyr, int c
     xyr[3 * i + 2] = (float)(keyed[i] & 0xff);
   }
   return cnt;
-}
-
-int orbx_debug_distribute(const float* xyr, int n, int min_x, int max_x, int min_y, int max_y, int n_features, float* out_xyr,
-                          int cap) {
-  if (n < 0 || (n > 0 && !xyr) || max_x <= min_x || max_y <= min_y) return ORBX_E_BADARG;
-  std::vector<OctCand> c(n);
-  for (int i = 0; i < n; i++) c[i] = OctCand{xyr[3 * i], xyr[3 * i + 1], xyr[3 * i + 2]};
-  std::vector<int> chosen;
-  int r = octree_select(c.data(), n, min_x, max_x, min_y, max_y, n_features, chosen);
-  if (r < 0) return r;
-  for (int i = 0; i < (int)chosen.size() && i < cap; i++) {
-    out_xyr[3 * i] = c[chosen[i]].x;
-    out_xyr[3 * i + 1] = c[chosen[i]].y;
-    out_xyr[3 * i + 2] = c[chosen[i]].response;
-  }
-  return (int)chosen.size();
 }
 
 }  // extern "C"

@@ -1,4 +1,6 @@
-// orbx_octree.cpp — host implementation of the keypoint quadtree selection
+// host_quadtree.cpp — host prototype of the keypoint quadtree selection (TEST INFRASTRUCTURE, built as
+// tests/cpp/libhostquadtree.so by tests/cpp/Makefile; the product's selection stage is the device code in
+// orb_slam_tracking_amd/csrc/orbx_octree_kernel.hip, and liborbx.so contains no CPU path)
 // (reference: ORBextractor::DistributeOctTree, Features/ORBextractor.cpp:698-1011;
 //  ExtractorNode::DivideNode cpp:617-676; compareNodes cpp:684-696).
 //
@@ -14,8 +16,9 @@
 //     single-key leaves of depth k-1, k-2, ... in their own (older) block orders.
 // The last, partial pass ("split the biggest nodes first until N is reached", cpp:897-965) is
 // replayed literally, including the UNSTABLE std::sort on (count, UL.x).
-// The device version of this stage (later rounds) uses the same formulation.
-#include "orbx_internal.h"
+// The device version of this stage uses the same formulation; this file lets CPU-only tests check the formulation
+// against the oracle's literal std::list restatement.
+#include "host_quadtree.h"
 
 #include <algorithm>
 #include <cmath>
@@ -252,3 +255,20 @@ int octree_select(const OctCand* c, int n, int minX, int maxX, int minY, int max
 }
 
 }  // namespace orbx
+
+// C entry point for the CPU tests (ctypes): DistributeOctTree (cpp:698-1011) on caller-supplied candidates.
+extern "C" int hostquadtree_distribute(const float* xyr, int n, int min_x, int max_x, int min_y, int max_y, int n_features,
+                                       float* out_xyr, int cap) {
+  if (n < 0 || (n > 0 && !xyr) || max_x <= min_x || max_y <= min_y) return ORBX_E_BADARG;
+  std::vector<orbx::OctCand> c(n);
+  for (int i = 0; i < n; i++) c[i] = orbx::OctCand{xyr[3 * i], xyr[3 * i + 1], xyr[3 * i + 2]};
+  std::vector<int> chosen;
+  int r = orbx::octree_select(c.data(), n, min_x, max_x, min_y, max_y, n_features, chosen);
+  if (r < 0) return r;
+  for (int i = 0; i < (int)chosen.size() && i < cap; i++) {
+    out_xyr[3 * i] = c[chosen[i]].x;
+    out_xyr[3 * i + 1] = c[chosen[i]].y;
+    out_xyr[3 * i + 2] = c[chosen[i]].response;
+  }
+  return (int)chosen.size();
+}

@@ -1,10 +1,10 @@
-// orbx_internal.h — declarations shared by the host-side translation units of liborbx.
+// host_quadtree.h — the host prototype of the path-code quadtree selection (TEST INFRASTRUCTURE: not part of liborbx.so).
 #pragma once
 #include <cstddef>
 #include <cstdint>
 #include <vector>
 
-#include "../../include/orbx.h"
+#include "../../include/orbx.h"  // error codes only
 
 namespace orbx {
 

@@ -1,0 +1,127 @@
+"""GPU tests of the drop-in boundary's host logic (run with -m gpu): a context that grows with the frames it is given
+(ORBextractor::operator() takes any image, Features/ORBextractor.cpp:1531-1545), synchronous calls behind stream-ordered
+batches, ordering against a caller's stream.  Everything is compared with the CPU oracle bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CANON = (1000, 1.2, 8, 20, 7)
+
+
+def _same(kg, dg, ko, do):
+    assert len(kg) == len(ko), (len(kg), len(ko))
+    assert kg.tobytes() == ko.tobytes()
+    assert np.array_equal(dg, do)
+
+
+def test_context_grows_with_frame_and_batch(orbx, oracle):
+    """One context created for 640x480 / one frame: 640x480, then 3840x2160, then 640x480 again, then a batch of 5 frames
+    through the device API (a drop-in must reallocate, not return ORBX_E_BADARG)."""
+    import torch
+    from orb_slam_tracking_amd import synth
+    e = orbx.ORBextractor(*CANON, max_width=640, max_height=480, max_batch=1)
+    oe = oracle.Extractor(*CANON)
+    small, big = synth.synth(640, 480, 11), synth.synth(3840, 2160, 4)
+    for im in (small, big, small):
+        r, k, d = e(im)
+        ro, ko, do = oe(im)
+        assert r == ro
+        _same(k, d, ko, do)
+        for l in (0, 3, 7):  # mvImagePyramid of the grown context
+            assert np.array_equal(e.image_pyramid(l), oe.level_image(l))
+    B, cap, w, h = 5, 1000, 752, 480
+    frames = synth.synth_frames(B, w, h, 77)
+    d_img = torch.from_numpy(frames).cuda()
+    d_k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+    d_d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    e.extract_batch_device(d_img, B, w, h, w, w * h, d_k, d_d, d_n, cap)
+    n = d_n.cpu().numpy()
+    kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, cap)
+    dd = d_d.cpu().numpy().reshape(B, cap, 32)
+    for f in range(B):
+        _, ko, do = oe(frames[f])
+        assert n[f] == len(ko)
+        _same(kk[f, :n[f]], dd[f, :n[f]], ko, do)
+    # a frame the path cannot take (a level narrower than one FAST cell) is refused before any growth
+    with pytest.raises(orbx.OrbxError) as ex:
+        e(np.zeros((100, 5000), np.uint8))
+    assert ex.value.code == orbx.E_TOOSMALL
+    e.close()
+
+
+def test_sync_host_call_behind_async_batch(orbx, oracle):
+    """a stream-ordered batch is in flight; orbx_extract_batch then copies page-locked host frames into the
+    context's staging buffer on the first stream and extracts a batch of the same size (>= 16 frames: two half-batch
+    streams).  The second stream must wait for that copy."""
+    import torch
+    from orb_slam_tracking_amd import synth
+    B, cap, w, h = 32, 1000, 640, 480
+    e = orbx.ORBextractor(*CANON, max_width=w, max_height=h, max_batch=B)
+    oe = oracle.Extractor(*CANON)
+    dev_np = synth.synth_frames(B, w, h, seed0=900)
+    dev_frames = torch.from_numpy(dev_np).cuda()
+    host_frames = torch.empty((B, h, w), dtype=torch.uint8).pin_memory()
+    first = np.arange(0, B, 2, dtype=np.int32)
+    o = dict(k=torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"), d=torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda"),
+             n=torch.zeros(B, dtype=torch.int32, device="cuda"), m=torch.zeros((B // 2) * cap, dtype=torch.int32, device="cuda"),
+             nm=torch.zeros(B // 2, dtype=torch.int32, device="cuda"))
+    for rep in range(3):
+        frames = synth.synth_frames(B, w, h, seed0=1200 + 40 * rep)
+        # prime the staging buffer with other content, so that a stale read cannot pass by accident
+        e.extract_batch(synth.synth_frames(B, w, h, seed0=5000 + rep))
+        host_frames.numpy()[:] = frames
+        e.extract_match_batch_device_async(dev_frames, B, w, h, w, w * h, o["k"], o["d"], o["n"], first, first + 1, (0, w, 0, h),
+                                           o["m"], o["nm"], None, 100, 0.9, True, cap)
+        res = e.extract_batch(host_frames.numpy())
+        e.wait()
+        for f in (0, 1, B // 2 - 1, B // 2, B // 2 + 1, B - 1):
+            _, ko, do = oe(frames[f])
+            _same(res[f][1], res[f][2], ko, do)
+        # the pyramid reader drains both streams too
+        e.extract_match_batch_device_async(dev_frames, B, w, h, w, w * h, o["k"], o["d"], o["n"], first, first + 1, (0, w, 0, h),
+                                           o["m"], o["nm"], None, 100, 0.9, True, cap)
+        oe(dev_np[B - 1])
+        assert np.array_equal(e.image_pyramid(5, frame=B - 1), oe.level_image(5))
+    e.close()
+
+
+def test_ordering_against_torch_stream(orbx, oracle):
+    """The frames are produced by torch work queued on torch's current stream right before the call: the binding orders the
+    context's private streams behind it (orbx_order_after).  A long torch kernel queue in front makes a missing ordering
+    visible; order_before lets a torch consumer read the results of an _async batch without a host wait."""
+    import torch
+    from orb_slam_tracking_amd import synth
+    B, cap, w, h = 16, 1000, 640, 480
+    e = orbx.ORBextractor(*CANON, max_width=w, max_height=h, max_batch=B)
+    oe = oracle.Extractor(*CANON)
+    frames = synth.synth_frames(B, w, h, seed0=4100)
+    src = torch.from_numpy(frames).cuda()
+    d_img = torch.zeros_like(src)
+    big = torch.zeros(64 << 20, dtype=torch.float32, device="cuda")
+    d_k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+    d_d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    first = np.arange(0, B, 2, dtype=np.int32)
+    d_m = torch.zeros((B // 2) * cap, dtype=torch.int32, device="cuda")
+    d_nm = torch.zeros(B // 2, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(20):
+        big.add_(1.0)  # ~ms of queued work in front of the producer
+    d_img.copy_(src)   # the producer of the frames, on torch's stream
+    e.extract_match_batch_device_async(d_img, B, w, h, w, w * h, d_k, d_d, d_n, first, first + 1, (0, w, 0, h), d_m, d_nm, None,
+                                       100, 0.9, True, cap)
+    e.order_before(torch.cuda.current_stream().cuda_stream)
+    n_copy = d_n.clone()  # torch consumer, no host-side wait in between
+    torch.cuda.synchronize()
+    e.wait()
+    n = d_n.cpu().numpy()
+    assert np.array_equal(n_copy.cpu().numpy(), n)
+    kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, cap)
+    dd = d_d.cpu().numpy().reshape(B, cap, 32)
+    for f in range(B):
+        _, ko, do = oe(frames[f])
+        assert n[f] == len(ko)
+        _same(kk[f, :n[f]], dd[f, :n[f]], ko, do)
+    e.close()

@@ -1,5 +1,6 @@
 """CPU-only checks of the product's host side: the C-ABI library loads and exports every symbol include/orbx.h
-declares, fails loudly without a GPU, and its quadtree stage equals the oracle's DistributeOctTree."""
+declares and fails loudly without a GPU; the path-code formulation the device quadtree uses (host prototype in
+tests/cpp/host_quadtree.cpp, test infrastructure, not part of liborbx.so) equals the oracle's DistributeOctTree."""
 import ctypes
 import os
 import re
@@ -48,6 +49,34 @@ def test_product_does_not_reference_oracle():
         assert "orbo_" not in open(os.path.join(ROOT, "include", fn)).read()
 
 
+_HQ = None
+
+
+def host_distribute(xyr, min_x, max_x, min_y, max_y, n_features):
+    """DistributeOctTree through the host prototype of the device formulation (tests/cpp/libhostquadtree.so)."""
+    global _HQ
+    if _HQ is None:
+        import subprocess
+        d = os.path.join(ROOT, "tests", "cpp")
+        p = subprocess.run(["make", "-C", d], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert p.returncode == 0, p.stdout
+        _HQ = ctypes.CDLL(os.path.join(d, "libhostquadtree.so"))
+        vp, i32 = ctypes.c_void_p, ctypes.c_int
+        _HQ.hostquadtree_distribute.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32]
+    xyr = np.ascontiguousarray(xyr, np.float32).reshape(-1, 3)
+    out = np.zeros((len(xyr) + 8, 3), np.float32)
+    r = _HQ.hostquadtree_distribute(xyr.ctypes.data, len(xyr), min_x, max_x, min_y, max_y, n_features, out.ctypes.data, len(out))
+    assert r >= 0, r
+    return out[:r]
+
+
+def test_liborbx_holds_no_cpu_quadtree(orbx):
+    """The product library is the HIP path only: the host prototype lives under tests/."""
+    L = ctypes.CDLL(orbx.lib_path())
+    assert not hasattr(L, "orbx_debug_distribute") and not hasattr(L, "hostquadtree_distribute")
+    assert not os.path.exists(os.path.join(ROOT, "orb_slam_tracking_amd", "csrc", "orbx_octree.cpp"))
+
+
 def _rand_cands(rng, W, H, n, sort):
     pos = rng.choice(W * H, size=n, replace=False)
     if sort:
@@ -70,7 +99,7 @@ def test_octree_matches_oracle_random(orbx, oracle):
         xyr = _rand_cands(rng, W, H, n, rng.random() < 0.5)
         N = int(rng.integers(0, max(2, 2 * n // 3 + 2)))
         a = oracle.distribute(xyr, 16, 16 + W, 16, 16 + H, N)
-        b = orbx.debug_distribute(xyr, 16, 16 + W, 16, 16 + H, N)
+        b = host_distribute(xyr, 16, 16 + W, 16, 16 + H, N)
         assert a.shape == b.shape and np.array_equal(a, b), (it, W, H, n, N)
         done += 1
     assert done > 400
@@ -92,7 +121,7 @@ def test_octree_level_geometries(orbx, oracle, shape):
         _, uniq = np.unique(xyr[:, 1] * 4096 + xyr[:, 0], return_index=True)
         xyr = xyr[np.sort(uniq)]
         a = oracle.distribute(xyr, 16, 16 + W, 16, 16 + H, N)
-        b = orbx.debug_distribute(xyr, 16, 16 + W, 16, 16 + H, N)
+        b = host_distribute(xyr, 16, 16 + W, 16, 16 + H, N)
         assert np.array_equal(a, b)
 
 
@@ -100,7 +129,7 @@ def test_octree_edge_cases(orbx, oracle):
     for xyr, N in [(np.zeros((0, 3), np.float32), 10), (np.array([[5, 5, 9]], np.float32), 10),
                    (np.array([[5, 5, 9], [6, 5, 9]], np.float32), 1), (np.array([[5, 5, 9], [300, 5, 9]], np.float32), 0)]:
         a = oracle.distribute(xyr, 16, 16 + 600, 16, 16 + 400, N)
-        b = orbx.debug_distribute(xyr, 16, 16 + 600, 16, 16 + 400, N)
+        b = host_distribute(xyr, 16, 16 + 600, 16, 16 + 400, N)
         assert np.array_equal(a, b)
 
 
