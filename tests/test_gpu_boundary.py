@@ -125,3 +125,43 @@ def test_ordering_against_torch_stream(orbx, oracle):
         assert n[f] == len(ko)
         _same(kk[f, :n[f]], dd[f, :n[f]], ko, do)
     e.close()
+
+
+def _fnv(b):
+    h = 1469598103934665603
+    for x in bytes(b):
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_cpp_opencv_shim_reference_frame_unchanged_call_sites(orbx, oracle, tmp_path, images):
+    """The reference-shaped Frame class of tests/cpp/shim_opencv_frame.cpp runs the reference's call sites verbatim through
+    the -DORBX_WITH_OPENCV branch of the shim (operator() with cv:: types; ORBmatcher(0.9, true) without setExtractor --
+    the device context comes from Frame::mpORBextractor); one extractor object takes 3840x2160, then two 752x480 frames,
+    then 3840x2160 again (the context grows).  The quiet flag is on: no stdout line of the reference may appear."""
+    import subprocess
+    from test_host import build_shim_opencv_frame
+    from orb_slam_tracking_amd import synth
+    exe = build_shim_opencv_frame(orbx, str(tmp_path))
+    a, b = images["init0"], images["init1"]
+    big = synth.synth(3840, 2160, 4)
+    pa, pb, pg = tmp_path / "a.raw", tmp_path / "b.raw", tmp_path / "big.raw"
+    pa.write_bytes(a.tobytes()); pb.write_bytes(b.tobytes()); pg.write_bytes(big.tobytes())
+    h, w = a.shape
+    p = subprocess.run([exe, str(w), str(h), str(pa), str(pb), "2000", "20", "7", "3840", "2160", str(pg)], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.strip().splitlines()
+    assert [l.split()[0] for l in lines] == ["GROW", "RESULT", "GROW"], p.stdout  # and nothing else on stdout (quiet flag)
+    oe = oracle.Extractor(2000, 1.2, 8, 20, 7)
+    _, kg, dg = oe(big, cap=4096)
+    lvl1_w = oe.level_size(1)[0]
+    for gl in (lines[0], lines[2]):
+        t = gl.split()
+        assert int(t[1]) == len(kg) and int(t[2]) == _fnv(kg.tobytes()) and int(t[3]) == _fnv(dg.tobytes()) and int(t[4]) == lvl1_w
+    _, ka, da = oe(a, cap=4096)
+    _, kb, db = oe(b, cap=4096)
+    nm, m12, _ = oracle.match_init(ka, da, kb, db, (0, w, 0, h), 100, 0.9, True)
+    t = lines[1].split()
+    assert (int(t[1]), int(t[2]), int(t[3])) == (len(ka), len(kb), nm) and nm > 20
+    assert int(t[4]) == _fnv(ka.tobytes()) and int(t[5]) == _fnv(da.tobytes()) and int(t[6]) == _fnv(m12.astype(np.int32).tobytes())

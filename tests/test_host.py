@@ -154,6 +154,35 @@ def build_shim_demo(orbx, out_dir):
     return exe
 
 
+def build_shim_opencv_frame(orbx, out_dir):
+    """Compiles tests/cpp/shim_opencv_frame.cpp: the -DORBX_WITH_OPENCV branch of the shim (the reference's real cv::
+    signatures) against the compile-check mock of six cv:: types in tests/cpp/mock_opencv (which pins nothing)."""
+    import subprocess
+    exe = os.path.join(out_dir, "shim_opencv_frame")
+    libdir = os.path.dirname(orbx.lib_path())
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-DORBX_WITH_OPENCV", "-I", os.path.join(ROOT, "tests", "cpp", "mock_opencv"),
+           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "shim_opencv_frame.cpp"),
+           "-L", libdir, "-lorbx", "-Wl,-rpath," + libdir, "-o", exe]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout
+    return exe
+
+
+def test_cpp_shim_opencv_branch_compiles(orbx, tmp_path):
+    """The branch that carries the reference's own signatures (cv::InputArray / cv::OutputArray / std::vector<cv::KeyPoint>&,
+    and SearchForInitialization(Frame&, Frame&, ...) with the context taken from Frame::mpORBextractor) is compiled here on
+    every CPU run; the GPU suite runs it (tests/test_gpu_boundary.py)."""
+    exe = build_shim_opencv_frame(orbx, str(tmp_path))
+    assert os.path.exists(exe)
+    if not _has_gpu():
+        import subprocess
+        raw = tmp_path / "z.raw"
+        raw.write_bytes(bytes(640 * 480))
+        p = subprocess.run([exe, "640", "480", str(raw), str(raw), "1000", "20", "7"], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+        assert p.returncode != 0 and "RESULT" not in p.stdout
+
+
 def test_cpp_shim_compiles_and_links(orbx, tmp_path):
     """The C++ drop-in classes (ORB_SLAM_Tracking::ORBextractor / ORBmatcher) build against the C ABI alone."""
     exe = build_shim_demo(orbx, str(tmp_path))
