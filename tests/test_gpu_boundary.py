@@ -46,7 +46,7 @@ def test_context_grows_with_frame_and_batch(orbx, oracle):
         _same(kk[f, :n[f]], dd[f, :n[f]], ko, do)
     # a frame the path cannot take (a level narrower than one FAST cell) is refused before any growth
     with pytest.raises(orbx.OrbxError) as ex:
-        e(np.zeros((100, 5000), np.uint8))
+        e(np.zeros((100, 2000), np.uint8))
     assert ex.value.code == orbx.E_TOOSMALL
     e.close()
 
