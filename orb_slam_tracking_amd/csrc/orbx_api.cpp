@@ -24,7 +24,7 @@ hipError_t launch_resize(hipStream_t st, int nFrames, const uint8_t* src, long l
                          uint8_t* dst, long long dstFrameStride, int dw, int dh, int dstride, const ResizeTab* xtab,
                          const ResizeTab* ytab, int dwordPath);
 hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, int img0Aligned,
-                       const uint8_t* pyr, const Geom& g, uint32_t* cand, int* cellCount);
+                       const uint8_t* pyr, const Geom& g, uint32_t* cand, int* cellCount, const FastCell* cells, int waveOk);
 hipError_t launch_pyramid_bands(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, uint8_t* pyr,
                                 const Geom& g, const ResizeTab* tab, const PyrBands& pb);
 hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const uint8_t* img0, long long img0FrameStride,
@@ -89,6 +89,10 @@ struct orbx_ctx {
   int* dOverflow = nullptr;
   ResizeTab* dTab = nullptr;
   size_t tabEntries = 0;
+  std::vector<FastCell> hCells;  // k_fast_wave's per-cell records of the current geometry (buildFastCells)
+  FastCell* dCells = nullptr;
+  size_t cellEntries = 0;
+  int fastWaveOk = 0;            // k_fast_wave usable for the current geometry: 0 no, 1 tiles of 16 dwords x 64 rows, 2 of 12 dwords
   SelKp* dSel = nullptr;
   int* dNsel = nullptr;
   // quadtree selection stage (device)
@@ -328,6 +332,40 @@ int buildGeometry(orbx_ctx* c, int w, int h, int stride0, Geom* out, std::vector
   return ORBX_OK;
 }
 
+// k_fast_wave's cell records (FastCell): the cell rectangles of ComputeKeyPointsOctTree (cpp:1078-1103) for every level,
+// with everything a wave would otherwise derive from its cell index.  Returns whether every cell fits the kernel's tile.
+// 0 = some cell does not fit (k_fast runs), 1 = tiles of 16 dwords x 64 rows, 2 = every cell image is at most 12 dwords wide.
+int buildFastCells(const Geom& g, std::vector<FastCell>* out) {
+  out->assign((size_t)g.nCellsTotal, FastCell{});
+  bool ok = true, narrow = true;
+  for (int l = 0; l < g.nlevels; l++) {
+    const LevelGeom& L = g.L[l];
+    for (int ci = 0; ci < L.nRows; ci++)
+      for (int cj = 0; cj < L.nCols; cj++) {
+        const int local = ci * L.nCols + cj;
+        FastCell& c = (*out)[(size_t)L.cellBase + local];
+        c.xoff_level = (uint32_t)l << 16;
+        c.stride = (uint32_t)L.stride;
+        c.segOff = (uint32_t)local * (uint32_t)L.segCap;
+        c.segCap = (uint32_t)L.segCap;
+        const int iniY = ORBX_MIN_BORDER + ci * L.hCell, iniX = ORBX_MIN_BORDER + cj * L.wCell;
+        if (iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6) continue;  // cpp:1088, 1101 (rows stay 0)
+        const int maxY = std::min(iniY + L.hCell + 6, L.maxBY), maxX = std::min(iniX + L.wCell + 6, L.maxBX);
+        const int cw = maxX - iniX, ch = maxY - iniY;
+        if (cw < 7 || ch < 7) continue;  // cv::FAST finds nothing in an image this small
+        const int ax0 = iniX & ~3, xoff = iniX - ax0, nw = (maxX - ax0 + 3) >> 2;
+        if (nw > 16 || ch > 64) ok = false;
+        if (nw > 12) narrow = false;
+        c.imgOff = (uint32_t)(iniY * L.stride + ax0);
+        c.nw_ch = (uint32_t)nw | ((uint32_t)ch << 16);
+        c.iw_ih = (uint32_t)(cw - 6) | ((uint32_t)(ch - 6) << 16);
+        c.xoff_level |= (uint32_t)xoff;
+        c.ox_oy = ((uint32_t)(cj * L.wCell - xoff) & 0xffffu) | ((uint32_t)(ci * L.hCell) << 16);
+      }
+  }
+  return ok ? (narrow ? 2 : 1) : 0;
+}
+
 struct Sizes {
   size_t pyrBytes, candEntries, tabEntries;
 };
@@ -379,15 +417,15 @@ size_t buildOctLaunch(const orbx_ctx* c, const Geom& g, OctLaunch* out) {
 // a larger frame or batch (ORBextractor::operator() takes any image, cpp:1531-1545).  Streams, events and the lazily sized
 // matcher / staging buffers are not touched.
 void freeAll(orbx_ctx* ctx) {
-  void* dev[] = {ctx->dPyr, ctx->dCand, ctx->dCandCount, ctx->dCellCount, ctx->dMaxN, ctx->dTab, ctx->dSel, ctx->dNsel, ctx->dSelStage,
-                 ctx->dNselLevel, ctx->dOctScratch, ctx->dIn, ctx->dKps, ctx->dDesc};
+  void* dev[] = {ctx->dPyr, ctx->dCand, ctx->dCandCount, ctx->dCellCount, ctx->dMaxN, ctx->dTab, ctx->dCells, ctx->dSel, ctx->dNsel,
+                 ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, ctx->dIn, ctx->dKps, ctx->dDesc};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   void* host[] = {ctx->hNsel, ctx->hFlags, ctx->hMaxN, ctx->hWide};
   for (void* p : host)
     if (p) (void)hipHostFree(p);
   ctx->dPyr = nullptr; ctx->dCand = nullptr; ctx->dCandCount = nullptr; ctx->dCellCount = nullptr; ctx->dMaxN = nullptr;
-  ctx->dTab = nullptr; ctx->dSel = nullptr; ctx->dNsel = nullptr; ctx->dSelStage = nullptr; ctx->dNselLevel = nullptr;
+  ctx->dTab = nullptr; ctx->dCells = nullptr; ctx->dSel = nullptr; ctx->dNsel = nullptr; ctx->dSelStage = nullptr; ctx->dNselLevel = nullptr;
   ctx->dOctScratch = nullptr; ctx->dIn = nullptr; ctx->dKps = nullptr; ctx->dDesc = nullptr;
   ctx->hNsel = nullptr; ctx->hFlags = nullptr; ctx->hMaxN = nullptr; ctx->hWide = nullptr;
   ctx->hNselDev = nullptr; ctx->hFlagsDev = nullptr; ctx->hMaxNDev = nullptr; ctx->hWideDev = nullptr;
@@ -415,6 +453,13 @@ int allocAll(orbx_ctx* ctx) {
     }
     ctx->candEntries = std::max(s.candEntries, bound) + 1024;
     ctx->cellCountEntries = (size_t)g.nCellsTotal * max_batch + 1024;
+    // cells of one frame over all levels, for every frame size up to the maximum: (wd / 35 + 1) * (ht / 35 + 1) per level
+    size_t cells = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+      const size_t wd = (size_t)(g.L[l].maxBX - ORBX_MIN_BORDER), ht = (size_t)(g.L[l].maxBY - ORBX_MIN_BORDER);
+      cells += (wd / 35 + 1) * (ht / 35 + 1);
+    }
+    ctx->cellEntries = std::max(cells, (size_t)g.nCellsTotal) + 64;
   }
   ctx->tabEntries = s.tabEntries + 64 * ctx->p.nlevels;
   const size_t B = (size_t)max_batch, nl = (size_t)ctx->p.nlevels;
@@ -433,6 +478,7 @@ int allocAll(orbx_ctx* ctx) {
   ALLOC(ctx->dCellCount, ctx->cellCountEntries * sizeof(int));
   ctx->dOverflow = ctx->dCandCount + B * nl;  // (unused tail kept for layout compatibility)
   ALLOC(ctx->dTab, ctx->tabEntries * sizeof(ResizeTab));
+  ALLOC(ctx->dCells, ctx->cellEntries * sizeof(FastCell));
   ALLOC(ctx->dSel, B * cap * sizeof(SelKp));
   ALLOC(ctx->dNsel, B * sizeof(int));
   ALLOC(ctx->dSelStage, B * cap * sizeof(SelKp));
@@ -513,10 +559,17 @@ int ensureGeometry(orbx_ctx* ctx, int w, int h, int stride0) {
     ctx->err = "internal: geometry exceeds the buffers sized at orbx_create";
     return ORBX_E_BADARG;
   }
+  if ((size_t)g.nCellsTotal > ctx->cellEntries) {
+    ctx->err = "internal: geometry exceeds the buffers sized at orbx_create";
+    return ORBX_E_BADARG;
+  }
   ctx->g = g;
   ctx->oct = oct;
   ctx->hTab = tab;
+  ctx->fastWaveOk = buildFastCells(g, &ctx->hCells);
   if (!tab.empty()) HIPCHK(hipMemcpyAsync(ctx->dTab, ctx->hTab.data(), tab.size() * sizeof(ResizeTab), hipMemcpyHostToDevice, ctx->st));
+  if (!ctx->hCells.empty())
+    HIPCHK(hipMemcpyAsync(ctx->dCells, ctx->hCells.data(), ctx->hCells.size() * sizeof(FastCell), hipMemcpyHostToDevice, ctx->st));
   HIPCHK(hipStreamSynchronize(ctx->st));
   ctx->curW = w;
   ctx->curH = h;
@@ -631,7 +684,8 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   }
   {
     StageTimer tm(ctx, ORBX_STAGE_FAST, si, st);
-    HIPCHK(launch_fast(st, n, a.dImg0, a.frameStride0, a.aligned0, ctx->dPyr, g, ctx->dCand, ctx->dCellCount));
+    HIPCHK(launch_fast(st, n, a.dImg0, a.frameStride0, a.aligned0, ctx->dPyr, g, ctx->dCand, ctx->dCellCount, ctx->dCells,
+                       ctx->fastWaveOk));
     tm.stop(1);
   }
   return ORBX_OK;

@@ -43,6 +43,20 @@ struct Geom {
   LevelGeom L[ORBX_MAX_LEVELS];
 };
 
+// k_fast_wave: what one wave needs to know about its FAST cell, precomputed on the host (buildFastCells) so that the kernel's
+// prologue is one scalar load instead of a level search and a dozen divisions / multiplications per wave
+struct FastCell {          // 32 bytes, eight dwords (16-bit fields are packed by hand: scalar loads come in dwords)
+  uint32_t imgOff;         // byte offset, inside the frame's level image, of the first staged dword (row iniY, column iniX & ~3)
+  uint32_t segOff;         // entry offset of the cell's candidate segment inside the frame's level area (local cell * segCap)
+  uint32_t stride;         // row stride of the level image in bytes
+  uint32_t nw_ch;          // staged dwords per row (<= 16) | rows (<= 64) << 16; rows == 0: the cell detects nothing (cpp:1088,1101)
+  uint32_t iw_ih;          // detection area = cell image minus the 3-px FAST border: width | height << 16
+  uint32_t xoff_level;     // iniX & 3 | pyramid level << 16
+  uint32_t ox_oy;          // candidate (x, y) = (tile column + ox, tile row + oy), relative to minBorder: (uint16)ox | oy << 16
+  uint32_t segCap;         // entries of the segment
+};
+static_assert(sizeof(FastCell) == 32, "FastCell is loaded with one s_load_dwordx8");
+
 // candidate entry written by the FAST kernel: x | y<<12 | score<<24, x/y relative to minBorder
 #if defined(__HIPCC__)
 #define ORBX_HD __host__ __device__

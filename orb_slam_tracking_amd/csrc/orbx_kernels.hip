@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 
 #include "../../include/orbx.h"
@@ -453,6 +454,323 @@ __global__ __launch_bounds__(FAST_T) void k_fast(const uint8_t* __restrict__ img
     for (int e = t; e < no; e += FAST_T) dstc[e] = outl[e];
   }
 }
+
+// -------------------------------------------------------------------------------------------------
+// k_fast_wave: the same stage with ONE WAVE PER CELL and no workgroup barrier anywhere.  k_fast above spends a 256-thread
+// workgroup on a cell of ~1400 pixels: five pixels per thread, and around them every wave pays the whole scalar prologue
+// (level search, cell rectangle, 64-bit addresses), six workgroup barriers and the loop control -- 0.83 scalar instructions
+// per vector instruction (r01 counters) -- and its 147,712 workgroups per 256 frames arrive at the dispatcher's limit
+// (~400 workgroups per microsecond chip-wide), which is why nothing done inside that kernel ever moved its 0.34 ms.
+// Here a wave owns the cell:
+//   * prologue = one s_load_dwordx8 of the cell record the host precomputed (FastCell);
+//   * the cell image (<= 64 rows x 16 dwords) is staged with eight dword loads per lane in flight;
+//   * the quick reject works on quads of four horizontally adjacent pixels per lane (dword LDS reads, packed 16-bit
+//     arithmetic); its survivors go through a ring in LDS (ballot + mbcnt compaction, no atomics) and are evaluated 64 at a
+//     time as soon as a full wave of them is waiting, so no list of all pixels is kept;
+//   * corners enter the strength map and a corner list (<= 256; a fuller cell is scanned instead), in-cell NMS runs over
+//     that list, survivors are stored straight into the cell's segment;
+//   * list appends are unconditional stores (a lane with nothing to append writes its own dummy slot): no exec-mask
+//     juggling and no branches in the hot loops;
+//   * workgroup -> cell map is XCD-aware (see the kernel).
+// Same arithmetic and the same outputs (a cell's survivors in another order, which the selection stage does not see).
+// Preconditions (launch_fast): 4-byte aligned level-0 rows, every cell image <= 61 x 64 pixels; otherwise k_fast runs.
+// -------------------------------------------------------------------------------------------------
+#define FW_RING 128   // quick-reject ring, entries (u16 tile offsets): fewer than 64 waiting + at most 64 new ones per append
+#define FW_CORN 256   // corner list, entries
+#define FW_CPW 4      // consecutive cells per wave
+#define FW_XK 4       // groups of FW_CPW cells per run of the XCD-aware order (see the kernel)
+
+__device__ __forceinline__ int fwMbcnt(unsigned long long m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// arc strength of the pixel at p (tile row stride TS): max over the 16 arcs of 9 contiguous ring pixels of the
+// smallest |difference| with one sign, as in k_fast
+template <int TS>
+__device__ __forceinline__ int fwStrength(const uint8_t* p) {
+  constexpr int RS = TS;
+  constexpr int ro[16] = {3 * RS,      3 * RS + 1,  2 * RS + 2,  RS + 3,  3,       -RS + 3,     -2 * RS + 2, -3 * RS + 1,
+                          -3 * RS,     -3 * RS - 1, -2 * RS - 2, -RS - 3, -3,      RS - 3,      2 * RS - 2,  3 * RS - 1};
+  const int v = p[0];
+  int d[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) d[k] = v - (int)p[ro[k]];
+  int mn3[16], mx3[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    mn3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+    mx3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+  }
+  int smn = -256, smx = 256;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    smn = max(smn, min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]));
+    smx = min(smx, max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]));
+  }
+  return max(smn, -smx);
+}
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+// Diagnostic build only (-DORBX_FAST_STAMPS): per wave, s_memtime deltas of k_fast_wave's phases, HW_ID / XCC_ID and start /
+// end in s_memtime and s_memrealtime ticks, stored to a buffer nothing else reads (cdna_hip_programming.md section 7,
+// in-kernel stamps); tools/fast_stamps.py prints phase shares, residency per CU and the chip-wide occupancy timeline.  The
+// production build contains no stamp.
+#ifdef ORBX_FAST_STAMPS
+#define FW_STAMP_WAVES (1 << 18)
+__device__ uint32_t g_fastStamps[FW_STAMP_WAVES * 12];
+#define FW_STAMP(k)                                                                        \
+  do {                                                                                     \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                          \
+    stampAcc_[k] += (uint32_t)(now_ - tPrev_);                                             \
+    tPrev_ = now_;                                                                         \
+  } while (0)
+#define FW_STAMP_INIT()                                                  \
+  unsigned long long tPrev_ = __builtin_amdgcn_s_memtime();              \
+  const uint32_t tStart_ = (uint32_t)tPrev_;                             \
+  const uint32_t rStart_ = (uint32_t)__builtin_amdgcn_s_memrealtime();   \
+  uint32_t stampAcc_[4] = {0u, 0u, 0u, 0u}
+#define FW_STAMP_FLUSH()                                                                                                  \
+  do {                                                                                                                    \
+    const unsigned wid_ = (blockIdx.y * gridDim.x + blockIdx.x) & (FW_STAMP_WAVES - 1);                                   \
+    if (lane == 0) {                                                                                                     \
+      *reinterpret_cast<uint4*>(&g_fastStamps[wid_ * 12]) = make_uint4(stampAcc_[0], stampAcc_[1], stampAcc_[2], stampAcc_[3]); \
+      *reinterpret_cast<uint4*>(&g_fastStamps[wid_ * 12 + 4]) =                                                          \
+          make_uint4(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)),                                        \
+                     __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)), tStart_, (uint32_t)__builtin_amdgcn_s_memtime()); \
+      *reinterpret_cast<uint4*>(&g_fastStamps[wid_ * 12 + 8]) = make_uint4(rStart_, (uint32_t)__builtin_amdgcn_s_memrealtime(), 0u, 0u); \
+    }                                                                                                                    \
+  } while (0)
+#else
+#define FW_STAMP(k) do {} while (0)
+#define FW_STAMP_INIT() do {} while (0)
+#define FW_STAMP_FLUSH() do {} while (0)
+#endif
+
+// TS = bytes per LDS tile row and per strength-map row: 48 when every cell image of the geometry is at most 12 dwords
+// wide (cells of ~36 px: every frame size from VGA up), else 64.
+// One wave = one workgroup works through FW_CPW consecutive cells: single-wave workgroups retire on their own (a 4-wave
+// workgroup holds its LDS until its slowest wave is done), and a few cells per wave keep the number of workgroups far
+// below the dispatcher's rate.
+template <int TS>
+__global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ img0, long long img0FrameStride,
+                                                  const uint8_t* __restrict__ pyr, const Geom g,
+                                                  const FastCell* __restrict__ cells, uint32_t* __restrict__ cand,
+                                                  int* __restrict__ cellCount, const int tileBytes, const int smapBytes) {
+  // tile[tileBytes] | strength map[smapBytes] | ring u16[FW_RING + 64] | corner list u16[FW_CORN + 64]
+  // (the 64 extra entries of the two lists are the per-lane dummy slots)
+  extern __shared__ __attribute__((aligned(16))) uint8_t fwLds[];
+  const int lane = threadIdx.x;
+  uint8_t* const tile = fwLds;
+  uint8_t* const smap = tile + tileBytes;
+  uint16_t* const ring = reinterpret_cast<uint16_t*>(smap + smapBytes);
+  uint16_t* const corn = ring + FW_RING + 64;
+  // XCD-aware group order.  Workgroups go round-robin to the 8 XCDs (the grid's x size is a multiple of 8 * FW_XK), so the
+  // workgroups with equal (blockIdx.x & 7) share an L2.  Each XCD takes every eighth RUN of FW_XK consecutive groups (= 16
+  // cells, about one cell row of the lowest level): horizontally adjacent cells, which overlap by 6 px and share cache lines,
+  // are fetched through one L2 (HBM reads 1.89 -> 0.5 MB per frame), while every XCD still gets cells of all levels -- a
+  // contiguous eighth of the cell list per XCD left the XCD with the small, corner-dense upper levels working twice as long
+  // as the others (measured: tools/fast_stamps.py).  The run -> XCD assignment rotates with the frame.
+  const int nGroups = (g.nCellsTotal + FW_CPW - 1) / FW_CPW;
+  const int xq = (int)((blockIdx.x + blockIdx.y) & 7u), xi = (int)(blockIdx.x >> 3);
+  const int grp = ((xi / FW_XK) * 8 + xq) * FW_XK + (xi % FW_XK);
+  if (grp >= nGroups) return;
+  const int f = blockIdx.y + g.frame0;
+  const int cid0 = grp * FW_CPW, cid1 = min(cid0 + FW_CPW, g.nCellsTotal);
+  FW_STAMP_INIT();
+  for (int cid = cid0; cid < cid1; cid++) {
+  const FastCell c = cells[cid];  // wave-uniform: one s_load_dwordx8
+  int* const myCount = cellCount + (long long)f * g.nCellsTotal + cid;
+  const int nw = (int)(c.nw_ch & 0xffffu), ch = (int)(c.nw_ch >> 16);
+  if (ch == 0) {  // every cell writes its counter (also 0), so the counters need no clearing between batches
+    if (lane == 0) *myCount = 0;
+    continue;
+  }
+  const int level = (int)(c.xoff_level >> 16);
+  const LevelGeom& L = g.L[level];
+  const uint8_t* const base =
+      (level == 0 ? img0 + (long long)f * img0FrameStride : pyr + L.imgOff + (long long)f * L.frameStride) + c.imgOff;
+  // ---- stage the cell image: lane = (row mod 4, dword), eight loads per lane in flight.  Rows and dwords beyond the cell
+  //      are clamped to its last ones (in-bounds duplicates), so nothing is predicated ----
+  {
+    const int rsub = lane >> 4, wcol = min(lane & 15, TS / 4 - 1);
+    const unsigned wsrc = 4u * (unsigned)min(wcol, nw - 1);
+    const int stride = (int)c.stride;
+    uint32_t* const tile32 = reinterpret_cast<uint32_t*>(tile);
+    for (int r0 = 0; r0 < ch; r0 += 32) {
+      uint32_t v[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int r = min(r0 + 4 * j + rsub, ch - 1);
+        v[j] = *reinterpret_cast<const uint32_t*>(base + ((unsigned)(r * stride) + wsrc));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int r = min(r0 + 4 * j + rsub, ch - 1);
+        tile32[r * (TS / 4) + wcol] = v[j];
+      }
+    }
+  }
+  const int iw = (int)(c.iw_ih & 0xffffu), ih = (int)(c.iw_ih >> 16), xoff = (int)(c.xoff_level & 0xffffu);
+  const int ox = (int)(int16_t)(c.ox_oy & 0xffffu), oy = (int)(c.ox_oy >> 16);
+  {  // strength map rows 0 .. ih + 1
+    uint4* const s128 = reinterpret_cast<uint4*>(smap);
+    for (int i = lane; i < (ih + 2) * (TS / 16); i += 64) s128[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order; this only pins the compiler's order)
+#ifdef ORBX_FAST_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);  // charge the staging phase with its loads
+#endif
+  FW_STAMP(0);
+
+  constexpr int RS = TS;
+  // a pixel is carried as its byte offset in the tile: (py + 3) * TS + xoff + px + 3; its strength-map byte is at
+  // (py + 1) * TS + px + 1 = offset - smOff
+  const int smOff = 2 * TS + xoff + 2;
+  // The quick reject works on QUADS of four horizontally adjacent pixels per lane: the quad's rows come from LDS as dwords
+  // (8 reads per 4 pixels instead of 20 byte reads) and the test runs on packed 16-bit pairs.  Item = (quad column, row);
+  // idx += 64  <=>  (qc, qy) += (dqc, dqy) with one wrap at most.
+  const int nqc = (iw + 3) >> 2, nItems = nqc * ih;
+  const uint32_t inv = c_inv20.v[nqc];  // nqc <= 15
+  const int qy0 = (int)(((uint32_t)lane * inv) >> 20), qc0 = lane - qy0 * nqc;
+  const int dqy = (int)((64u * inv) >> 20), dqc = 64 - dqy * nqc;
+  const int sh = (xoff + 3) & 3;                       // byte phase of a quad's first pixel inside its dword (wave-uniform)
+  const int offA0 = (qy0 + 3) * TS + xoff + 3 - sh + 4 * qc0;  // dword-aligned tile offset of the quad's first pixel
+  const int dOffA = dqy * TS + 4 * dqc;
+  // v_perm_b32 selectors (SGPRs): two tap bytes -> the halves of a u16 pair (0x0c = constant 0).  Centre / top / bottom bytes
+  // sh + {0..3} of the dword pair at the quad; left compass bytes sh + 1 + {0..3} of the pair one dword to the left; right
+  // compass bytes sh + 3 + {0..3} of the pair at the quad (sh <= 1) or sh - 1 + {0..3} of the pair one dword to the right
+  const uint32_t selC0 = 0x0c000c00u + (uint32_t)sh * 0x00010001u + 0x00010000u, selC1 = selC0 + 0x00020002u;
+  const uint32_t selL0 = selC0 + 0x00010001u, selL1 = selL0 + 0x00020002u;
+  const bool rNear = sh <= 1;
+  const uint32_t selR0 = 0x0c000c00u + (uint32_t)(rNear ? sh + 3 : sh - 1) * 0x00010001u + 0x00010000u, selR1 = selR0 + 0x00020002u;
+  const int off0 = 3 * TS + xoff + 3;  // a valid pixel offset for idle lanes
+  uint32_t* const dstc = cand + L.candOff + (long long)f * L.candCap + c.segOff;
+  const int segCap = (int)c.segCap;
+  int nOut = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    const int th = pass == 0 ? g.iniTh : g.minTh;
+    const uint32_t th2 = (uint32_t)th * 0x00010001u;
+    int head = 0, nList = 0, nCorn = 0;  // wave-uniform (SGPRs)
+    // evaluates the `cnt` oldest ring entries: exact strength; corners (s > th) enter the strength map and the corner list
+    auto flush = [&](const int cnt) {
+      __builtin_amdgcn_wave_barrier();
+      const bool act = lane < cnt;
+      const int o = act ? (int)ring[(head + lane) & (FW_RING - 1)] : off0;
+      const int sv = fwStrength<TS>(tile + o);
+      const bool corner = act && sv > th;
+      // (a lane without a corner stores into its dummy slot behind the ring: unconditional store, no exec-mask juggling)
+      *(corner ? smap + (o - smOff) : reinterpret_cast<uint8_t*>(ring + FW_RING + lane)) = (uint8_t)sv;
+      const unsigned long long mc = __ballot(corner);
+      const int pos = nCorn + fwMbcnt(mc);
+      corn[(corner && pos < FW_CORN) ? pos : FW_CORN + lane] = (uint16_t)o;
+      nCorn += (int)__popcll(mc);
+      head = (head + cnt) & (FW_RING - 1);
+      nList -= cnt;
+    };
+    // ---- quick reject on the 4 compass pixels (an arc of 9 holds two adjacent ones), survivors into the ring ----
+    {
+      int qc = qc0, offA = offA0;
+      const uint32_t* const t32 = reinterpret_cast<const uint32_t*>(tile);
+      for (int idx0 = 0; idx0 < nItems; idx0 += 64) {
+        const int wA = offA >> 2;  // dword index of the quad's first pixel's dword
+        const uint32_t cM = t32[wA - 1], c0 = t32[wA], c1 = t32[wA + 1], c2 = t32[wA + 2];
+        const uint32_t t0 = t32[wA - 3 * (TS / 4)], t1 = t32[wA - 3 * (TS / 4) + 1];
+        const uint32_t b0 = t32[wA + 3 * (TS / 4)], b1 = t32[wA + 3 * (TS / 4) + 1];
+        const uint32_t rlo = rNear ? c0 : c1, rhi = rNear ? c1 : c2;
+        uint32_t fl[2];
+#pragma unroll
+        for (int hp = 0; hp < 2; hp++) {  // pixels (0, 1) and (2, 3) of the quad as u16 pairs
+          const uint32_t V = __builtin_amdgcn_perm(c1, c0, hp ? selC1 : selC0);
+          const uint32_t QL = __builtin_amdgcn_perm(c0, cM, hp ? selL1 : selL0), QR = __builtin_amdgcn_perm(rhi, rlo, hp ? selR1 : selR0);
+          const uint32_t QT = __builtin_amdgcn_perm(t1, t0, hp ? selC1 : selC0), QB = __builtin_amdgcn_perm(b1, b0, hp ? selC1 : selC0);
+          const ushort2v vV = __builtin_bit_cast(ushort2v, V), vL = __builtin_bit_cast(ushort2v, QL), vR = __builtin_bit_cast(ushort2v, QR),
+                         vT = __builtin_bit_cast(ushort2v, QT), vB = __builtin_bit_cast(ushort2v, QB);
+          // corner needs (max(T, B) > hi and max(L, R) > hi) or (min(T, B) < lo and min(L, R) < lo)
+          const ushort2v mx = __builtin_elementwise_min(__builtin_elementwise_max(vT, vB), __builtin_elementwise_max(vL, vR));
+          const ushort2v mn = __builtin_elementwise_max(__builtin_elementwise_min(vT, vB), __builtin_elementwise_min(vL, vR));
+          const ushort2v hi = vV + __builtin_bit_cast(ushort2v, th2);
+          const short2v e1 = __builtin_bit_cast(short2v, hi) - __builtin_bit_cast(short2v, mx);                      // < 0: mx > hi
+          const short2v e2 = __builtin_bit_cast(short2v, mn) + __builtin_bit_cast(short2v, th2) - __builtin_bit_cast(short2v, vV);  // < 0: mn < lo
+          fl[hp] = (__builtin_bit_cast(uint32_t, e1) | __builtin_bit_cast(uint32_t, e2)) & 0x80008000u;
+        }
+        // the quad's four verdicts as bits 0..3, cleared for pixels beyond the row's end and for idle lanes
+        const int nv = (idx0 + lane < nItems) ? min(iw - 4 * qc, 4) : 0;
+        const uint32_t bits = (((fl[0] >> 15) & 1u) | ((fl[0] >> 30) & 2u) | ((fl[1] >> 13) & 4u) | ((fl[1] >> 28) & 8u)) & ((1u << nv) - 1u);
+        const int offP = offA + sh;  // tile offset of the quad's first pixel
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const bool cj = (bits >> j) & 1u;
+          const unsigned long long m = __ballot(cj);
+          ring[cj ? ((head + nList + fwMbcnt(m)) & (FW_RING - 1)) : FW_RING + lane] = (uint16_t)(offP + j);
+          nList += (int)__popcll(m);
+          if (nList >= 64) flush(64);
+        }
+        qc += dqc;
+        offA += dOffA;
+        if (qc >= nqc) { qc -= nqc; offA += TS - 4 * nqc; }
+      }
+      FW_STAMP(1);
+      if (nList > 0) flush(nList);
+    }
+    __builtin_amdgcn_wave_barrier();
+    FW_STAMP(2);
+    // ---- in-cell NMS on the strength map; survivors are the cell's keypoints ----
+    auto nms = [&](const int oIn, const bool act) {
+      const int o = act ? oIn : off0;
+      const uint8_t* q = smap + (o - smOff);
+      // all nine reads are issued together (short-circuit tests would chain nine LDS round trips)
+      const int sv = q[0];
+      const int n0 = q[-RS - 1], n1 = q[-RS], n2 = q[-RS + 1], n3 = q[-1], n4 = q[1], n5 = q[RS - 1], n6 = q[RS], n7 = q[RS + 1];
+      const int nmax = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+      const bool keep = act && sv > 1 && sv > nmax;
+      const unsigned long long mk = __ballot(keep);
+      if (keep) {
+        const int slot = nOut + fwMbcnt(mk);
+        // tile row = y - oy, tile column = x - ox; o / TS by multiply-shift (exact for o < 2^12)
+        const int row = TS == 64 ? (o >> 6) : (int)(((uint32_t)o * 43691u) >> 21);
+        static_assert(TS == 64 || TS == 48, "row split of a tile offset");
+        if (slot < segCap) dstc[slot] = packCand(o - row * TS + ox, row + oy, sv - 1);
+      }
+      nOut += (int)__popcll(mk);
+    };
+    if (nCorn <= FW_CORN) {
+      for (int e0 = 0; e0 < nCorn; e0 += 64) nms((int)corn[min(e0 + lane, FW_CORN - 1)], e0 + lane < nCorn);
+    } else {  // more corners than the list holds (noise at a low threshold): scan the strength map instead
+      const uint32_t invw = c_inv20.v[iw];
+      const int py0 = (int)(((uint32_t)lane * invw) >> 20), px0 = lane - py0 * iw;
+      const int dpy = (int)((64u * invw) >> 20), dpx = 64 - dpy * iw;
+      int px = px0, off = (py0 + 3) * TS + xoff + px0 + 3;
+      const int npix = iw * ih;
+      for (int idx0 = 0; idx0 < npix; idx0 += 64) {
+        const bool live = idx0 + lane < npix;
+        const int sv = live ? (int)smap[off - smOff] : 0;
+        const unsigned long long any = __ballot(sv > 0);
+        if (any) nms(off, sv > 0);
+        px += dpx;
+        off += dpy * TS + dpx;
+        if (px >= iw) { px -= iw; off += TS - iw; }
+      }
+    }
+    FW_STAMP(3);
+    // cpp:1109-1123: the cell is retried at minThFAST only if it yielded nothing at iniThFAST
+    if (nOut > 0 || pass == 1 || g.minTh >= g.iniTh) break;
+  }
+  if (lane == 0) *myCount = min(nOut, segCap);  // nOut <= segCap: NMS survivors are never 8-neighbours
+  __builtin_amdgcn_wave_barrier();  // the next cell's staging stores come after this cell's last LDS reads
+  }  // cells of this wave
+  FW_STAMP_FLUSH();
+}
+#ifdef ORBX_FAST_STAMPS
+extern "C" int orbx_diag_fast_stamps(uint32_t* out, int nWaves) {  // out: nWaves x 12 dwords; nWaves < 0: clear the buffer
+  if (nWaves < 0) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_fastStamps)) != hipSuccess) return -1;
+    return (int)hipMemset(p, 0, sizeof(uint32_t) * 12 * FW_STAMP_WAVES);
+  }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fastStamps), sizeof(uint32_t) * 12 * (size_t)nWaves);
+}
+#endif
 
 // =================================================================================================
 // K4+K5+K6  orientation + patch-local Gaussian + steered BRIEF per keypoint.
@@ -1861,13 +2179,36 @@ hipError_t launch_pyramid_bands(hipStream_t st, int nFrames, const uint8_t* img0
 }
 
 hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, int img0Aligned,
-                       const uint8_t* pyr, const Geom& g, uint32_t* cand, int* cellCount) {
-  dim3 block(FAST_T, 1, 1), grid(g.nCellsTotal, nFrames, 1);
+                       const uint8_t* pyr, const Geom& g, uint32_t* cand, int* cellCount, const FastCell* cells, int waveOk) {
   int cw = 7, ch = 7;  // largest cell image of this geometry (cell + 6 px overlap, cpp:1094-1103)
   for (int l = 0; l < g.nlevels; l++) {
     cw = std::max(cw, std::min(g.L[l].wCell + 6, ORBX_CELL_MAX));
     ch = std::max(ch, std::min(g.L[l].hCell + 6, ORBX_CELL_MAX));
   }
+  static const bool forceOld = getenv("ORBX_FAST_WG") != nullptr;  // diagnostics: the workgroup-per-cell kernel
+  if (waveOk && img0Aligned && cells && !forceOld) {
+    // one wave per workgroup, FW_CPW cells per wave; x size padded to whole rounds of 8 runs (XCD-aware order)
+    const int groups = ((g.nCellsTotal + FW_CPW - 1) / FW_CPW + 8 * FW_XK - 1) / (8 * FW_XK) * (8 * FW_XK);
+    const int ts = waveOk == 2 ? 48 : 64;  // tile / strength-map row stride: 48 when every cell image is <= 12 dwords wide
+    // (+ 16: the quick reject's dword reads reach a few bytes beyond the last tile row)
+    const int tileBytes = ch * ts + 16, smapBytes = (ch - 6 + 2) * ts;
+    const size_t lds = (size_t)(tileBytes + smapBytes + (FW_RING + 64) * 2 + (FW_CORN + 64) * 2);
+    static const bool dbg = getenv("ORBX_FAST_DEBUG") != nullptr;
+    if (dbg) {
+      int nb48 = -1, nb64 = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb48, k_fast_wave<48>, 64, lds);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb64, k_fast_wave<64>, 64, lds);
+      fprintf(stderr, "k_fast_wave: ts %d lds %zu B, occupancy API: %d / %d workgroups per CU\n", ts, lds, nb48, nb64);
+    }
+    if (ts == 48)
+      hipLaunchKernelGGL(k_fast_wave<48>, dim3(groups, nFrames, 1), dim3(64, 1, 1), lds, st, img0, img0FrameStride, pyr, g, cells,
+                         cand, cellCount, tileBytes, smapBytes);
+    else
+      hipLaunchKernelGGL(k_fast_wave<64>, dim3(groups, nFrames, 1), dim3(64, 1, 1), lds, st, img0, img0FrameStride, pyr, g, cells,
+                         cand, cellCount, tileBytes, smapBytes);
+    return hipGetLastError();
+  }
+  dim3 block(FAST_T, 1, 1), grid(g.nCellsTotal, nFrames, 1);
   FastLds fl;
   fl.tileBytes = (ch * TILE_STRIDE + 15) & ~15;
   fl.smapBytes = (SMAP_STRIDE * (ch - 6 + 2) + 15) & ~15;
