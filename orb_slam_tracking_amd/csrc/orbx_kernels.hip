@@ -477,8 +477,12 @@ __global__ __launch_bounds__(FAST_T) void k_fast(const uint8_t* __restrict__ img
 // -------------------------------------------------------------------------------------------------
 #define FW_RING 128   // quick-reject ring, entries (u16 tile offsets): fewer than 64 waiting + at most 64 new ones per append
 #define FW_CORN 256   // corner list, entries
-#define FW_CPW 4      // consecutive cells per wave
-#define FW_XK 4       // groups of FW_CPW cells per run of the XCD-aware order (see the kernel)
+#ifndef FW_CPW
+#define FW_CPW 1      // consecutive cells per wave (measured per 256 frames: 1: 0.275 ms, 2: 0.288, 4: 0.316, 8: 0.361: the tail grows)
+#endif
+#ifndef FW_XK
+#define FW_XK 16      // groups of FW_CPW cells per run of the XCD-aware order (8 .. 64 measured equal)
+#endif
 
 __device__ __forceinline__ int fwMbcnt(unsigned long long m) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -549,9 +553,8 @@ __device__ uint32_t g_fastStamps[FW_STAMP_WAVES * 12];
 
 // TS = bytes per LDS tile row and per strength-map row: 48 when every cell image of the geometry is at most 12 dwords
 // wide (cells of ~36 px: every frame size from VGA up), else 64.
-// One wave = one workgroup works through FW_CPW consecutive cells: single-wave workgroups retire on their own (a 4-wave
-// workgroup holds its LDS until its slowest wave is done), and a few cells per wave keep the number of workgroups far
-// below the dispatcher's rate.
+// One wave = one workgroup = FW_CPW consecutive cells: single-wave workgroups retire on their own (a 4-wave workgroup holds
+// its LDS until its slowest wave is done).
 template <int TS>
 __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ img0, long long img0FrameStride,
                                                   const uint8_t* __restrict__ pyr, const Geom g,
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
   uint16_t* const ring = reinterpret_cast<uint16_t*>(smap + smapBytes);
   uint16_t* const corn = ring + FW_RING + 64;
   // XCD-aware group order.  Workgroups go round-robin to the 8 XCDs (the grid's x size is a multiple of 8 * FW_XK), so the
-  // workgroups with equal (blockIdx.x & 7) share an L2.  Each XCD takes every eighth RUN of FW_XK consecutive groups (= 16
+  // workgroups with equal (blockIdx.x & 7) share an L2.  Each XCD takes every eighth RUN of FW_XK consecutive groups (16
   // cells, about one cell row of the lowest level): horizontally adjacent cells, which overlap by 6 px and share cache lines,
   // are fetched through one L2 (HBM reads 1.89 -> 0.5 MB per frame), while every XCD still gets cells of all levels -- a
   // contiguous eighth of the cell list per XCD left the XCD with the small, corner-dense upper levels working twice as long

@@ -14,7 +14,7 @@ e = orbx.ORBextractor(1000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=
 k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"); d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
 n = torch.zeros(B, dtype=torch.int32, device="cuda")
 L = orbx.lib()
-nw = 256 * 160
+nw = 256 * 640
 buf = np.zeros((nw, 12), np.uint32)
 for it in range(3):
     if it == 2:

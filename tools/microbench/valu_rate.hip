@@ -1,32 +1,68 @@
-// valu_rate.hip — issue rate of wave64 vector instructions on one SIMD of gfx950, measured (cycles per instruction per SIMD
-// with 1..8 waves per SIMD issuing independent chains).  Decides the denominator of the VALU roofline in bench.py / DESIGN.md.
-// build: hipcc -O3 --offload-arch=gfx950 tools/microbench/valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate
+// valu_rate.hip — issue rate of wave64 vector instructions on one SIMD of gfx950 (MI355X), measured: cycles per instruction
+// per SIMD with n = 1, 2, 4, 8 waves per SIMD, each wave issuing eight independent chains.  The n = 8 column is the
+// throughput that bounds a VALU-bound kernel; it decides the denominator of the VALU roofline in bench.py / DESIGN.md.
+// build + run: hipcc -O3 --offload-arch=gfx950 -Wno-unused-value tools/microbench/valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
 #include <cstdint>
 #include <vector>
 
-#define REP 64  // unrolled instructions per loop iteration and chain
-#define ITERS 2000
+#define REP 64
+#define ITERS 1000
+
+// eight copies of one instruction on eight different destination registers
+#define OP8_2(ins) asm volatile(ins " %0, %0, %8\n" ins " %1, %1, %8\n" ins " %2, %2, %8\n" ins " %3, %3, %8\n" ins " %4, %4, %8\n" ins " %5, %5, %8\n" ins " %6, %6, %8\n" ins " %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k1), "v"(k2))
+#define OP8_3(ins) asm volatile(ins " %0, %0, %8, %9\n" ins " %1, %1, %8, %9\n" ins " %2, %2, %8, %9\n" ins " %3, %3, %8, %9\n" ins " %4, %4, %8, %9\n" ins " %5, %5, %8, %9\n" ins " %6, %6, %8, %9\n" ins " %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k1), "v"(k2))
+#define OP8_1(ins) asm volatile(ins " %0, %0\n" ins " %1, %1\n" ins " %2, %2\n" ins " %3, %3\n" ins " %4, %4\n" ins " %5, %5\n" ins " %6, %6\n" ins " %7, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k1), "v"(k2))
+// compares write an SGPR pair each
+#define OP8_C(ins) asm volatile(ins " s[20:21], %0, %8\n" ins " s[22:23], %1, %8\n" ins " s[24:25], %2, %8\n" ins " s[26:27], %3, %8\n" ins " s[28:29], %4, %8\n" ins " s[30:31], %5, %8\n" ins " s[32:33], %6, %8\n" ins " s[34:35], %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k1), "v"(k2) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35")
+#define OP8_CND() asm volatile("v_cndmask_b32 %0, %0, %8, s[20:21]\n v_cndmask_b32 %1, %1, %8, s[20:21]\n v_cndmask_b32 %2, %2, %8, s[20:21]\n v_cndmask_b32 %3, %3, %8, s[20:21]\n v_cndmask_b32 %4, %4, %8, s[20:21]\n v_cndmask_b32 %5, %5, %8, s[20:21]\n v_cndmask_b32 %6, %6, %8, s[20:21]\n v_cndmask_b32 %7, %7, %8, s[20:21]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k1), "v"(k2) : "s20", "s21")
+#define OP8_MB() asm volatile("v_mbcnt_lo_u32_b32 %0, %8, %0\n v_mbcnt_lo_u32_b32 %1, %8, %1\n v_mbcnt_lo_u32_b32 %2, %8, %2\n v_mbcnt_lo_u32_b32 %3, %8, %3\n v_mbcnt_lo_u32_b32 %4, %8, %4\n v_mbcnt_lo_u32_b32 %5, %8, %5\n v_mbcnt_lo_u32_b32 %6, %8, %6\n v_mbcnt_lo_u32_b32 %7, %8, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k1), "v"(k2))
+#define OP8_SDWA() asm volatile("v_sub_u32_sdwa %0, %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n v_sub_u32_sdwa %1, %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n v_sub_u32_sdwa %2, %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n v_sub_u32_sdwa %3, %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n v_sub_u32_sdwa %4, %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n v_sub_u32_sdwa %5, %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n v_sub_u32_sdwa %6, %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n v_sub_u32_sdwa %7, %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k1), "v"(k2))
 
 template <int OP>
-__global__ __launch_bounds__(1024) void k(uint32_t* out, unsigned long long* cyc, int iters) {
+__global__ __launch_bounds__(256) void k(uint32_t* out, unsigned long long* cyc, int iters) {
+  extern __shared__ uint32_t dummyLds[];
+  if (iters < 0) dummyLds[threadIdx.x] = 1;
   uint32_t a0 = threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 ^ 0x55, a3 = a0 + 7, a4 = a0 * 5, a5 = a0 + 11, a6 = a0 ^ 0x33, a7 = a0 * 7 + 3;
   const uint32_t k1 = out[0], k2 = out[1];
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; it++) {
 #pragma unroll
     for (int r = 0; r < REP / 8; r++) {
-      // 8 independent chains per wave: no dependency stalls at 4+ cycle latencies
-      if (OP == 0) { asm volatile("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k1)); }
-      if (OP == 1) { asm volatile("v_min3_i32 %0, %0, %8, %9\n v_min3_i32 %1, %1, %8, %9\n v_min3_i32 %2, %2, %8, %9\n v_min3_i32 %3, %3, %8, %9\n v_min3_i32 %4, %4, %8, %9\n v_min3_i32 %5, %5, %8, %9\n v_min3_i32 %6, %6, %8, %9\n v_min3_i32 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k1), "v"(k2)); }
-      if (OP == 2) { asm volatile("v_perm_b32 %0, %0, %8, %9\n v_perm_b32 %1, %1, %8, %9\n v_perm_b32 %2, %2, %8, %9\n v_perm_b32 %3, %3, %8, %9\n v_perm_b32 %4, %4, %8, %9\n v_perm_b32 %5, %5, %8, %9\n v_perm_b32 %6, %6, %8, %9\n v_perm_b32 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k1), "v"(k2)); }
-      if (OP == 3) { asm volatile("v_pk_max_u16 %0, %0, %8\n v_pk_max_u16 %1, %1, %8\n v_pk_max_u16 %2, %2, %8\n v_pk_max_u16 %3, %3, %8\n v_pk_max_u16 %4, %4, %8\n v_pk_max_u16 %5, %5, %8\n v_pk_max_u16 %6, %6, %8\n v_pk_max_u16 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k1)); }
-      if (OP == 4) { asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k1), "v"(k2)); }
-      if (OP == 5) { asm volatile("v_dot4_u32_u8 %0, %0, %8, %9\n v_dot4_u32_u8 %1, %1, %8, %9\n v_dot4_u32_u8 %2, %2, %8, %9\n v_dot4_u32_u8 %3, %3, %8, %9\n v_dot4_u32_u8 %4, %4, %8, %9\n v_dot4_u32_u8 %5, %5, %8, %9\n v_dot4_u32_u8 %6, %6, %8, %9\n v_dot4_u32_u8 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k1), "v"(k2)); }
-      if (OP == 6) { asm volatile("v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k1)); }
-      if (OP == 7) { asm volatile("v_pk_fma_f32 %0, %0, %2, %2\n v_pk_fma_f32 %1, %1, %2, %2\n v_pk_fma_f32 %0, %0, %2, %2\n v_pk_fma_f32 %1, %1, %2, %2\n v_pk_fma_f32 %0, %0, %2, %2\n v_pk_fma_f32 %1, %1, %2, %2\n v_pk_fma_f32 %0, %0, %2, %2\n v_pk_fma_f32 %1, %1, %2, %2" : "+v"(*(unsigned long long*)&a0), "+v"(*(unsigned long long*)&a2) : "v"(*(unsigned long long*)&a4)); }
-      if (OP == 8) { asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k1) : "vcc"); }
+      if (OP == 0) OP8_2("v_add_u32");
+      if (OP == 1) OP8_3("v_min3_i32");
+      if (OP == 2) OP8_3("v_perm_b32");
+      if (OP == 3) OP8_2("v_pk_max_u16");
+      if (OP == 4) OP8_3("v_fma_f32");
+      if (OP == 5) OP8_3("v_dot4_u32_u8");
+      if (OP == 6) OP8_2("v_mul_lo_u32");
+      if (OP == 7) OP8_2("v_min_i32");
+      if (OP == 8) OP8_2("v_max_u32");
+      if (OP == 9) OP8_2("v_and_b32");
+      if (OP == 10) OP8_2("v_lshrrev_b32");
+      if (OP == 11) OP8_3("v_bfe_u32");
+      if (OP == 12) OP8_3("v_alignbyte_b32");
+      if (OP == 13) OP8_3("v_lshl_add_u32");
+      if (OP == 14) OP8_3("v_add3_u32");
+      if (OP == 15) OP8_3("v_mad_u32_u24");
+      if (OP == 16) OP8_2("v_mul_u32_u24");
+      if (OP == 17) OP8_C("v_cmp_gt_i32");
+      if (OP == 18) OP8_CND();
+      if (OP == 19) OP8_MB();
+      if (OP == 20) OP8_SDWA();
+      if (OP == 21) OP8_2("v_pk_add_u16");
+      if (OP == 22) OP8_2("v_pk_sub_i16");
+      if (OP == 23) OP8_3("v_dot2_u32_u16");
+      if (OP == 24) OP8_3("v_or3_b32");
+      if (OP == 25) OP8_3("v_sad_u8");
+      if (OP == 26) OP8_3("v_max3_u32");
+      if (OP == 27) OP8_3("v_med3_i32");
+      if (OP == 28) OP8_1("v_mov_b32");
+      if (OP == 29) OP8_1("v_cvt_f32_u32");
+      if (OP == 30) OP8_2("v_sub_u32");
+      if (OP == 31) OP8_2("v_xor_b32");
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -37,35 +73,39 @@ __global__ __launch_bounds__(1024) void k(uint32_t* out, unsigned long long* cyc
 template <int OP>
 void run(const char* name) {
   uint32_t* out; unsigned long long* cyc;
-  hipMalloc(&out, (2 + 1024 * 1024) * 4); hipMemset(out, 0, 64); hipMalloc(&cyc, 8 * 4096);
-  printf("%-16s", name);
-  for (int wavesPerSimd : {1, 2, 4, 8}) {
-    const int threads = 64 * 4 * wavesPerSimd > 1024 ? 1024 : 64 * 4 * wavesPerSimd;  // one workgroup per CU fills every SIMD
-    const int blocksPerCu = (64 * 4 * wavesPerSimd) / threads;
-    const int blocks = 256 * blocksPerCu;
-    k<OP><<<blocks, threads>>>(out, cyc, 10);
+  const int maxBlocks = 256 * 8 * 4;
+  hipMalloc(&out, (2 + (size_t)maxBlocks * 256) * 4); hipMemset(out, 0, 64); hipMalloc(&cyc, (size_t)maxBlocks * 4 * 8);
+  printf("%-18s", name);
+  for (int n : {1, 2, 4, 8}) {  // co-resident 256-thread workgroups per CU = waves per SIMD, enforced through the LDS size
+    const int lds = 160 * 1024 / n - (n == 1 ? 0 : 2048);
+    const int blocks = 256 * n * 4;  // four rounds: most waves run in the steady state
+    hipFuncSetAttribute((const void*)k<OP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    k<OP><<<blocks, 256, lds>>>(out, cyc, 10);
     hipDeviceSynchronize();
-    k<OP><<<blocks, threads>>>(out, cyc, ITERS);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    k<OP><<<blocks, 256, lds>>>(out, cyc, ITERS);
+    hipEventRecord(e1);
     hipDeviceSynchronize();
-    std::vector<unsigned long long> h(blocks * (threads / 64));
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h((size_t)blocks * 4);
     hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
-    double s = 0; for (auto v : h) s += (double)v; s /= h.size();
-    // every wave issued ITERS * REP instructions; a SIMD holds wavesPerSimd of them
-    printf("  %dw/SIMD: %.2f cyc/instr/SIMD", wavesPerSimd, s / ((double)ITERS * REP * wavesPerSimd));
+    std::sort(h.begin(), h.end());
+    const double med = (double)h[h.size() / 2];
+    const double instr = (double)blocks * 4 * ITERS * REP;
+    printf("  n=%d %5.2f cyc (%.2f T/s)", n, med / ((double)ITERS * REP * n), instr / (ms * 1e-3) / 1e12);
   }
   printf("\n");
   hipFree(out); hipFree(cyc);
 }
 
 int main() {
-  run<0>("v_add_u32");
-  run<1>("v_min3_i32");
-  run<2>("v_perm_b32");
-  run<3>("v_pk_max_u16");
-  run<4>("v_fma_f32");
-  run<5>("v_dot4_u32_u8");
-  run<6>("v_mul_lo_u32");
-  run<7>("v_pk_fma_f32");
-  run<8>("v_cndmask_b32");
+  printf("cycles per wave64 instruction per SIMD with n waves per SIMD (chip-wide wave-instructions per second)\n");
+  run<0>("v_add_u32"); run<30>("v_sub_u32"); run<9>("v_and_b32"); run<31>("v_xor_b32"); run<10>("v_lshrrev_b32"); run<7>("v_min_i32"); run<8>("v_max_u32");
+  run<28>("v_mov_b32"); run<29>("v_cvt_f32_u32"); run<16>("v_mul_u32_u24"); run<4>("v_fma_f32");
+  run<17>("v_cmp_gt_i32 (sgpr)"); run<18>("v_cndmask (sgpr)"); run<19>("v_mbcnt_lo"); run<20>("v_sub_u32_sdwa");
+  run<1>("v_min3_i32"); run<26>("v_max3_u32"); run<27>("v_med3_i32"); run<2>("v_perm_b32"); run<11>("v_bfe_u32"); run<12>("v_alignbyte_b32");
+  run<13>("v_lshl_add_u32"); run<14>("v_add3_u32"); run<24>("v_or3_b32"); run<15>("v_mad_u32_u24"); run<25>("v_sad_u8"); run<6>("v_mul_lo_u32");
+  run<3>("v_pk_max_u16"); run<21>("v_pk_add_u16"); run<22>("v_pk_sub_i16"); run<5>("v_dot4_u32_u8"); run<23>("v_dot2_u32_u16");
   return 0;
 }
