@@ -5,10 +5,16 @@ One step = one pass of the hot path over one batch of synthetic 640x480 frames t
   orbx_extract_match_batch_device_async: extraction of B frames -> SearchForInitialization of the B/2 consecutive pairs
   (window 100, ratio 0.9), issued stream-ordered with at most two batches in flight (every batch is complete when the
   clock stops)  ->  (N > 1) RCCL all_gather of the per-frame keypoint counts.
-Frames are sharded per rank (weak scaling: B frames per GPU), one process per GPU.
-Prints ONE JSON line on rank 0 (see the task contract): metric/value/roofline/cpu_baseline.
+Frames are sharded per rank (weak scaling: B frames per GPU), one process per GPU.  The steps rotate through four distinct
+input sets (315 MB per GPU, more than the 256 MB Infinity Cache), so no step finds its input cache-resident.
+Prints ONE JSON line on rank 0 (see the task contract): metric / value / roofline / cpu_baseline.
+
+`value` comes from the first timed region of exactly --steps steps; four more regions of the same length follow and only
+feed `spread` (median / min / max of the five).  The roofline of the dominant kernel is the VALU one:
+these kernels are bound by vector-instruction issue, not by HBM.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -22,6 +28,11 @@ sys.path.insert(0, ROOT)
 PARAMS = (1000, 1.2, 8, 20, 7)  # BASELINE "canonical" preset: 1000 features, 8 levels
 W, H = 640, 480
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+# VALU issue capacity of the chip: 256 CUs x 4 SIMDs x 2.4 GHz SIMD-cycles per second.  A wave64 vector instruction holds
+# its SIMD's issue port for 2 cycles (add / sub / logic / shift / mov / fma) or 4 cycles (min / max / compare / cndmask /
+# cvt / every three-operand integer op / packed 16-bit / dot4 / dot2): tools/microbench/valu_rate.hip, measured on gfx950.
+VALU_PEAK_SIMD_CYCLES = 256 * 4 * 2.4e9
+KERNEL_OF = {"pyramid": "k_pyramid_bands", "fast": "k_fast_wave", "describe": "k_describe_patch"}
 
 
 def level_sizes(w, h, nlevels=8, sf=1.2):
@@ -38,11 +49,23 @@ def algorithmic_bytes(w, h, n_kp):
     P = [a * b for a, b in level_sizes(w, h)]
     sp = sum(P)
     return {
-        "pyramid": (sp - P[-1]) + (sp - P[0]),          # level reads + level writes, 7 launches
+        "pyramid": (sp - P[-1]) + (sp - P[0]),          # level reads + level writes
         "fast": sp,                                      # every level pixel read once
         "describe": 2 * sp + n_kp * (749 + 512) + n_kp * 60,  # blur read+write of the model, disc + samples, outputs
         "total": 5 * sp - P[0] - P[-1] + 1321 * n_kp,
     }
+
+
+def load_pmc():
+    """The committed counter profile of this round (profiles/r*_pmc.json, made by tools/pmc_to_json.py from rocprofv3 --pmc
+    passes of this very command): per kernel and per frame, VALU wave-instructions, VALU issue cycles and HBM bytes."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return None, None
+    try:
+        return json.load(open(files[-1])), os.path.basename(files[-1])
+    except Exception:
+        return None, None
 
 
 def cpu_share():
@@ -60,11 +83,12 @@ def cpu_share():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--regions", type=int, default=5, help="timed regions of --steps steps (the first one gives `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline leg")
+    ap.add_argument("--cpu-reps", type=int, default=30, help="timed repetitions per thread of the CPU baseline (>= 30 by protocol)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 path)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
@@ -99,7 +123,9 @@ def main():
     # this rank's shard of the global batch (frame i -> rank i // B, contiguous blocks; pairs never straddle ranks)
     lo, hi = sharding.shard_range(B * world, world, rank)
     frames = synth.synth_frames(hi - lo, W, H, seed0=1000 + lo // 2)
-    d_img = torch.from_numpy(frames).to(dev)
+    # four input sets: the frames, and their vertical / horizontal / both mirror images (pairs stay pairs of one scene)
+    host_sets = [frames, frames[:, ::-1, :], frames[:, :, ::-1], frames[:, ::-1, ::-1]]
+    d_imgs = [torch.from_numpy(np.ascontiguousarray(s)).to(dev) for s in host_sets]
     # two sets of output arrays: the batches are issued stream-ordered (orbx_extract_match_batch_device_async), batch k + 1
     # is issued while batch k runs, and two batches in flight must not share their outputs
     outs = []
@@ -131,7 +157,8 @@ def main():
     def gather_counts(k):
         finish_gather()
         snap = snaps[k & 1]
-        snap.copy_(outs[k & 1]["n"])  # batch k has been waited for: its counts are final
+        snap.copy_(outs[k & 1]["n"])  # batch k has been waited for: its counts are final.  (The copy runs on torch's stream;
+        # the binding orders the context's streams behind it before the next batch rewrites that array: orbx_order_after.)
         pending[0] = dist.all_gather_into_tensor(counts_all, snap, async_op=True)
 
     def step():
@@ -139,7 +166,7 @@ def main():
         # consecutive pairs, issued behind the previous batch (at most two in flight)
         k = nstep[0]
         o = outs[k & 1]
-        ext.extract_match_batch_device_async(d_img, B, W, H, W, W * H, o["k"], o["d"], o["n"], first, second, (0, W, 0, H),
+        ext.extract_match_batch_device_async(d_imgs[k & 3], B, W, H, W, W * H, o["k"], o["d"], o["n"], first, second, (0, W, 0, H),
                                              o["m"], o["nm"], None, 100, 0.9, True, cap)
         nstep[0] = k + 1
         if world > 1 and ngathered[0] < k:  # batch k - 1 is the oldest in flight: wait for it, gather its counts
@@ -174,17 +201,23 @@ def main():
         dom = max(("pyramid", "fast", "describe"), key=lambda s: stage_prof[s][0])
         ext.profile_stages([dom])  # timed steps: events around the dominant kernel only (each pair costs stream time)
     ext.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+
+    def timed_region():
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    dt = timed_region()                 # the contract's region: exactly --steps steps
     prof = ext.profile_get()
+    region_dts = [dt] + [timed_region() for _ in range(max(args.regions, 1) - 1)]
     ext.profile_enable(False)
     if stage_prof is None:
         stage_prof, stage_steps = prof, args.steps
@@ -195,33 +228,50 @@ def main():
         nm_mean = float(d_nm.float().mean().item())
         ab = algorithmic_bytes(W, H, n_kp)
         # dominant kernel = stage with the largest device time per step (warmup steps, every stage bracketed by events);
-        # its launch duration below is measured over the timed steps
+        # its launch duration below is measured over the first timed region (events on the context's own streams)
         dev_ms = {s: stage_prof[s][0] / stage_steps for s in ("pyramid", "fast", "describe", "match")}
         kern = max(("pyramid", "fast", "describe"), key=lambda s: dev_ms[s])
         launches = max(prof[kern][1], 1)
         avg_launch_ms = prof[kern][0] / launches
-        bytes_per_launch = ab[kern] * B * args.steps / launches
-        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        kname = {"pyramid": "k_pyramid_bands", "fast": "k_fast", "describe": "k_describe_patch"}[kern]
-        # HBM bytes per launch from the committed PMC pass (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json);
-        # null when that profile has no entry for the dominant kernel
-        traffic = None
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["bytes_per_frame"].get(kname)
-            if tr:
-                traffic = (tr["fetch"] + tr["write"]) * B * args.steps / launches
-        except Exception:
-            traffic = None
-        # the other two extraction kernels, from the warmup steps' events (same byte model), for comparison
+        frames_per_launch = B * args.steps / launches
+        kname = KERNEL_OF[kern]
+        pmc, pmc_file = load_pmc()
+        pk = (pmc or {}).get("per_frame", {}).get(kname)
+        secs = avg_launch_ms * 1e-3
+        roof = {"bound": "valu", "kernel": kname, "unit": "T SIMD-issue-cycles/s", "peak": VALU_PEAK_SIMD_CYCLES / 1e12,
+                "avg_launch_ms": avg_launch_ms, "frames_per_launch": frames_per_launch,
+                "formula": "achieved = VALU issue cycles per frame [4 x (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2), %s] x frames per "
+                           "launch / launch duration [HIP events, live]; peak = 256 CUs x 4 SIMDs x 2.4 GHz" % (pmc_file or "no PMC file")}
+        if pk and secs > 0:
+            roof["achieved"] = pk["valu_issue_cycles"] * frames_per_launch / secs / 1e12
+            roof["frac"] = roof["achieved"] / roof["peak"]
+            roof["valu_wave_instr_per_s"] = pk["valu_instr"] * frames_per_launch / secs
+            roof["traffic"] = (pk["fetch_bytes"] + pk["write_bytes"]) * frames_per_launch  # HBM bytes per launch, counters
+        else:
+            roof["achieved"] = roof["frac"] = roof["traffic"] = None
+        # secondary: the HBM view of the same launch (algorithmic bytes of SURVEY 8(d) and counter bytes against 8 TB/s)
+        bytes_per_launch = ab[kern] * frames_per_launch
+        roof["hbm"] = {"algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_GBs": bytes_per_launch / secs / 1e9 if secs > 0 else None,
+                       "algorithmic_frac": bytes_per_launch / secs / 1e9 / HBM_PEAK_GBS if secs > 0 else None,
+                       "counter_GBs": roof["traffic"] / secs / 1e9 if roof.get("traffic") and secs > 0 else None,
+                       "counter_frac": roof["traffic"] / secs / 1e9 / HBM_PEAK_GBS if roof.get("traffic") and secs > 0 else None,
+                       "peak_GBs": HBM_PEAK_GBS,
+                       "whole_path_algorithmic_GBs": ab["total"] * B * world * args.steps / dt / 1e9}
+        # the other extraction kernels, from the warmup steps' events (same formulas), for comparison
         others = {}
         for s2 in ("pyramid", "fast", "describe"):
             if s2 == kern or stage_prof[s2][1] == 0:
                 continue
             l2 = stage_prof[s2][1]
             ms2 = stage_prof[s2][0] / l2
-            gbs = ab[s2] * B * stage_steps / l2 / (ms2 * 1e-3) / 1e9 if ms2 > 0 else 0.0
-            others[{"pyramid": "k_pyramid_bands", "fast": "k_fast", "describe": "k_describe_patch"}[s2]] = {
-                "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": ms2}
+            fpl = B * stage_steps / l2
+            p2 = (pmc or {}).get("per_frame", {}).get(KERNEL_OF[s2])
+            ent = {"avg_launch_ms": ms2, "hbm_algorithmic_frac": ab[s2] * fpl / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS if ms2 > 0 else None}
+            if p2 and ms2 > 0:
+                ent["valu_frac"] = p2["valu_issue_cycles"] * fpl / (ms2 * 1e-3) / VALU_PEAK_SIMD_CYCLES
+                ent["hbm_counter_frac"] = (p2["fetch_bytes"] + p2["write_bytes"]) * fpl / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS
+            others[KERNEL_OF[s2]] = ent
+        rates = sorted(B * world * args.steps / t for t in region_dts)
         out = {
             "metric": "frames/sec (extract+match, 1000 feat, 640x480)",
             "value": B * world * args.steps / dt,
@@ -230,15 +280,14 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "640x480 gray frames, 1000 features, 8 levels, FAST 20/7; %d frames per GPU per step "
-                                   "resident in HBM, %d consecutive-pair SearchForInitialization (window 100, ratio 0.9)"
-                                   % (B, B // 2),
+            "config": {"workload": "640x480 gray frames, 1000 features, 8 levels, FAST 20/7; %d frames per GPU per step resident in "
+                                   "HBM (4 input sets rotating, 315 MB per GPU), %d consecutive-pair SearchForInitialization "
+                                   "(window 100, ratio 0.9)" % (B, B // 2),
                        "frames_per_gpu": B, "pairs_per_gpu": B // 2, "mean_keypoints": n_kp, "mean_nmatches": nm_mean,
                        "parallelism": "frames sharded per GPU (%d ranks), RCCL all_gather of keypoint counts" % world},
-            "roofline": {"bound": "hbm", "kernel": kname,
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "whole_path_GBs": ab["total"] * B * world * args.steps / dt / 1e9},
+            "spread": {"regions": len(region_dts), "steps_per_region": args.steps, "median": rates[len(rates) // 2],
+                       "min": rates[0], "max": rates[-1], "note": "`value` is the first region; the others follow it back to back"},
+            "roofline": roof,
             "roofline_other_kernels": others,
             "stage_ms_per_step": {s: stage_prof[s][0] / stage_steps for s in stage_prof},
             "stage_ms_source": "warmup steps, every stage bracketed by HIP events (sums over the two half-batch streams); the "
@@ -248,15 +297,26 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O
             cores = cpu_share()
-            sample = frames[:8]
-            sec1, fr1, _ = O.bench_pairs(PARAMS, sample, 100, 0.9, 1, 1)  # calibrate: one pass, one core
-            reps = max(1, min(50, int(args.cpu_seconds / max(sec1, 1e-3))))
-            sec, fr, _ = O.bench_pairs(PARAMS, sample, 100, 0.9, cores, reps)
-            out["cpu_baseline"] = {"value": fr / sec, "unit": "frames/s", "cores": cores, "kind": "port",
-                                   "sample": "oracle restatement (scalar C++, -O3, no SIMD): %d threads x %d reps of 8 of the same "
-                                             "640x480 frames (extract A + extract B + match per pair); 1-core rate %.1f frames/s"
-                                             % (cores, reps, fr1 / sec1),
-                                   "one_core_value": fr1 / sec1}
+            sample = frames[:2 * min(cores, 16)] if len(frames) >= 2 * min(cores, 16) else frames
+            reps = max(args.cpu_reps, 30)
+
+            def stats(r):  # r: [threads, reps, 3] seconds
+                tot = r[:, :, 0].ravel() * 1e3
+                return {"ms_per_pair_median": float(np.median(tot)), "p10": float(np.percentile(tot, 10)), "p90": float(np.percentile(tot, 90)),
+                        "extract_only_ms_median": float(np.median(r[:, :, 1]) * 1e3), "match_only_ms_median": float(np.median(r[:, :, 2]) * 1e3),
+                        "frames_per_s": float(r.shape[0] * 2.0 / np.median(r[:, :, 0]))}
+            one = stats(O.bench_protocol(PARAMS, sample, 100, 0.9, 1, 5, reps, False))
+            allc = stats(O.bench_protocol(PARAMS, sample, 100, 0.9, cores, 5, reps, False))
+            try:
+                alln = stats(O.bench_protocol(PARAMS, sample, 100, 0.9, cores, 5, reps, True))
+            except Exception as e:  # no compiler on the host: the generic build stands alone
+                alln = {"error": str(e)[:200]}
+            out["cpu_baseline"] = {"value": allc["frames_per_s"], "unit": "frames/s", "cores": cores, "kind": "port",
+                                   "sample": "oracle restatement (scalar C++, -O3, one frame pair per pinned thread): per thread 5 warm-ups + "
+                                             "%d timed repetitions of extract A + extract B + SearchForInitialization on its own pair of the "
+                                             "same 640x480 frames (SURVEY 8(d) protocol); value = threads x 2 frames / median repetition"
+                                             % reps,
+                                   "all_cores": allc, "one_core": one, "all_cores_march_native": alln}
             out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:

@@ -22,6 +22,10 @@
 #include <cstring>
 #include <list>
 #include <thread>
+#ifdef __linux__
+#include <pthread.h>
+#include <sched.h>
+#endif
 #include <utility>
 #include <vector>
 
@@ -1018,6 +1022,69 @@ double orbo_bench_pairs(int nfeatures, float scaleFactor, int nlevels, int iniTh
   if (frames_out) *frames_out = frames.load();
   if (checksum_out) *checksum_out = checksum.load();
   return sec;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// CPU baseline, measurement protocol of SURVEY.md 8(d): every worker thread is pinned to one core and times, with
+// steady_clock, `reps` repetitions of  extract(frame A) + extract(frame B) + SearchForInitialization(A, B)  on its own
+// pair of frames (pair (tid mod npairs)), after `warmups` untimed repetitions.  All workers run concurrently (the
+// "all host cores" figure); nthreads == 1 is "the repo's CPU path".  times[(tid * reps + r) * 3 + {0, 1, 2}] = seconds of
+// the whole repetition, of the two extractions alone, and of the matching alone.  Returns 0.
+// ---------------------------------------------------------------------------------------------
+int orbo_bench_protocol(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh, const uint8_t* imgs, int nimgs,
+                        int w, int h, int windowSize, float nnratio, int nthreads, int warmups, int reps, double* times) {
+  const int npairs = nimgs / 2;
+  if (npairs < 1 || nthreads < 1 || reps < 1 || !times) return -1;
+  std::atomic<int> ready{0};
+  std::atomic<bool> go{false};
+  auto worker = [&](int tid) {
+#ifdef __linux__
+    {  // pin to the tid-th core this process may use
+      cpu_set_t all, one;
+      CPU_ZERO(&all);
+      if (sched_getaffinity(0, sizeof all, &all) == 0) {
+        int seen = 0, want = tid % std::max(CPU_COUNT(&all), 1);
+        for (int c = 0; c < CPU_SETSIZE; c++)
+          if (CPU_ISSET(c, &all) && seen++ == want) {
+            CPU_ZERO(&one);
+            CPU_SET(c, &one);
+            (void)pthread_setaffinity_np(pthread_self(), sizeof one, &one);
+            break;
+          }
+      }
+    }
+#endif
+    Extractor e(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+    std::vector<KP> ka, kb; std::vector<uint8_t> da, db; std::vector<int> m;
+    Bounds b{0, w, 0, h};
+    const int p = (tid % npairs) * 2;
+    auto once = [&](double* t3) {
+      const auto t0 = std::chrono::steady_clock::now();
+      e.extract(imgs + (size_t)p * w * h, w, h, w, 0, 0, ka, da);
+      e.extract(imgs + (size_t)(p + 1) * w * h, w, h, w, 0, 0, kb, db);
+      const auto t1 = std::chrono::steady_clock::now();
+      m.resize(ka.size() + 1);
+      (void)searchForInitialization(ka.data(), da.data(), (int)ka.size(), kb.data(), db.data(), (int)kb.size(), b, windowSize,
+                                    nnratio, true, m.data(), nullptr);
+      const auto t2 = std::chrono::steady_clock::now();
+      if (t3) {
+        t3[0] = std::chrono::duration<double>(t2 - t0).count();
+        t3[1] = std::chrono::duration<double>(t1 - t0).count();
+        t3[2] = std::chrono::duration<double>(t2 - t1).count();
+      }
+    };
+    for (int r = 0; r < warmups; r++) once(nullptr);
+    ready++;
+    while (!go.load()) std::this_thread::yield();
+    for (int r = 0; r < reps; r++) once(times + ((size_t)tid * reps + r) * 3);
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; t++) th.emplace_back(worker, t);
+  while (ready.load() < nthreads) std::this_thread::yield();
+  go = true;
+  for (auto& t : th) t.join();
+  return 0;
 }
 
 }  // extern "C"

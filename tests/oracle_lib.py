@@ -248,6 +248,32 @@ def bench_pairs(params, imgs: np.ndarray, window=100, nnratio=0.9, nthreads=1, r
     return float(sec), int(frames.value), int(chk.value)
 
 
+def bench_protocol(params, imgs: np.ndarray, window=100, nnratio=0.9, nthreads=1, warmups=5, reps=30, native=False):
+    """CPU baseline by the protocol of SURVEY.md 8(d): pinned worker threads, each timing `reps` repetitions of extract(A) +
+    extract(B) + SearchForInitialization on its own frame pair after `warmups` untimed ones.  Returns an array
+    [nthreads, reps, 3] of seconds (whole repetition, extraction alone, matching alone).  native=True uses the
+    -march=native build of the same restatement."""
+    imgs = np.ascontiguousarray(imgs, np.uint8)
+    n, h, w = imgs.shape
+    L = lib()
+    if native:
+        # -march=native means THIS host's instruction set: always compiled where it runs (the in-tree .so files travel from the
+        # build container to the GPU box, whose host CPU may differ), into a scratch directory
+        import tempfile
+        path = os.path.join(tempfile.mkdtemp(prefix="orbx_oracle_native_"), "liborbx_oracle_native.so")
+        subprocess.run(["g++", "-O3", "-DNDEBUG", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread", "-march=native", "-shared",
+                        "-o", path, os.path.join(ORACLE_DIR, "orbx_oracle.cpp")], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        L = ctypes.CDLL(path)
+    L.orbo_bench_protocol.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_void_p]
+    out = np.zeros((nthreads, reps, 3), np.float64)
+    r = L.orbo_bench_protocol(params[0], params[1], params[2], params[3], params[4], _p(imgs), n, w, h, window, nnratio, nthreads,
+                              warmups, reps, _p(out))
+    assert r == 0
+    return out
+
+
 def std_sort_sized(triples: np.ndarray) -> np.ndarray:
     """libstdc++ std::sort with the reference's compareNodes on (count, UL.x, id) triples (cpp:684-696, 912)."""
     t = np.ascontiguousarray(triples, np.int32).reshape(-1, 3).copy()
