@@ -215,6 +215,19 @@ int orbx_check_fundamental(orbx_ctx* ctx, int n_models, const float* F21, const 
                            const orbx_keypoint* k2, int n2, const int32_t* matches12, float sigma, float* scores,
                            uint8_t* inliers, int* n_matches_out, int* best);
 
+/* Initializer::CheckRT (Initialization/Initializer.cpp:569-713) for `n_models` (R21, t21) hypotheses at once -- ReconstructHF
+ * (:440-567) calls it once per candidate of cv::decomposeEssentialMat / cv::decomposeHomographyMat with the same matches and
+ * inlier flags.  R21: n_models row-major 3x3, t21: n_models x 3, K: row-major 3x3 (all CV_32F upstream); k1 / k2 / matches12 as
+ * above; matches_inliers[i] = vbMatchesInliers[i] for the N pairs of mvMatches12; th2 = the squared reprojection threshold
+ * (4 * sigma^2 upstream).  Outputs per model m: n_good[m] = the return value, tri_good[m * n1 + k] = vbTriGood[k],
+ * p3d[(m * n1 + k) * 3 ..] = vP3D[k] (zeros where the reference books nothing), parallax[m] in degrees.  cv::triangulatePoints
+ * is restated as a DLT with a fixed one-sided Jacobi SVD in f64; the reference's two quirks in this function (booking under
+ * the compacted index, camera-2 depth test on z / z) are kept: see oracle/orbx_oracle.cpp.  Floating point: n_good and
+ * tri_good equal the CPU restatement, points and parallax agree with it to 1e-4 relative (in practice bitwise).  Host pointers. */
+int orbx_check_rt(orbx_ctx* ctx, int n_models, const float* R21, const float* t21, const float* K, const orbx_keypoint* k1, int n1,
+                  const orbx_keypoint* k2, int n2, const int32_t* matches12, const uint8_t* matches_inliers, float th2,
+                  int32_t* n_good, uint8_t* tri_good, float* p3d, float* parallax);
+
 /* ---- measurement hooks (bench.py; HIP events on the ctx stream) ---------------------------- */
 #define ORBX_STAGE_PYRAMID 0
 #define ORBX_STAGE_FAST 1

@@ -229,6 +229,23 @@ class ORBextractor {
     return best;
   }
 
+  // Drop-in for the candidate loop of Initializer::ReconstructHF (Initialization/Initializer.cpp:497-515): every (R, t) of the
+  // decomposition is checked in one call.  R21s: nModels row-major 3x3, t21s: nModels x 3, K: row-major 3x3 (all float);
+  // vbMatchesInliers has one flag per match (the pairs with vnMatches12[i] >= 0, in order).  Per model m: the return value of
+  // CheckRT in nGood[m], vbTriGood in triGood[m * N1 + k], vP3D in p3d[(m * N1 + k) * 3 ..], parallax[m].
+  void CheckRT(int nModels, const float* R21s, const float* t21s, const float* K, const std::vector<KeyPointT>& vKeys1,
+               const std::vector<KeyPointT>& vKeys2, const std::vector<int>& vnMatches12, const std::vector<uint8_t>& vbMatchesInliers,
+               float th2, std::vector<int>& nGood, std::vector<uint8_t>& triGood, std::vector<float>& p3d, std::vector<float>& parallax) {
+    nGood.assign((size_t)nModels, 0);
+    parallax.assign((size_t)nModels, 0.f);
+    triGood.assign((size_t)nModels * vKeys1.size() + 1, 0);
+    p3d.assign((size_t)nModels * vKeys1.size() * 3 + 3, 0.f);
+    const int r = orbx_check_rt(ctx_, nModels, R21s, t21s, K, reinterpret_cast<const orbx_keypoint*>(vKeys1.data()), (int)vKeys1.size(),
+                                reinterpret_cast<const orbx_keypoint*>(vKeys2.data()), (int)vKeys2.size(), vnMatches12.data(),
+                                vbMatchesInliers.data(), th2, nGood.data(), triGood.data(), p3d.data(), parallax.data());
+    if (r != ORBX_OK) throw orbx::Error(r, orbx_last_error(ctx_));
+  }
+
   void UndistortKeyPoints(const std::vector<KeyPointT>& mvKeys, const orbx_camera& cam, std::vector<KeyPointT>& mvKeysUn) {
     mvKeysUn.resize(mvKeys.size());
     const int r = orbx_undistort_keypoints(ctx_, reinterpret_cast<const orbx_keypoint*>(mvKeys.data()), (int)mvKeys.size(), &cam,

@@ -991,6 +991,157 @@ int orbo_match_init(const KP* k1, const uint8_t* d1, int n1, const KP* k2, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// Initializer::CheckRT (Initialization/Initializer.cpp:569-713): triangulate the inlier matches with one (R21, t21)
+// hypothesis and count the points that lie in front of both cameras with a small reprojection error.
+//
+// cv::triangulatePoints and the cv::Mat arithmetic are OpenCV, absent from this tree; restated
+// [from-knowledge], PARITY UNPINNED like every OpenCV primitive here:
+//   * triangulatePoints: per point the 4x4 DLT matrix A (f64), rows x*P(2,:) - P(0,:), y*P(2,:) - P(1,:) for the two
+//     views; the point is the right singular vector of the smallest singular value of A, stored as f32.  OpenCV runs
+//     its one-sided Jacobi SVD; here: the same Hestenes scheme (column pairs in (i, j) order, rotation chosen as OpenCV's
+//     JacobiSVDImpl_ does, at most 30 sweeps, eps = DBL_EPSILON * 10), no library call, so that the device can repeat
+//     it operation for operation.  The singular vector's sign is arbitrary and cancels in x / w.
+//   * gemm on CV_32F accumulates in double and rounds once: P2 = K [R|t], O2 = -R^T t, x3Dc2 = R x + t.
+//   * Mat / scalar = Mat * (1.0 / scalar) with the factor rounded to f32 first; cv::norm and Mat::dot accumulate in
+//     double.
+// Quirks of the reference that are kept (they change which points count):
+//   * the i-th TRIANGULATED point (i counts inliers only) is booked under match i, not under the i-th inlier's match
+//     (vbTriGood[vMatches12[i].first], vP3D[vMatches12[i].first] with the compacted index, :643-704);
+//   * the depth test in camera 2 looks at z / z of the normalised point (:665-670), i.e. it never fires for finite z;
+//     invZ2 is then 1 / (z * (1 / z)).
+// Outputs: vbTriGood[n1], vP3D[n1 * 3] (zeros where nothing was booked), *parallax (degrees); returns nGood.
+// ---------------------------------------------------------------------------------------------
+namespace {
+// right singular vector of the smallest singular value of the 4x4 matrix A (row-major), one-sided Jacobi in f64
+void smallestRightSingularVector4(const double Ain[16], double x[4]) {
+  double At[4][4], V[4][4], W[4];  // At[i] = column i of A (OpenCV works on the transposed matrix), V[i] = row i of V^T
+  for (int i = 0; i < 4; i++)
+    for (int k = 0; k < 4; k++) { At[i][k] = Ain[k * 4 + i]; V[i][k] = i == k ? 1.0 : 0.0; }
+  for (int i = 0; i < 4; i++) { double sd = 0; for (int k = 0; k < 4; k++) sd += At[i][k] * At[i][k]; W[i] = sd; }
+  const double eps = 2.2204460492503131e-16 * 10;
+  for (int iter = 0; iter < 30; iter++) {
+    bool changed = false;
+    for (int i = 0; i < 3; i++)
+      for (int j = i + 1; j < 4; j++) {
+        double a = W[i], p = 0, b = W[j];
+        for (int k = 0; k < 4; k++) p += At[i][k] * At[j][k];
+        if (std::fabs(p) <= eps * std::sqrt(a * b)) continue;
+        p *= 2;
+        const double beta = a - b, gamma = std::sqrt(p * p + beta * beta);
+        double c, sn;
+        if (beta < 0) {
+          const double delta = (gamma - beta) * 0.5;
+          sn = std::sqrt(delta / gamma);
+          c = p / (gamma * sn * 2);
+        } else {
+          c = std::sqrt((gamma + beta) / (gamma * 2));
+          sn = p / (gamma * c * 2);
+        }
+        a = b = 0;
+        for (int k = 0; k < 4; k++) {
+          const double t0 = c * At[i][k] + sn * At[j][k], t1 = -sn * At[i][k] + c * At[j][k];
+          At[i][k] = t0; At[j][k] = t1;
+          a += t0 * t0; b += t1 * t1;
+        }
+        W[i] = a; W[j] = b;
+        changed = true;
+        for (int k = 0; k < 4; k++) {
+          const double t0 = c * V[i][k] + sn * V[j][k], t1 = -sn * V[i][k] + c * V[j][k];
+          V[i][k] = t0; V[j][k] = t1;
+        }
+      }
+    if (!changed) break;
+  }
+  int best = 0;  // smallest squared column norm; the first one among equals
+  for (int i = 1; i < 4; i++)
+    if (W[i] < W[best]) best = i;
+  for (int k = 0; k < 4; k++) x[k] = V[best][k];
+}
+}  // namespace
+
+int orbo_check_rt(const float* R21, const float* t21, const float* K, const KP* k1, int n1, const KP* k2, const int* first,
+                  const int* second, int N, const uint8_t* inliers, float th2, uint8_t* vbTriGood, float* vP3D, float* parallax) {
+  // 1. projection matrices (:577-589)
+  float P1[12] = {K[0], K[1], K[2], 0, K[3], K[4], K[5], 0, K[6], K[7], K[8], 0};
+  float Rt[12], P2[12];
+  for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rt[r * 4 + c] = R21[r * 3 + c]; Rt[r * 4 + 3] = t21[r]; }
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 4; c++) {
+      double sd = 0;
+      for (int k = 0; k < 3; k++) sd += (double)K[r * 3 + k] * (double)Rt[k * 4 + c];
+      P2[r * 4 + c] = (float)sd;
+    }
+  float O2[3];  // -R21^T t21 (:592)
+  for (int r = 0; r < 3; r++) {
+    double sd = 0;
+    for (int k = 0; k < 3; k++) sd += (double)R21[k * 3 + r] * (double)t21[k];
+    O2[r] = (float)(-1.0 * sd);
+  }
+  for (int i = 0; i < n1; i++) { vbTriGood[i] = 0; vP3D[3 * i] = vP3D[3 * i + 1] = vP3D[3 * i + 2] = 0.f; }
+  std::vector<float> vCos;
+  int nGood = 0, ci = 0;  // ci = compacted index (the i of the reference's loop :640)
+  for (int m = 0; m < N; m++) {
+    if (!inliers[m]) continue;
+    const int i = ci++;
+    const float u1 = k1[first[m]].x, v1 = k1[first[m]].y, u2 = k2[second[m]].x, v2 = k2[second[m]].y;
+    // cv::triangulatePoints (:627): DLT in f64, result stored as f32
+    double A[16];
+    for (int k = 0; k < 4; k++) {
+      A[0 * 4 + k] = (double)u1 * (double)P1[2 * 4 + k] - (double)P1[0 * 4 + k];
+      A[1 * 4 + k] = (double)v1 * (double)P1[2 * 4 + k] - (double)P1[1 * 4 + k];
+      A[2 * 4 + k] = (double)u2 * (double)P2[2 * 4 + k] - (double)P2[0 * 4 + k];
+      A[3 * 4 + k] = (double)v2 * (double)P2[2 * 4 + k] - (double)P2[1 * 4 + k];
+    }
+    double xd[4];
+    smallestRightSingularVector4(A, xd);
+    const float X[4] = {(float)xd[0], (float)xd[1], (float)xd[2], (float)xd[3]};
+    const int book = first[i];  // quirk: match i, not match m
+    const float invW = (float)(1.0 / (double)X[3]);
+    const float xn[3] = {X[0] * invW, X[1] * invW, X[2] * invW};
+    if (!std::isfinite(X[0]) || !std::isfinite(X[1]) || !std::isfinite(X[2])) { vbTriGood[book] = 0; continue; }
+    if (X[0] == 0 && X[1] == 0 && X[2] == 0) { vbTriGood[book] = 0; continue; }
+    // 3.1 parallax (:659-667)
+    const float oc2[3] = {xn[0] - O2[0], xn[1] - O2[1], xn[2] - O2[2]};
+    const float dist1 = (float)std::sqrt((double)xn[0] * xn[0] + (double)xn[1] * xn[1] + (double)xn[2] * xn[2]);
+    const float dist2 = (float)std::sqrt((double)oc2[0] * oc2[0] + (double)oc2[1] * oc2[1] + (double)oc2[2] * oc2[2]);
+    const double dot = (double)xn[0] * oc2[0] + (double)xn[1] * oc2[1] + (double)xn[2] * oc2[2];
+    const float cosParallax = (float)(dot / (double)(dist1 * dist2));
+    // 3.2 the point in camera 2 (:671-672)
+    float xc2[3];
+    for (int r = 0; r < 3; r++) {
+      double sd = 0;
+      for (int k = 0; k < 3; k++) sd += (double)R21[r * 3 + k] * (double)xn[k];
+      xc2[r] = (float)(1.0 * sd + 1.0 * (double)t21[r]);
+    }
+    const float invZc2 = (float)(1.0 / (double)xc2[2]);
+    const float xc2n[3] = {xc2[0] * invZc2, xc2[1] * invZc2, xc2[2] * invZc2};
+    if (xn[2] <= 0 && (double)cosParallax < 0.99998) continue;
+    if (xc2n[2] <= 0 && (double)cosParallax < 0.99998) continue;
+    // 3.3 reprojection errors (:682-695)
+    const float invZ1 = (float)(1.0 / (double)xn[2]);
+    const float im1x = K[0] * xn[0] * invZ1 + K[2], im1y = K[4] * xn[1] * invZ1 + K[5];
+    const float e1 = (im1x - u1) * (im1x - u1) + (im1y - v1) * (im1y - v1);
+    const float invZ2 = (float)(1.0 / (double)xc2n[2]);
+    const float im2x = K[0] * xc2n[0] * invZ2 + K[2], im2y = K[4] * xc2n[1] * invZ2 + K[5];
+    const float e2 = (im2x - u2) * (im2x - u2) + (im2y - v2) * (im2y - v2);
+    if (e1 > th2 || e2 > th2) continue;
+    // 3.4 (:698-704)
+    vCos.push_back(cosParallax);
+    vP3D[3 * book] = xn[0]; vP3D[3 * book + 1] = xn[1]; vP3D[3 * book + 2] = xn[2];
+    nGood++;
+    if ((double)cosParallax < 0.99998) vbTriGood[book] = 1;
+  }
+  if (nGood > 0) {  // :708-712
+    std::sort(vCos.begin(), vCos.end());
+    const size_t idx = (size_t)std::min(50, (int)vCos.size() - 1);
+    *parallax = (float)(std::acos((double)vCos[idx]) * 180 / 3.14159265358979323846);
+  } else {
+    *parallax = 0;
+  }
+  return nGood;
+}
+
+// ---------------------------------------------------------------------------------------------
 // CPU baseline: extract(A) + extract(B) + SearchForInitialization(A,B) per pair.
 // `nthreads` independent workers each loop over the same pairs for `reps` repetitions; returns
 // wall seconds, frames processed in *frames_out.

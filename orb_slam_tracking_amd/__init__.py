@@ -107,6 +107,7 @@ def lib() -> ctypes.CDLL:
     L.orbx_to_gray_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, sz, i32, i32, vp, i32, sz]
     L.orbx_check_homography.argtypes = [vp, i32, vp, vp, vp, i32, vp, i32, vp, f32, vp, vp, vp, vp]
     L.orbx_check_fundamental.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, f32, vp, vp, vp, vp]
+    L.orbx_check_rt.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, f32, vp, vp, vp, vp]
     L.orbx_profile_enable.argtypes = [vp, i32]
     L.orbx_profile_reset.argtypes = [vp]
     L.orbx_profile_get.argtypes = [vp, vp, vp]
@@ -404,6 +405,27 @@ class ORBextractor:
     def check_fundamental(self, F21, keys1, keys2, matches12, sigma: float = 1.0):
         """CheckFundamental for a stack of hypotheses -> (scores, vbMatchesInliers per model, index the RANSAC loop keeps)."""
         return self._check_models(1, F21, None, keys1, keys2, matches12, sigma)
+
+    def check_rt(self, R21, t21, K, keys1, keys2, matches12, matches_inliers, th2: float = 4.0):
+        """Initializer::CheckRT (Initializer.cpp:569-713) for a stack of (R21, t21) hypotheses ->
+        (nGood[m], vbTriGood[m, n1], vP3D[m, n1, 3], parallax[m])."""
+        R21 = np.ascontiguousarray(R21, np.float32).reshape(-1, 3, 3)
+        t21 = np.ascontiguousarray(t21, np.float32).reshape(-1, 3)
+        K = np.ascontiguousarray(K, np.float32).reshape(3, 3)
+        k1 = np.ascontiguousarray(keys1, KEYPOINT_DTYPE)
+        k2 = np.ascontiguousarray(keys2, KEYPOINT_DTYPE)
+        m12 = np.ascontiguousarray(matches12, np.int32)
+        inl = np.ascontiguousarray(matches_inliers, np.uint8)
+        nm = len(R21)
+        if len(t21) != nm or len(m12) != len(k1) or len(inl) != int((m12 >= 0).sum()):
+            raise OrbxError(E_BADARG, "check_rt: one t21 per R21, one matches12 entry per keypoint of frame 1, one inlier flag per match")
+        ngood = np.zeros(max(nm, 1), np.int32)
+        par = np.zeros(max(nm, 1), np.float32)
+        good = np.zeros((max(nm, 1), max(len(k1), 1)), np.uint8)
+        p3d = np.zeros((max(nm, 1), max(len(k1), 1), 3), np.float32)
+        self._check(self._L.orbx_check_rt(self._h, nm, _ptr(R21), _ptr(t21), _ptr(K), _ptr(k1), len(k1), _ptr(k2), len(k2), _ptr(m12),
+                                          _ptr(inl), float(th2), _ptr(ngood), _ptr(good), _ptr(p3d), _ptr(par)), "orbx_check_rt")
+        return ngood[:nm], good[:nm, :len(k1)].astype(bool), p3d[:nm, :len(k1)], par[:nm]
 
     # -- mvImagePyramid (hpp:111) ----------------------------------------------------------------
     def level_size(self, level: int) -> Tuple[int, int]:

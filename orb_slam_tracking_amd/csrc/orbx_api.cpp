@@ -42,6 +42,7 @@ size_t octScratchBytes(int nMax, int qMax);
 hipError_t launch_to_gray(hipStream_t st, int nFrames, const uint8_t* src, long long srcFrameStride, int sstride, int w, int h,
                           int channels, int rgb, uint8_t* dst, long long dstFrameStride, int dstride);
 hipError_t launch_check_model(hipStream_t st, int nModels, const ScoreArgs& a);
+hipError_t launch_check_rt(hipStream_t st, int nModels, const CheckRtArgs& a);
 hipError_t launch_debug_sincos(hipStream_t st, const float* angle, int n, float* c, float* s);
 hipError_t launch_undistort(hipStream_t st, int nFrames, const orbx_keypoint* in, const int* nkp, int capacity, const CamD& c,
                             orbx_keypoint* out);
@@ -403,6 +404,10 @@ size_t buildOctLaunch(const orbx_ctx* c, const Geom& g, OctLaunch* out) {
     P.candCap[l] = L.candCap;
     P.selOff[l] = selOff;
     selOff += L.quota;
+    // Per-unit scratch: the device side (octreeGlobalUnit) derives its layout from the same two numbers through the same
+    // formula, so stride and layout cannot drift apart: nMax = the level's worst-case candidate count (cells x segCap bound,
+    // capped at what the sort keys can index), qMax = max(quota, nIni).  A unit with more candidates than nMax is refused on
+    // the device (n > nMax -> -1) before anything is written.
     P.scrNMax[l] = std::min(L.candMax, ORBX_OCT_MAX_CAND);
     P.scrStride[l] = (int64_t)octScratchBytes(P.scrNMax[l], std::max(L.quota, O.nIni));  // = octreeGlobalUnit's qMax
     P.scrOff[l] = scr;
@@ -554,7 +559,11 @@ int ensureGeometry(orbx_ctx* ctx, int w, int h, int stride0) {
   Sizes s = sizesOf(ctx, g, tab.size());
   OctLaunch oct;
   const size_t octBytes = buildOctLaunch(ctx, g, &oct);
-  if (s.pyrBytes > ctx->pyrBytes || s.candEntries > ctx->candEntries || s.tabEntries > ctx->tabEntries ||
+  // every buffer sized at allocAll must hold this geometry's layout end (level offsets are computed for maxB frames)
+  bool selFits = true;
+  for (int l = 0; l < g.nlevels; l++)
+    selFits = selFits && oct.selOff[l] + g.L[l].quota <= g.selCap && oct.scrOff[l] + oct.scrStride[l] * ctx->maxB <= (int64_t)octBytes;
+  if (!selFits || s.pyrBytes > ctx->pyrBytes || s.candEntries > ctx->candEntries || s.tabEntries > ctx->tabEntries ||
       octBytes > ctx->octScratchBytes || (size_t)g.nCellsTotal * ctx->maxB > ctx->cellCountEntries) {
     ctx->err = "internal: geometry exceeds the buffers sized at orbx_create";
     return ORBX_E_BADARG;
@@ -1197,7 +1206,10 @@ int ensureMatchScratch(orbx_ctx* ctx, int nPairs, int capacity) {
     const int w = waitAll(ctx);  // the buffers about to be replaced are in use
     if (w != ORBX_OK) return w;
   }
-  // per pair: see matchScratchStride (orbx_device.h)
+  // per pair: matchScratchStride(capacity) ints (orbx_device.h) -- the one function both this allocation and launch_match's
+  // stride argument use; the kernels index a pair's area with [pair * stride, (pair + 1) * stride) and clamp their own
+  // counts to the capacities the layout was computed from (queries / trains to matchWideCap(capacity), list entries per
+  // query to MW_CP, per-frame counts to `capacity`)
   const size_t need = (size_t)nPairs * (size_t)matchScratchStride(capacity);
   if (need > ctx->matchScratchInts) {
     if (ctx->dMatchScratch) (void)hipFree(ctx->dMatchScratch);
@@ -1518,6 +1530,76 @@ int orbx_check_fundamental(orbx_ctx* ctx, int n_models, const float* F21, const 
                            int n2, const int32_t* matches12, float sigma, float* scores, uint8_t* inliers, int* n_matches_out,
                            int* best) {
   return checkModels(ctx, 1, n_models, F21, nullptr, k1, n1, k2, n2, matches12, sigma, scores, inliers, n_matches_out, best);
+}
+
+// ---- Initializer::CheckRT (Initialization/Initializer.cpp:569-713) -------------------------------------
+int orbx_check_rt(orbx_ctx* ctx, int n_models, const float* R21, const float* t21, const float* K, const orbx_keypoint* k1, int n1,
+                  const orbx_keypoint* k2, int n2, const int32_t* matches12, const uint8_t* matches_inliers, float th2, int32_t* n_good,
+                  uint8_t* tri_good, float* p3d, float* parallax) {
+  if (!ctx || n_models < 0 || n1 < 0 || n2 < 0 || !K || (n_models > 0 && (!R21 || !t21 || !n_good || !parallax)) ||
+      (n1 > 0 && (!k1 || !matches12)) || (n2 > 0 && !k2) || (n_models > 0 && n1 > 0 && (!tri_good || !p3d)))
+    return ORBX_E_BADARG;
+  if (n_models == 0) return ORBX_OK;
+  // mvMatches12 (Initializer.cpp:24-33), then the inliers in match order (:617-622); the i-th of them is booked under the
+  // i-th MATCH's first keypoint (:643, :700: the reference indexes vMatches12 with the compacted index)
+  std::vector<int32_t> fs, sc;
+  for (int i = 0; i < n1; i++)
+    if (matches12[i] >= 0) {
+      if (matches12[i] >= n2) return ORBX_E_BADARG;
+      fs.push_back(i);
+      sc.push_back(matches12[i]);
+    }
+  const int N = (int)fs.size();
+  if (N > 0 && !matches_inliers) return ORBX_E_BADARG;
+  std::vector<float> pts;
+  std::vector<int32_t> book;
+  for (int m = 0; m < N; m++)
+    if (matches_inliers[m]) {
+      const int i = (int)book.size();
+      book.push_back(fs[i]);
+      pts.push_back(k1[fs[m]].x); pts.push_back(k1[fs[m]].y); pts.push_back(k2[sc[m]].x); pts.push_back(k2[sc[m]].y);
+    }
+  const int nInl = (int)book.size();
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t bR = (size_t)n_models * 9 * 4, bT = (size_t)n_models * 3 * 4, bP = (size_t)nInl * 16, bB = (size_t)nInl * 4,
+               bG = (size_t)n_models * n1, bX = (size_t)n_models * n1 * 12, bC = (size_t)n_models * nInl * 4, bN = (size_t)n_models * 4;
+  const size_t need = al(bR) + al(bT) + al(bP) + al(bB) + al(bG) + al(bX) + al(bC) + 2 * al(bN) + 256;
+  if (need > ctx->scoreBytes) {
+    if (ctx->dScore) (void)hipFree(ctx->dScore);
+    ctx->dScore = nullptr; ctx->scoreBytes = 0;
+    HIPCHK(hipMalloc((void**)&ctx->dScore, need));
+    ctx->scoreBytes = need;
+  }
+  uint8_t* p = ctx->dScore;
+  CheckRtArgs a{};
+  hipStream_t st = ctx->st;
+  a.R21 = (const float*)p; p += al(bR);
+  a.t21 = (const float*)p; p += al(bT);
+  a.pts = (const float*)p; p += al(bP);
+  a.book = (const int32_t*)p; p += al(bB);
+  a.good = p; p += al(bG);
+  a.p3d = (float*)p; p += al(bX);
+  a.cosBuf = (float*)p; p += al(bC);
+  a.nGood = (int32_t*)p; p += al(bN);
+  a.parallax = (float*)p;
+  for (int i = 0; i < 9; i++) a.K[i] = K[i];
+  a.th2 = th2; a.nInl = nInl; a.n1 = n1;
+  HIPCHK(hipMemcpyAsync((void*)a.R21, R21, bR, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync((void*)a.t21, t21, bT, hipMemcpyHostToDevice, st));
+  if (nInl) {
+    HIPCHK(hipMemcpyAsync((void*)a.pts, pts.data(), bP, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync((void*)a.book, book.data(), bB, hipMemcpyHostToDevice, st));
+  }
+  HIPCHK(launch_check_rt(st, n_models, a));
+  HIPCHK(hipMemcpyAsync(n_good, a.nGood, bN, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(parallax, a.parallax, bN, hipMemcpyDeviceToHost, st));
+  if (n1) {
+    HIPCHK(hipMemcpyAsync(tri_good, a.good, bG, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(p3d, a.p3d, bX, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  return ORBX_OK;
 }
 
 // ---- Converter::toGray (Utils/Converter.cpp:5-19) ------------------------------------------------

@@ -123,6 +123,23 @@ struct ScoreArgs {
   uint8_t* inliers;   // [nModels][N]
 };
 
+// k_check_rt: CheckRT (Initializer.cpp:569-713) over nModels (R21, t21) hypotheses
+struct CheckRtArgs {
+  const float* R21;      // [nModels][9]
+  const float* t21;      // [nModels][3]
+  const float* pts;      // [nInl][4] (u1, v1, u2, v2) of the inlier matches, in match order
+  const int32_t* book;   // [nInl] keypoint of frame 1 the i-th triangulated point is booked under (the reference's quirk)
+  float K[9];
+  float th2;
+  int32_t nInl, n1;
+  uint8_t* good;         // [nModels][n1]
+  float* p3d;            // [nModels][n1][3]
+  float* cosBuf;         // [nModels][nInl] scratch: cosines of the counted points
+  int32_t* nGood;        // [nModels]
+  float* parallax;       // [nModels]
+};
+
+
 // camera of cv::undistortPoints in the doubles OpenCV converts mK / mDistCoef (CV_32F, Settings.hpp:32,39) to
 struct CamD {
   double fx, fy, cx, cy, ifx, ify;  // ifx = 1./fx, ify = 1./fy

@@ -138,6 +138,9 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
 // global-scratch variant, 1024 threads, for the (frame, level) units the LDS variant left (nselLevel == -2), or for all
 // units when `all` is set.  Scratch of unit (f, level) starts at scrOff[level] + f * scrStride[level]; layout:
 // octScratchBytes().
+static_assert(OCT_SORT_LDS * 2 >= OCT_PAR_SCR_FOR(OCT_PAR_MAX), "the sort exchange buffer doubles as the parallel-replay scratch of the global-scratch units");
+static_assert(OCT_SORT_LDS * 2 >= 256 * (1024 / 64), "... and as the 256 x nWaves digit counters of the radix sort (1024-thread instance)");
+static_assert(OCT_SORT_LDS >= 1024, "the register sort of the 1024-thread instance exchanges 1024 padded keys through it");
 __global__ __launch_bounds__(1024) void k_octree_global(const uint32_t* __restrict__ cand, const int* __restrict__ cellCount,
                                                        const OctLaunch P, SelKp* __restrict__ selStage,
                                                        int* __restrict__ nselLevel, uint8_t* __restrict__ scratch, int all) {

@@ -13,7 +13,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-SO = os.path.join(ORACLE_DIR, "liborbx_oracle.so")
+SO = os.environ.get("ORBX_ORACLE_SO") or os.path.join(ORACLE_DIR, "liborbx_oracle.so")  # (the sanitizer test points this at the ASan build)
 
 KP = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"),
                ("class_id", "<i4")])
@@ -23,6 +23,8 @@ _L = None
 
 def build(force: bool = False) -> str:
     src = os.path.join(ORACLE_DIR, "orbx_oracle.cpp")
+    if os.environ.get("ORBX_ORACLE_SO"):
+        return SO
     if force or not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(src):
         subprocess.run(["make", "-C", ORACLE_DIR], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     return SO
@@ -355,6 +357,58 @@ def check_fundamental(F21, k1, k2, matches12, sigma=1.0):
     L.orbo_check_fundamental.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
     sc = L.orbo_check_fundamental(_p(F21), _p(k1), _p(k2), _p(first), _p(second), len(first), sigma, _p(inl))
     return np.float32(sc), inl[:len(first)].astype(bool)
+
+
+def check_rt(R21, t21, K, k1, k2, matches12, inliers, th2=4.0):
+    """Oracle of Initializer::CheckRT (Initializer.cpp:569-713) -> (nGood, vbTriGood[n1], vP3D[n1, 3], parallax)."""
+    k1, k2 = np.ascontiguousarray(k1, KP), np.ascontiguousarray(k2, KP)
+    first, second = _pairs(matches12)
+    R21 = np.ascontiguousarray(R21, np.float32).reshape(9)
+    t21 = np.ascontiguousarray(t21, np.float32).reshape(3)
+    K = np.ascontiguousarray(K, np.float32).reshape(9)
+    inl = np.ascontiguousarray(inliers, np.uint8)
+    assert len(inl) == len(first)
+    good = np.zeros(max(len(k1), 1), np.uint8)
+    p3d = np.zeros((max(len(k1), 1), 3), np.float32)
+    par = ctypes.c_float(0)
+    L = lib()
+    L.orbo_check_rt.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_float,
+                                                                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    n = L.orbo_check_rt(_p(R21), _p(t21), _p(K), _p(k1), len(k1), _p(k2), _p(first), _p(second), len(first), _p(inl), th2, _p(good), _p(p3d),
+                        ctypes.byref(par))
+    return int(n), good[:len(k1)].astype(bool), p3d[:len(k1)], np.float32(par.value)
+
+
+def two_view_case(seed=0, n=500, outliers=0.2, noise=0.5):
+    """Synthetic two-view geometry for CheckRT: 3-D points in front of camera 1, camera 2 = (R, t), pixel noise, a share of
+    wrong matches, matches12 with holes.  Returns K, R, t (float64 truth), k1, k2, matches12 and the four (R, t) candidates
+    an essential-matrix decomposition yields (the true one first)."""
+    rng = np.random.default_rng(seed)
+    K = np.array([[609.2855, 0, 351.4274], [0, 609.3422, 237.7324], [0, 0, 1.0]])
+    ang = np.deg2rad(rng.uniform(2, 8, 3)) * rng.choice([-1, 1], 3)
+    cx, sx, cy, sy, cz, sz = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1]), np.cos(ang[2]), np.sin(ang[2])
+    R = (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+         @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+    t = rng.normal(0, 1, 3); t /= np.linalg.norm(t)
+    X = np.stack([rng.uniform(-4, 4, n), rng.uniform(-3, 3, n), rng.uniform(4, 20, n)], 1)
+    p1 = (K @ X.T).T; p1 = p1[:, :2] / p1[:, 2:]
+    X2 = (R @ X.T).T + t
+    p2 = (K @ X2.T).T; p2 = p2[:, :2] / p2[:, 2:]
+    k1, k2 = np.zeros(n, KP), np.zeros(n + 20, KP)
+    k1["x"], k1["y"] = (p1[:, 0] + rng.normal(0, noise, n)).astype(np.float32), (p1[:, 1] + rng.normal(0, noise, n)).astype(np.float32)
+    perm = rng.permutation(n + 20)
+    k2["x"][perm[:n]] = (p2[:, 0] + rng.normal(0, noise, n)).astype(np.float32)
+    k2["y"][perm[:n]] = (p2[:, 1] + rng.normal(0, noise, n)).astype(np.float32)
+    k2["x"][perm[n:]], k2["y"][perm[n:]] = rng.uniform(0, 640, 20).astype(np.float32), rng.uniform(0, 480, 20).astype(np.float32)
+    m12 = perm[:n].astype(np.int32)
+    wrong = rng.random(n) < outliers
+    m12[wrong] = rng.integers(0, n + 20, wrong.sum())
+    m12[rng.random(n) < 0.1] = -1  # unmatched keypoints
+    # the twisted-pair candidates of decomposeEssentialMat: (R, t), (R, -t), (R', t), (R', -t), R' = R rotated by pi about t
+    tx = t / np.linalg.norm(t)
+    Rpi = 2 * np.outer(tx, tx) - np.eye(3)
+    cands = [(R, t), (R, -t), (Rpi @ R, t), (Rpi @ R, -t)]
+    return K, R, t, k1, k2, m12, cands
 
 
 def scoring_case(seed=0, n=400, n_models=24):

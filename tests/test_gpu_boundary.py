@@ -165,3 +165,23 @@ def test_cpp_opencv_shim_reference_frame_unchanged_call_sites(orbx, oracle, tmp_
     t = lines[1].split()
     assert (int(t[1]), int(t[2]), int(t[3])) == (len(ka), len(kb), nm) and nm > 20
     assert int(t[4]) == _fnv(ka.tobytes()) and int(t[5]) == _fnv(da.tobytes()) and int(t[6]) == _fnv(m12.astype(np.int32).tobytes())
+
+
+def test_regression_r01_fault_tiny_units_on_global_scratch(orbx, oracle):
+    """Round-1 fault (gpurun_out repro.log .. repro5.log: `oracle 300` / `oracle 10` -> memory access
+    fault): a (frame, level) unit with a handful of candidates on the global-scratch selection kernel.  The register bitonic
+    sort works on max(pow2ceil(n), workgroup size) padded keys, so the unit's key / node arrays must be allocated for at
+    least the workgroup size however small n is (octScratchBytes pads both to >= 1024 entries).  Every candidate count
+    around the padding steps, every selection kernel variant, quotas below and above the count."""
+    e = orbx.ORBextractor(*CANON, max_width=640, max_height=480, max_batch=1)
+    rng = np.random.default_rng(77)
+    W, H = 608, 448
+    for n in (1, 2, 3, 10, 15, 16, 17, 63, 64, 65, 255, 256, 257, 300, 434, 1023, 1024, 1025, 2047, 2048, 2049):
+        pos = np.sort(rng.choice(W * H, size=n, replace=False))
+        xyr = np.stack([pos % W, pos // W, rng.integers(1, 200, n)], 1).astype(np.float32)
+        for N in (1, 10, 217, 300, 434):
+            exp = oracle.distribute(xyr, 16, 16 + W, 16, 16 + H, N)[:N]
+            for variant in (1, 0, 2):
+                got = e.debug_distribute_device(xyr, 16, 16 + W, 16, 16 + H, N, variant)
+                assert got.shape == exp.shape and np.array_equal(got, exp), (n, N, variant)
+    e.close()

@@ -880,3 +880,34 @@ def test_sincos_matches_libm(orbx, ext640, oracle):
     ec, es = oracle.sincos_deg_batch(a)
     bad = np.nonzero((c != ec) | (s != es))[0]
     assert len(bad) == 0, (len(bad), a[bad[:5]], c[bad[:5]], ec[bad[:5]], s[bad[:5]], es[bad[:5]])
+
+
+def test_check_rt(orbx, ext640, oracle):
+    """Initializer::CheckRT (Initializer.cpp:569-713) on the device for the four (R, t) candidates of a decomposition at once,
+    against the CPU restatement: nGood and vbTriGood equal; vP3D and the parallax within 1e-4 relative (floating point:
+    both run the same fixed Jacobi SVD in uncontracted f64, so they normally agree bitwise -- counted, not required)."""
+    exact = total = 0
+    for seed in range(5):
+        K, R, t, k1, k2, m12, cands = oracle.two_view_case(100 + seed, n=200 + 150 * seed, outliers=0.25, noise=0.6)
+        first = np.nonzero(m12 >= 0)[0]
+        rng = np.random.default_rng(seed)
+        inl = (rng.random(len(first)) < 0.8).astype(np.uint8)
+        Rs = np.stack([c[0] for c in cands]).astype(np.float32)
+        ts = np.stack([c[1] for c in cands]).astype(np.float32)
+        ng, good, p3d, par = ext640.check_rt(Rs, ts, K, k1, k2, m12, inl, 4.0)
+        for m in range(len(cands)):
+            on, ogood, op3d, opar = oracle.check_rt(Rs[m], ts[m], K, k1, k2, m12, inl, 4.0)
+            assert ng[m] == on and np.array_equal(good[m], ogood), (seed, m, ng[m], on)
+            assert np.allclose(p3d[m], op3d, rtol=1e-4, atol=1e-6) and abs(float(par[m]) - float(opar)) <= 1e-4 * max(1.0, float(opar))
+            exact += int(p3d[m].tobytes() == op3d.tobytes() and par[m].tobytes() == np.float32(opar).tobytes())
+            total += 1
+    assert exact >= total - 2, (exact, total)  # bitwise equality is the rule
+    # edge cases: no hypothesis, no inlier, no match
+    K, R, t, k1, k2, m12, cands = oracle.two_view_case(7, n=120)
+    first = np.nonzero(m12 >= 0)[0]
+    ng, good, p3d, par = ext640.check_rt(np.zeros((0, 3, 3), np.float32), np.zeros((0, 3), np.float32), K, k1, k2, m12, np.ones(len(first), np.uint8))
+    assert len(ng) == 0
+    ng, good, p3d, par = ext640.check_rt(R, t, K, k1, k2, m12, np.zeros(len(first), np.uint8))
+    assert ng[0] == 0 and not good.any() and not p3d.any() and par[0] == 0
+    ng, good, p3d, par = ext640.check_rt(R, t, K, k1, k2, np.full(len(k1), -1, np.int32), np.zeros(0, np.uint8))
+    assert ng[0] == 0 and par[0] == 0

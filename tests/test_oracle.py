@@ -332,3 +332,74 @@ def test_initializer_scoring_loops(oracle):
     assert 0.6 < inl.mean() < 0.95 and len(inl) == len(first)  # ~20 % of the pairs are gross outliers
     sc0, inl0 = oracle.check_homography(H21[0], H12[0], k1, k2, np.full(len(k1), -1, np.int32), 1.0)
     assert sc0 == 0 and len(inl0) == 0
+
+
+def _check_rt_np(R, t, K, k1, k2, first, second, inliers, th2):
+    """Independent float64 evaluation of CheckRT's geometry with numpy's LAPACK SVD: which inlier matches triangulate in front
+    of camera 1 with a small reprojection error in both views (cosine < 0.99998), booked like the reference books them."""
+    P1 = np.hstack([K, np.zeros((3, 1))])
+    P2 = K @ np.hstack([R, t.reshape(3, 1)])
+    O2 = -R.T @ t
+    sel = np.nonzero(inliers)[0]
+    good, pts, cos_all = {}, {}, []
+    for i, m in enumerate(sel):
+        u1, v1, u2, v2 = float(k1["x"][first[m]]), float(k1["y"][first[m]]), float(k2["x"][second[m]]), float(k2["y"][second[m]])
+        A = np.stack([u1 * P1[2] - P1[0], v1 * P1[2] - P1[1], u2 * P2[2] - P2[0], v2 * P2[2] - P2[1]])
+        X = np.linalg.svd(A)[2][3]
+        x = X[:3] / X[3]
+        oc2 = x - O2
+        cosp = x @ oc2 / (np.linalg.norm(x) * np.linalg.norm(oc2))
+        xc2 = R @ x + t
+        if x[2] <= 0 and cosp < 0.99998:
+            continue
+        p1 = K @ x; p1 = p1[:2] / p1[2]
+        p2 = K @ xc2; p2 = p2[:2] / p2[2]
+        e1, e2 = (p1[0] - u1) ** 2 + (p1[1] - v1) ** 2, (p2[0] - u2) ** 2 + (p2[1] - v2) ** 2
+        if e1 > th2 or e2 > th2:
+            continue
+        cos_all.append(cosp)
+        pts[first[i]] = x
+        good[first[i]] = cosp < 0.99998
+    return good, pts, sorted(cos_all)
+
+
+def test_check_rt(oracle):
+    """Initializer::CheckRT (Initializer.cpp:569-713): the restatement (fixed one-sided Jacobi SVD for the DLT, OpenCV's
+    float / double mixing) against a float64 LAPACK evaluation of the same geometry.  Tolerances: the restatement rounds the
+    homogeneous point and most intermediate results to float32 like the reference (relative 2e-4 on points, 5e-3 degrees on
+    the parallax); decisions may only differ for points within 1e-3 of a threshold (none in these cases)."""
+    for seed in range(4):
+        K, R, t, k1, k2, m12, cands = oracle.two_view_case(seed, n=300 + 50 * seed)
+        first = np.nonzero(m12 >= 0)[0].astype(np.int32)
+        second = m12[first]
+        rng = np.random.default_rng(seed)
+        inliers = (rng.random(len(first)) < 0.85).astype(np.uint8)
+        for (Rc, tc) in cands:
+            R32, t32, K32 = Rc.astype(np.float32), tc.astype(np.float32), K.astype(np.float32)
+            n, good, p3d, par = oracle.check_rt(R32, t32, K32, k1, k2, m12, inliers, 4.0)
+            g, pts, cosv = _check_rt_np(R32.astype(np.float64), t32.astype(np.float64), K32.astype(np.float64), k1, k2, first, second,
+                                        inliers, 4.0)
+            assert n == len(cosv)
+            assert set(np.nonzero(good)[0].tolist()) == {k for k, v in g.items() if v}
+            for k, x in pts.items():
+                # (a point near infinity -- cosine >= 0.99998, not flagged good -- divides by a float32 w close to 0: looser)
+                assert np.allclose(p3d[k], x, rtol=2e-4 if g[k] else 5e-2, atol=1e-5), (k, p3d[k], x)
+            booked = set(pts)
+            assert all(not p3d[k].any() for k in range(len(k1)) if k not in booked)  # zeros where nothing was booked
+            if n:
+                exp = np.degrees(np.arccos(cosv[min(50, n - 1)]))
+                assert abs(float(par) - exp) < 5e-3 + 1e-4 * exp, (par, exp)
+            else:
+                assert par == 0
+    # the true pose reconstructs most inliers, a wrong translation sign none (camera-1 depth test)
+    K, R, t, k1, k2, m12, cands = oracle.two_view_case(9)
+    first = np.nonzero(m12 >= 0)[0]
+    ones = np.ones(len(first), np.uint8)
+    n_true = oracle.check_rt(cands[0][0], cands[0][1], K, k1, k2, m12, ones)[0]
+    n_neg = oracle.check_rt(cands[1][0], cands[1][1], K, k1, k2, m12, ones)[0]
+    assert n_true > 0.6 * len(first) and n_neg == 0
+    # degenerate inputs: no matches, no inliers
+    n, good, p3d, par = oracle.check_rt(R, t, K, k1, k2, np.full(len(k1), -1, np.int32), np.zeros(0, np.uint8))
+    assert n == 0 and not good.any() and par == 0
+    n, good, p3d, par = oracle.check_rt(R, t, K, k1, k2, m12, np.zeros(len(first), np.uint8))
+    assert n == 0 and not good.any() and not p3d.any() and par == 0
