@@ -72,6 +72,22 @@ typedef struct orbx_ctx orbx_ctx;
 int orbx_create(const orbx_params* params, int device_id, int max_width, int max_height, int max_batch,
                 void* stream, orbx_ctx** out);
 void orbx_destroy(orbx_ctx* ctx);
+
+/* The two constants of the path that depend on the OpenCV release the reference is linked against (its CMakeLists.txt:13 pins
+ * none), selectable per context so that the library can be diffed against any OpenCV-linked build without touching a kernel:
+ *   gaussian_variant  Q8 taps of cv::GaussianBlur(7x7, sigma 2) on 8-bit images (ORBextractor.cpp:1601):
+ *     ORBX_GAUSS_ERROR_DIFFUSION (default)  [18,34,48,56,48,34,18], sum 256: getGaussianKernelFixedPoint_ED, OpenCV >= 4.1.1 / 3.4.7
+ *     ORBX_GAUSS_ROUNDED                    [18,34,49,55,49,34,18], sum 257: each tap rounded, the bit-exact path of OpenCV
+ *                                           3.4.1 .. 3.4.6 / 4.0 .. 4.1.0 and the integer filter of older releases
+ *   gray_variant      cv::cvtColor RGB/BGR -> gray on 8-bit (Converter.cpp:11-13):
+ *     ORBX_GRAY_14BIT (default)             (R*4899 + G*9617 + B*1868 + 2^13) >> 14: OpenCV 3.x .. 4.0
+ *     ORBX_GRAY_15BIT                       (R*9798 + G*19235 + B*3735 + 2^14) >> 15: OpenCV >= 4.1
+ * Takes effect for the calls that follow (batches in flight are waited for). */
+#define ORBX_GAUSS_ERROR_DIFFUSION 0
+#define ORBX_GAUSS_ROUNDED 1
+#define ORBX_GRAY_14BIT 0
+#define ORBX_GRAY_15BIT 1
+int orbx_set_opencv_variant(orbx_ctx* ctx, int gaussian_variant, int gray_variant);
 const char* orbx_last_error(const orbx_ctx* ctx);
 
 /* ---- getters (Features/ORBextractor.hpp:87-108) ------------------------------------------- */

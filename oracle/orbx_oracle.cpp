@@ -120,7 +120,13 @@ inline int reflect101(int p, int n) {
 // fixed-point path: Q8 taps from the error-diffusion rule => [18,34,48,56,48,34,18] (sum 256);
 // horizontal sum kept in Q8 (u16), vertical in Q16, round to nearest.  Call site: cpp:1598-1606.
 // ---------------------------------------------------------------------------------------------
-const int kGauss[7] = {18, 34, 48, 56, 48, 34, 18};
+// Both version-dependent constants of the path are selectable (orbo_set_opencv_variant, mirrored by the product's
+// orbx_set_opencv_variant): the Gaussian Q8 taps below and the BGR2GRAY coefficients of toGray.
+//   variant 0: error diffusion, sum 256 (getGaussianKernelFixedPoint_ED, OpenCV >= 4.1.1 / 3.4.7)  [from-knowledge]
+//   variant 1: every tap rounded, sum 257 (bit-exact path of 3.4.1 .. 4.1.0, integer filter before) [from-knowledge]
+const int kGaussTab[2][7] = {{18, 34, 48, 56, 48, 34, 18}, {18, 34, 49, 55, 49, 34, 18}};
+int gGaussVariant = 0, gGrayVariant = 0;
+#define kGauss (kGaussTab[gGaussVariant])
 
 void gaussian7(const uint8_t* src, int w, int h, int stride, uint8_t* dst, int dstride) {
   std::vector<uint16_t> tmp((size_t)w * h);
@@ -865,11 +871,13 @@ int orbo_to_gray(const uint8_t* src, int w, int h, int stride, int channels, int
     return 1;
   }
   if (channels != 3) return 0;
-  const int c0 = rgb ? 4899 : 1868, c1 = 9617, c2 = rgb ? 1868 : 4899;
+  // variant 0: 14-bit coefficients (OpenCV 3.x .. 4.0); variant 1: 15-bit (OpenCV >= 4.1)  [from-knowledge]
+  const int cr = gGrayVariant ? 9798 : 4899, cg = gGrayVariant ? 19235 : 9617, cb = gGrayVariant ? 3735 : 1868, sh = gGrayVariant ? 15 : 14;
+  const int c0 = rgb ? cr : cb, c1 = cg, c2 = rgb ? cb : cr;
   for (int y = 0; y < h; y++) {
     const uint8_t* s = src + (size_t)y * stride;
     uint8_t* d = dst + (size_t)y * dstride;
-    for (int x = 0; x < w; x++) d[x] = (uint8_t)((s[3 * x] * c0 + s[3 * x + 1] * c1 + s[3 * x + 2] * c2 + (1 << 13)) >> 14);
+    for (int x = 0; x < w; x++) d[x] = (uint8_t)((s[3 * x] * c0 + s[3 * x + 1] * c1 + s[3 * x + 2] * c2 + (1 << (sh - 1))) >> sh);
   }
   return 1;
 }
@@ -1236,6 +1244,11 @@ int orbo_bench_protocol(int nfeatures, float scaleFactor, int nlevels, int iniTh
   go = true;
   for (auto& t : th) t.join();
   return 0;
+}
+
+void orbo_set_opencv_variant(int gaussian_variant, int gray_variant) {
+  gGaussVariant = gaussian_variant ? 1 : 0;
+  gGrayVariant = gray_variant ? 1 : 0;
 }
 
 }  // extern "C"

@@ -95,6 +95,7 @@ def lib() -> ctypes.CDLL:
                                                   ctypes.POINTER(_Bounds), i32, f32, i32, vp, vp, vp]
     L.orbx_extract_match_batch_device_async.argtypes = [vp, i32, vp, i32, i32, i32, sz, vp, vp, i32, vp, i32, vp, vp,
                                                   ctypes.POINTER(_Bounds), i32, f32, i32, vp, vp, vp]
+    L.orbx_set_opencv_variant.argtypes = [vp, i32, i32]
     L.orbx_wait_one.argtypes = [vp]
     L.orbx_wait.argtypes = [vp]
     L.orbx_order_after.argtypes = [vp, vp]
@@ -173,6 +174,12 @@ class ORBextractor:
             self.close()
         except Exception:
             pass
+
+    GAUSS_ERROR_DIFFUSION, GAUSS_ROUNDED, GRAY_14BIT, GRAY_15BIT = 0, 1, 0, 1
+
+    def set_opencv_variant(self, gaussian_variant: int = 0, gray_variant: int = 0) -> None:
+        """The two OpenCV-release dependent constants of the path (include/orbx.h): Gaussian Q8 taps, BGR2GRAY coefficients."""
+        self._check(self._L.orbx_set_opencv_variant(self._h, int(gaussian_variant), int(gray_variant)), "orbx_set_opencv_variant")
 
     def order_after(self, stream: Optional[int]) -> None:
         """Work issued on this context from now on starts after everything queued on `stream` (hipStream_t handle)."""

@@ -29,7 +29,7 @@ hipError_t launch_pyramid_bands(hipStream_t st, int nFrames, const uint8_t* img0
                                 const Geom& g, const ResizeTab* tab, const PyrBands& pb);
 hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const uint8_t* img0, long long img0FrameStride,
                                  int img0Aligned, const uint8_t* pyr, const Geom& g, const SelKp* sel, const int* nsel,
-                                 orbx_keypoint* kps, uint8_t* desc, int capacity);
+                                 orbx_keypoint* kps, uint8_t* desc, int capacity, int gaussVariant);
 hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int* dSecond, const orbx_keypoint* kps,
                         const uint8_t* desc, const int* nkp, int capacity, orbx_bounds b, int window, float nnratio, int checkOri,
                         int* matches12, int* nmatches, int* stats, int* scratch, int pair0, int wideMode, int* hostWide);
@@ -40,7 +40,7 @@ hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage
                               int* hostMaxN);
 size_t octScratchBytes(int nMax, int qMax);
 hipError_t launch_to_gray(hipStream_t st, int nFrames, const uint8_t* src, long long srcFrameStride, int sstride, int w, int h,
-                          int channels, int rgb, uint8_t* dst, long long dstFrameStride, int dstride);
+                          int channels, int rgb, uint8_t* dst, long long dstFrameStride, int dstride, int grayVariant);
 hipError_t launch_check_model(hipStream_t st, int nModels, const ScoreArgs& a);
 hipError_t launch_check_rt(hipStream_t st, int nModels, const CheckRtArgs& a);
 hipError_t launch_debug_sincos(hipStream_t st, const float* angle, int n, float* c, float* s);
@@ -67,6 +67,7 @@ struct orbx_ctx {
   std::vector<float> scale, invScale, sigma2, invSigma2;
   std::vector<int> quota;
   int umax[16]{};
+  int gaussVariant = 0, grayVariant = 0;  // orbx_set_opencv_variant
   int selCap = 0;  // sum of the per-level quotas
 
   // geometry of the current frame size
@@ -713,7 +714,7 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   {
     StageTimer tm(ctx, ORBX_STAGE_DESCRIBE, si, st);
     HIPCHK(launch_describe_patch(st, n, g.selCap, a.dImg0, a.frameStride0, a.aligned0, ctx->dPyr, g, ctx->dSel, ctx->dNsel,
-                                 a.dKps, a.dDesc, a.capacity));
+                                 a.dKps, a.dDesc, a.capacity, ctx->gaussVariant));
     tm.stop(1);
   }
   return ORBX_OK;
@@ -1045,6 +1046,16 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (ctx->st2) (void)hipStreamDestroy(ctx->st2);
   if (ctx->ownStream && ctx->st) (void)hipStreamDestroy(ctx->st);
   delete ctx;
+}
+
+int orbx_set_opencv_variant(orbx_ctx* ctx, int gaussian_variant, int gray_variant) {
+  if (!ctx || gaussian_variant < 0 || gaussian_variant > 1 || gray_variant < 0 || gray_variant > 1) return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  const int w = waitAll(ctx);  // batches in flight keep the constants they were issued with
+  if (w == ORBX_E_HIP) return w;
+  ctx->gaussVariant = gaussian_variant;
+  ctx->grayVariant = gray_variant;
+  return ORBX_OK;
 }
 
 const char* orbx_last_error(const orbx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -1615,7 +1626,7 @@ int orbx_to_gray_batch_device(orbx_ctx* ctx, int n_frames, const uint8_t* d_src,
   if (n_frames == 0) return ORBX_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
   HIPCHK(launch_to_gray(ctx->st, n_frames, d_src, (long long)frame_stride_bytes, stride, width, height, channels, rgb, d_gray,
-                        (long long)gray_frame_stride_bytes, gray_stride));
+                        (long long)gray_frame_stride_bytes, gray_stride, ctx->grayVariant));
   HIPCHK(hipStreamSynchronize(ctx->st));
   return ORBX_OK;
 }
@@ -1637,7 +1648,7 @@ int orbx_to_gray(orbx_ctx* ctx, const uint8_t* img, int width, int height, int s
   }
   uint8_t* dG = ctx->dColor + (size_t)sstride * height;
   HIPCHK(hipMemcpy2DAsync(ctx->dColor, sstride, img, stride, (size_t)width * channels, height, hipMemcpyHostToDevice, ctx->st));
-  HIPCHK(launch_to_gray(ctx->st, 1, ctx->dColor, 0, sstride, width, height, channels, rgb, dG, 0, gstride));
+  HIPCHK(launch_to_gray(ctx->st, 1, ctx->dColor, 0, sstride, width, height, channels, rgb, dG, 0, gstride, ctx->grayVariant));
   HIPCHK(hipMemcpy2DAsync(gray, gray_stride, dG, gstride, width, height, hipMemcpyDeviceToHost, ctx->st));
   HIPCHK(hipStreamSynchronize(ctx->st));
   return ORBX_OK;

@@ -866,6 +866,10 @@ __device__ const IcTables d_ic = makeIcTables();
 #define DESC_WAVES 3   // keypoints (= waves) per workgroup: consecutive keypoints of a frame's list are spatially close, so
                        // putting them on one CU lets their overlapping windows hit in that CU's L1 (1: 0.44 ms, 2: 0.38,
                        // 3: 0.365, 4: 0.39, 8: 0.44, 16: 0.63 per 256 frames; 3 slices of 5.8 KB keep 27 waves per CU)
+// GV = Gaussian Q8 tap set (orbx_set_opencv_variant): 0 = [18,34,48,56,48,34,18] (error diffusion, sum 256: OpenCV >= 4.1.1 /
+// 3.4.7), 1 = [18,34,49,55,49,34,18] (every tap rounded, sum 257: the bit-exact path of 3.4.1 .. 4.1.0 and the integer filter
+// before it; a sum of 2^24 or more saturates to 255)
+template <int GV>
 __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_t* __restrict__ img0, long long img0FrameStride,
                                                        int img0Aligned, const uint8_t* __restrict__ pyr, const Geom g,
                                                        const SelKp* __restrict__ sel, const int* __restrict__ nsel,
@@ -978,7 +982,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   // ---- horizontal pass: blurred column c (x = kx-18+c) uses window bytes s+c .. s+c+6 of the staged row.
   //      Item = (row pair, group of 4 columns): 4 dwords per row cover the 10 bytes the 4 columns need; 60 lanes x 4 steps ----
   {
-    const uint32_t K0 = 18u | (34u << 8) | (48u << 16) | (56u << 24), K1 = 48u | (34u << 8) | (18u << 16);
+    constexpr uint32_t T0 = 18u, T1 = 34u, T2 = GV ? 49u : 48u, T3 = GV ? 55u : 56u;
+    constexpr uint32_t K0 = T0 | (T1 << 8) | (T2 << 16) | (T3 << 24), K1 = T2 | (T1 << 8) | (T0 << 16);
     const int rpl = lane / 10, gq = lane - rpl * 10;
 #pragma unroll
     for (int it = 0; it < 4; it++) {
@@ -1011,8 +1016,9 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   //      even row taps (18,34)(48,56)(48,34)(18,0), odd row taps (0,18)(34,48)(56,48)(34,18).  Item = (q, group of 4
   //      columns), 190 items over 3 steps; the blurred bytes overwrite the raw window (no longer needed) ----
   {
-    const uint32_t E0 = 18u | (34u << 16), E1 = 48u | (56u << 16), E2 = 48u | (34u << 16), E3 = 18u;
-    const uint32_t O0 = 18u << 16, O1 = 34u | (48u << 16), O2 = 56u | (48u << 16), O3 = 34u | (18u << 16);
+    constexpr uint32_t T0 = 18u, T1 = 34u, T2 = GV ? 49u : 48u, T3 = GV ? 55u : 56u;
+    constexpr uint32_t E0 = T0 | (T1 << 16), E1 = T2 | (T3 << 16), E2 = T2 | (T1 << 16), E3 = T0;
+    constexpr uint32_t O0 = T0 << 16, O1 = T1 | (T2 << 16), O2 = T3 | (T2 << 16), O3 = T1 | (T0 << 16);
     int q = lane / 10, gq = lane - q * 10;
 #pragma unroll
     for (int it = 0; it < 3; it++) {
@@ -1023,8 +1029,12 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
         const uint4 P3 = *reinterpret_cast<const uint4*>(&hz2[(q + 3) * PW_COLS + 4 * gq]);
 #define ORBX_VE(c) dot2u16(P0.c, E0, dot2u16(P1.c, E1, dot2u16(P2.c, E2, dot2u16(P3.c, E3, 32768u))))
 #define ORBX_VO(c) dot2u16(P0.c, O0, dot2u16(P1.c, O1, dot2u16(P2.c, O2, dot2u16(P3.c, O3, 32768u))))
-        const uint32_t e0 = ORBX_VE(x), e1 = ORBX_VE(y), e2 = ORBX_VE(z), e3 = ORBX_VE(w);
-        const uint32_t o0 = ORBX_VO(x), o1 = ORBX_VO(y), o2 = ORBX_VO(z), o3 = ORBX_VO(w);
+        uint32_t e0 = ORBX_VE(x), e1 = ORBX_VE(y), e2 = ORBX_VE(z), e3 = ORBX_VE(w);
+        uint32_t o0 = ORBX_VO(x), o1 = ORBX_VO(y), o2 = ORBX_VO(z), o3 = ORBX_VO(w);
+        if (GV) {  // taps that sum to 257: saturate_cast<uchar>
+          e0 = min(e0, 0xffffffu); e1 = min(e1, 0xffffffu); e2 = min(e2, 0xffffffu); e3 = min(e3, 0xffffffu);
+          o0 = min(o0, 0xffffffu); o1 = min(o1, 0xffffffu); o2 = min(o2, 0xffffffu); o3 = min(o3, 0xffffffu);
+        }
 #undef ORBX_VE
 #undef ORBX_VO
         // each sum is < 2^24: its blurred byte is bits 16..23; v_perm_b32 gathers byte 2 of four sums into one dword
@@ -2071,13 +2081,15 @@ __global__ __launch_bounds__(64) void k_check_model(const ScoreArgs a) {
 
 // =================================================================================================
 // Colour -> gray: Converter::toGray (Utils/Converter.cpp:5-19) = cv::cvtColor(COLOR_RGB2GRAY / COLOR_BGR2GRAY) on 8-bit,
-// Y = (c0*ch0 + c1*ch1 + c2*ch2 + 8192) >> 14 with (c0, c1, c2) = (4899, 9617, 1868) for RGB order and reversed for BGR.
+// Y = (c0*ch0 + c1*ch1 + c2*ch2 + 2^(shift-1)) >> shift with (c0, c1, c2) = (R, G, B weights) for RGB order and reversed for BGR:
+// (4899, 9617, 1868) >> 14 (OpenCV 3.x .. 4.0, the default) or (9798, 19235, 3735) >> 15 (OpenCV >= 4.1), orbx_set_opencv_variant.
 // Thread = 4 output pixels: 12 source bytes as 3 aligned dwords -> one dword store (byte paths when unaligned / at the
 // row tail).  HBM streaming: 3 B read + 1 B written per pixel.
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_to_gray(const uint8_t* __restrict__ src, long long srcFrameStride, int sstride, int w,
-                                                 int h, int c0, int c1, int c2, int srcAligned, uint8_t* __restrict__ dst,
+                                                 int h, int c0, int c1, int c2, int shift, int srcAligned, uint8_t* __restrict__ dst,
                                                  long long dstFrameStride, int dstride, int dstAligned) {
+  const uint32_t half = 1u << (shift - 1);
   const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
   const int y = blockIdx.y;
   if (x >= w) return;
@@ -2087,10 +2099,10 @@ __global__ __launch_bounds__(256) void k_to_gray(const uint8_t* __restrict__ src
   if (x + 4 <= w && srcAligned) {
     const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s);
     const uint32_t a = s4[0], b = s4[1], c = s4[2];  // bytes 0..11 = p0(0,1,2) p1(3,4,5) p2(6,7,8) p3(9,10,11)
-    const uint32_t y0 = ((a & 255) * c0 + ((a >> 8) & 255) * c1 + ((a >> 16) & 255) * c2 + 8192) >> 14;
-    const uint32_t y1 = ((a >> 24) * c0 + (b & 255) * c1 + ((b >> 8) & 255) * c2 + 8192) >> 14;
-    const uint32_t y2 = (((b >> 16) & 255) * c0 + (b >> 24) * c1 + (c & 255) * c2 + 8192) >> 14;
-    const uint32_t y3 = (((c >> 8) & 255) * c0 + ((c >> 16) & 255) * c1 + (c >> 24) * c2 + 8192) >> 14;
+    const uint32_t y0 = ((a & 255) * c0 + ((a >> 8) & 255) * c1 + ((a >> 16) & 255) * c2 + half) >> shift;
+    const uint32_t y1 = ((a >> 24) * c0 + (b & 255) * c1 + ((b >> 8) & 255) * c2 + half) >> shift;
+    const uint32_t y2 = (((b >> 16) & 255) * c0 + (b >> 24) * c1 + (c & 255) * c2 + half) >> shift;
+    const uint32_t y3 = (((c >> 8) & 255) * c0 + ((c >> 16) & 255) * c1 + (c >> 24) * c2 + half) >> shift;
     out = y0 | y1 << 8 | y2 << 16 | y3 << 24;
     if (dstAligned) {
       *reinterpret_cast<uint32_t*>(d) = out;
@@ -2100,7 +2112,7 @@ __global__ __launch_bounds__(256) void k_to_gray(const uint8_t* __restrict__ src
     return;
   }
   const int n = min(4, w - x);
-  for (int i = 0; i < n; i++) d[i] = (uint8_t)((s[3 * i] * c0 + s[3 * i + 1] * c1 + s[3 * i + 2] * c2 + 8192) >> 14);
+  for (int i = 0; i < n; i++) d[i] = (uint8_t)((s[3 * i] * c0 + s[3 * i + 1] * c1 + s[3 * i + 2] * c2 + half) >> shift);
 }
 
 __global__ __launch_bounds__(256) void k_copy_rows(const uint8_t* __restrict__ src, long long srcFrameStride, int sstride, int w,
@@ -2115,7 +2127,7 @@ __global__ __launch_bounds__(256) void k_copy_rows(const uint8_t* __restrict__ s
 // launch wrappers (called from orbx_api.cpp)
 // =================================================================================================
 hipError_t launch_to_gray(hipStream_t st, int nFrames, const uint8_t* src, long long srcFrameStride, int sstride, int w, int h,
-                          int channels, int rgb, uint8_t* dst, long long dstFrameStride, int dstride) {
+                          int channels, int rgb, uint8_t* dst, long long dstFrameStride, int dstride, int grayVariant) {
   if (nFrames <= 0) return hipSuccess;
   if (channels == 1) {  // Converter.cpp:6-8: copyTo
     dim3 block(256, 1, 1), grid((w + 255) / 256, h, nFrames);
@@ -2125,7 +2137,8 @@ hipError_t launch_to_gray(hipStream_t st, int nFrames, const uint8_t* src, long 
   const int srcAligned = ((uintptr_t)src % 4 == 0) && (srcFrameStride % 4 == 0) && (sstride % 4 == 0);
   const int dstAligned = ((uintptr_t)dst % 4 == 0) && (dstFrameStride % 4 == 0) && (dstride % 4 == 0);
   dim3 block(256, 1, 1), grid((w + 1023) / 1024, h, nFrames);
-  hipLaunchKernelGGL(k_to_gray, grid, block, 0, st, src, srcFrameStride, sstride, w, h, rgb ? 4899 : 1868, 9617, rgb ? 1868 : 4899,
+  const int cr = grayVariant ? 9798 : 4899, cg = grayVariant ? 19235 : 9617, cb = grayVariant ? 3735 : 1868, shift = grayVariant ? 15 : 14;
+  hipLaunchKernelGGL(k_to_gray, grid, block, 0, st, src, srcFrameStride, sstride, w, h, rgb ? cr : cb, cg, rgb ? cb : cr, shift,
                      srcAligned, dst, dstFrameStride, dstride, dstAligned);
   return hipGetLastError();
 }
@@ -2224,11 +2237,15 @@ hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long lo
 
 hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const uint8_t* img0, long long img0FrameStride,
                                  int img0Aligned, const uint8_t* pyr, const Geom& g, const SelKp* sel, const int* nsel,
-                                 orbx_keypoint* kps, uint8_t* desc, int capacity) {
+                                 orbx_keypoint* kps, uint8_t* desc, int capacity, int gaussVariant) {
   if (maxSel <= 0) return hipSuccess;
   dim3 block(64 * DESC_WAVES, 1, 1), grid(((maxSel + DESC_WAVES - 1) / DESC_WAVES + 7) / 8 * 8, nFrames, 1);  // x: multiple of 8
-  hipLaunchKernelGGL(k_describe_patch, grid, block, 0, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps, desc,
-                     capacity);
+  if (gaussVariant)
+    hipLaunchKernelGGL(k_describe_patch<1>, grid, block, 0, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps, desc,
+                       capacity);
+  else
+    hipLaunchKernelGGL(k_describe_patch<0>, grid, block, 0, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps, desc,
+                       capacity);
   return hipGetLastError();
 }
 

@@ -150,6 +150,15 @@ class Extractor:
         return out[:n]
 
 
+def set_opencv_variant(gaussian_variant=0, gray_variant=0):
+    """Process-wide: Gaussian Q8 taps (0 = error diffusion [18,34,48,56,..], 1 = rounded [18,34,49,55,..]) and BGR2GRAY
+    coefficients (0 = 14-bit, 1 = 15-bit) of the oracle; mirrors the product's orbx_set_opencv_variant."""
+    L = lib()
+    L.orbo_set_opencv_variant.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.orbo_set_opencv_variant.restype = None
+    L.orbo_set_opencv_variant(int(gaussian_variant), int(gray_variant))
+
+
 def resize_linear(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
     src = np.ascontiguousarray(src)
     dst = np.zeros((dh, dw), np.uint8)

@@ -911,3 +911,39 @@ def test_check_rt(orbx, ext640, oracle):
     assert ng[0] == 0 and not good.any() and not p3d.any() and par[0] == 0
     ng, good, p3d, par = ext640.check_rt(R, t, K, k1, k2, np.full(len(k1), -1, np.int32), np.zeros(0, np.uint8))
     assert ng[0] == 0 and par[0] == 0
+
+
+def test_opencv_variant_constants(orbx, oracle):
+    """orbx_set_opencv_variant: the rounded Gaussian taps [18,34,49,55,..] (sum 257, saturating) and the 15-bit BGR2GRAY
+    coefficients in the kernels == the oracle with the same variant, on frames with saturated regions; the default variant
+    afterwards == the default oracle again."""
+    import torch
+    from orb_slam_tracking_amd import synth
+    w, h, B = 640, 480, 4
+    frames = synth.synth_frames(B, w, h, 3300)
+    frames[0, 100:260, 200:420] = 255   # bright plateau next to texture: the saturating case of the sum-257 taps
+    frames[0, 120:250:9, 210:410:7] = 0
+    e = orbx.ORBextractor(*CANON, max_width=w, max_height=h, max_batch=B)
+    oe = oracle.Extractor(*CANON)
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, (97, 203, 3), dtype=np.uint8)
+    try:
+        for gv, cv_ in ((1, 1), (1, 0), (0, 1), (0, 0)):
+            e.set_opencv_variant(gv, cv_)
+            oracle.set_opencv_variant(gv, cv_)
+            res = e.extract_batch(frames)
+            for f in range(B):
+                ro, ko, do = oe(frames[f])
+                assert res[f][0] == ro
+                _same(res[f][1], res[f][2], ko, do)
+            for b in (True, False):
+                assert np.array_equal(e.to_gray(rgb, b), oracle.to_gray(rgb, b))
+            d_src = torch.from_numpy(rgb).cuda()
+            d_g = torch.zeros((97, 203), dtype=torch.uint8, device="cuda")
+            e.to_gray_batch_device(d_src, 1, 203, 97, 203 * 3, 0, 3, True, d_g, 203, 0)
+            assert np.array_equal(d_g.cpu().numpy(), oracle.to_gray(rgb, True))
+        with pytest.raises(orbx.OrbxError):
+            e.set_opencv_variant(2, 0)
+    finally:
+        oracle.set_opencv_variant(0, 0)
+        e.close()

@@ -403,3 +403,109 @@ def test_check_rt(oracle):
     assert n == 0 and not good.any() and par == 0
     n, good, p3d, par = oracle.check_rt(R, t, K, k1, k2, m12, np.zeros(len(first), np.uint8))
     assert n == 0 and not good.any() and not p3d.any() and par == 0
+
+
+def _resize_np(src, dw, dh):
+    """Independent numpy evaluation of cv::resize(INTER_LINEAR) on 8UC1 (SURVEY appendix A2): per axis
+    f = (d + 0.5) * scale - 0.5 in float32, clamp, Q11 weights by round-half-even, horizontal pass in int32, vertical pass
+    ((b0 * (T0 >> 4)) >> 16) + ((b1 * (T1 >> 4)) >> 16) + 2 >> 2 -- vectorised over the whole image, no oracle code."""
+    sh, sw = src.shape
+
+    def taps(dn, sn, fix):
+        scale = 1.0 / (float(dn) / sn)
+        f = ((np.arange(dn) + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        if fix:  # columns: the offset is pulled inside and the fraction dropped; rows are only clipped when they are read
+            lo = s < 0
+            s[lo], f[lo] = 0, 0
+            hi = s >= sn - 1
+            s[hi], f[hi] = sn - 1, 0
+        c1 = np.rint(f * np.float32(2048)).astype(np.int64)        # np.rint = round half to even = cvRound
+        c0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+        return np.clip(s, 0, sn - 1), np.clip(s + 1, 0, sn - 1), c0, c1
+    sx0, sx1, a0, a1 = taps(dw, sw, True)
+    sy0, sy1, b0, b1 = taps(dh, sh, False)
+    S = src.astype(np.int64)
+    T = S[:, sx0] * a0 + S[:, sx1] * a1                           # horizontal pass, no shift
+    out = (((b0[:, None] * (T[sy0] >> 4)) >> 16) + ((b1[:, None] * (T[sy1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def test_resize_against_numpy(oracle):
+    """A2 pinned by an independent evaluation (the property test above only checks constants, monotony and identity): random
+    images, the pyramid's own chain of sizes (640x480 -> 533x400 -> ... and 752x480 -> 627x400), odd sizes, up-scaling."""
+    rng = np.random.default_rng(12)
+    for (sw, sh, dw, dh) in ((640, 480, 533, 400), (533, 400, 444, 333), (214, 161, 179, 134), (752, 480, 627, 400), (61, 47, 53, 40),
+                             (33, 29, 32, 28), (40, 30, 57, 41), (7, 5, 3, 2), (100, 100, 100, 100)):
+        img = rng.integers(0, 256, (sh, sw), dtype=np.uint8)
+        assert np.array_equal(oracle.resize_linear(img, dw, dh), _resize_np(img, dw, dh)), (sw, sh, dw, dh)
+    ramp = (np.add.outer(np.arange(120), np.arange(160)) % 256).astype(np.uint8)
+    assert np.array_equal(oracle.resize_linear(ramp, 133, 100), _resize_np(ramp, 133, 100))
+
+
+def _fast_atan2_np(y, x):
+    """Independent float32 evaluation of cv::fastAtan2 (SURVEY appendix A5): every operation rounded to float32 by numpy."""
+    f = np.float32
+    p1, p3 = f(0.9997878412794807) * f(180 / np.pi), f(-0.3258083974640975) * f(180 / np.pi)
+    p5, p7 = f(0.1555786518463281) * f(180 / np.pi), f(-0.04432655554792128) * f(180 / np.pi)
+    eps = f(2.2204460492503131e-16)
+    y, x = f(y), f(x)
+    ax, ay = np.abs(x), np.abs(y)
+    if ax >= ay:
+        c = ay / (ax + eps)
+        c2 = c * c
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
+    else:
+        c = ax / (ay + eps)
+        c2 = c * c
+        a = f(90.0) - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
+    if x < 0:
+        a = f(180.0) - a
+    if y < 0:
+        a = f(360.0) - a
+    return f(a)
+
+
+def test_fast_atan2_against_numpy_f32(oracle):
+    """A5 bit for bit against a numpy float32 evaluation of the same polynomial (the property test above only bounds the error
+    against atan2): integer moments of the size IC_Angle produces, axes, diagonals, tiny and huge values."""
+    rng = np.random.default_rng(13)
+    cases = [(0, 0), (0, 5), (5, 0), (0, -5), (-5, 0), (7, 7), (-7, 7), (7, -7), (-7, -7), (1, 1200000), (1200000, 1), (1e-30, 1e-30), (3e38, 1e38)]
+    cases += [tuple(float(v) for v in rng.integers(-1500000, 1500000, 2)) for _ in range(5000)]
+    with np.errstate(all="ignore"):
+        for (y, x) in cases:
+            a, b = np.float32(oracle.fast_atan2(y, x)), _fast_atan2_np(y, x)
+            assert a.tobytes() == b.tobytes() or (np.isnan(a) and np.isnan(b)), (y, x, a, b)
+
+
+def test_opencv_variants(oracle):
+    """The two OpenCV-release dependent constants, selectable (orbo_set_opencv_variant / orbx_set_opencv_variant): Gaussian Q8
+    taps with every tap rounded (sum 257, saturating) and the 15-bit BGR2GRAY coefficients, each against numpy; the defaults
+    are restored and still give the committed fixtures (test_golden_vectors)."""
+    rng = np.random.default_rng(14)
+    try:
+        oracle.set_opencv_variant(1, 1)
+        k = np.array([18, 34, 49, 55, 49, 34, 18])
+        img = rng.integers(0, 256, (19, 27), dtype=np.uint8)
+        img[:6, :9] = 255  # saturation: 255 * 257 * 257 + 32768 >= 2^24
+        pad = np.pad(img, 3, mode="reflect").astype(np.int64)
+        hz = sum(k[i] * pad[:, i:i + 27] for i in range(7))
+        vt = sum(k[i] * hz[i:i + 19, :] for i in range(7))
+        exp = np.minimum((vt + 32768) >> 16, 255).astype(np.uint8)
+        assert np.array_equal(oracle.gaussian7(img), exp) and exp.max() == 255 and ((vt + 32768) >> 16).max() > 255
+        im = rng.integers(0, 256, (31, 45, 3), dtype=np.uint8)
+        a = im.astype(np.int64)
+        assert np.array_equal(oracle.to_gray(im, True), (a[..., 0] * 9798 + a[..., 1] * 19235 + a[..., 2] * 3735 + 16384) >> 15)
+        assert np.array_equal(oracle.to_gray(im, False), (a[..., 2] * 9798 + a[..., 1] * 19235 + a[..., 0] * 3735 + 16384) >> 15)
+        assert oracle.to_gray(np.full((2, 2, 3), 255, np.uint8), True).tolist() == [[255, 255], [255, 255]]  # 9798 + 19235 + 3735 = 2^15
+        # the variants change descriptors (blur) but not keypoints
+        from orb_slam_tracking_amd import synth
+        fr = synth.synth(320, 240, 21)
+        oe = oracle.Extractor(400, 1.2, 5, 20, 7)
+        _, k1, d1 = oe(fr)
+        oracle.set_opencv_variant(0, 0)
+        _, k0, d0 = oe(fr)
+        assert k0.tobytes() == k1.tobytes() and not np.array_equal(d0, d1)
+    finally:
+        oracle.set_opencv_variant(0, 0)
