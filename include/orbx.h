@@ -32,6 +32,7 @@ extern "C" {
 #define ORBX_E_TOOSMALL (-3) /* a pyramid level is narrower than one FAST cell: UB upstream (cpp:1071-1074) */
 #define ORBX_E_HIP (-4)
 #define ORBX_E_CAPACITY (-5)
+#define ORBX_E_RCCL (-6)     /* the multi-device context could not load / initialise RCCL, or a collective failed */
 
 /* mirrors cv::KeyPoint (28 bytes): pt.x pt.y size angle response octave class_id */
 typedef struct orbx_keypoint {
@@ -258,6 +259,28 @@ int orbx_profile_enable(orbx_ctx* ctx, int on);
 int orbx_profile_stages(orbx_ctx* ctx, unsigned stage_mask);
 int orbx_profile_reset(orbx_ctx* ctx);
 int orbx_profile_get(orbx_ctx* ctx, double* ms, int64_t* launches);
+
+/* ---- several MI355X from one host process ---------------------------------------- */
+/* One orbx_ctx per device; a batch is cut into contiguous even-sized blocks, one per device (consecutive pairs (2k, 2k + 1)
+ * never straddle devices); the only exchange is an ncclAllGather of the per-frame keypoint counts over xGMI.  RCCL is loaded
+ * with dlopen when a context with more than one device is created (ORBX_E_RCCL if that fails); device ids must be distinct. */
+typedef struct orbx_multi orbx_multi;
+int orbx_multi_create(const orbx_params* params, int n_devices, const int* device_ids, int max_width, int max_height,
+                      int max_batch_per_device, orbx_multi** out);
+void orbx_multi_destroy(orbx_multi* m);
+int orbx_multi_size(const orbx_multi* m);
+orbx_ctx* orbx_multi_ctx(orbx_multi* m, int r); /* device r's context, for every other call of this header */
+const char* orbx_multi_last_error(const orbx_multi* m);
+/* the block [*lo, *hi) of a batch of n_frames that device r of n_devices owns */
+int orbx_multi_shard_range(int n_frames, int n_devices, int r, int* lo, int* hi);
+/* d_*[r] = device r's arrays for ITS block (frames already resident in its HBM; layout of orbx_extract_match_batch_device).
+ * Every device extracts its block and matches the block's consecutive pairs; counts_all (host, n_frames entries) receives the
+ * all-gathered keypoint counts in global frame order (every device holds the same copy). */
+int orbx_multi_extract_match_batch_device(orbx_multi* m, int n_frames, const uint8_t* const* d_imgs, int width, int height, int stride,
+                                          size_t frame_stride_bytes, orbx_keypoint* const* d_kps, uint8_t* const* d_desc32, int capacity,
+                                          int32_t* const* d_n_out, const orbx_bounds* bounds, int window_size, float nnratio,
+                                          int check_orientation, int32_t* const* d_matches12, int32_t* const* d_nmatches,
+                                          int32_t* counts_all);
 
 /* ---- test hooks (used by tests/ only; stable but not part of the reference surface) -------- */
 /* candidates of (frame, level) of the last extract call, as produced by the FAST kernel, sorted

@@ -19,15 +19,15 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 __all__ = ["KEYPOINT_DTYPE", "OrbxError", "ORBextractor", "ORBmatcher", "Frame", "lib", "lib_path",
-           "STAGES", "E_EMPTY", "E_BADARG", "E_TOOSMALL", "E_HIP", "E_CAPACITY"]
+           "STAGES", "E_EMPTY", "E_BADARG", "E_TOOSMALL", "E_HIP", "E_CAPACITY", "E_RCCL"]
 
 # mirrors cv::KeyPoint / orbx_keypoint (28 bytes)
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                            ("octave", "<i4"), ("class_id", "<i4")])
 assert KEYPOINT_DTYPE.itemsize == 28
 
-E_EMPTY, E_BADARG, E_TOOSMALL, E_HIP, E_CAPACITY = -1, -2, -3, -4, -5
-_ERRNAMES = {-1: "ORBX_E_EMPTY", -2: "ORBX_E_BADARG", -3: "ORBX_E_TOOSMALL", -4: "ORBX_E_HIP", -5: "ORBX_E_CAPACITY"}
+E_EMPTY, E_BADARG, E_TOOSMALL, E_HIP, E_CAPACITY, E_RCCL = -1, -2, -3, -4, -5, -6
+_ERRNAMES = {-1: "ORBX_E_EMPTY", -2: "ORBX_E_BADARG", -3: "ORBX_E_TOOSMALL", -4: "ORBX_E_HIP", -5: "ORBX_E_CAPACITY", -6: "ORBX_E_RCCL"}
 STAGES = ("pyramid", "fast", "select", "describe", "match")
 
 
@@ -109,6 +109,17 @@ def lib() -> ctypes.CDLL:
     L.orbx_check_homography.argtypes = [vp, i32, vp, vp, vp, i32, vp, i32, vp, f32, vp, vp, vp, vp]
     L.orbx_check_fundamental.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, f32, vp, vp, vp, vp]
     L.orbx_check_rt.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, f32, vp, vp, vp, vp]
+    L.orbx_multi_create.argtypes = [ctypes.POINTER(_Params), i32, vp, i32, i32, i32, ctypes.POINTER(vp)]
+    L.orbx_multi_destroy.argtypes = [vp]
+    L.orbx_multi_destroy.restype = None
+    L.orbx_multi_size.argtypes = [vp]
+    L.orbx_multi_ctx.argtypes = [vp, i32]
+    L.orbx_multi_ctx.restype = vp
+    L.orbx_multi_last_error.argtypes = [vp]
+    L.orbx_multi_last_error.restype = ctypes.c_char_p
+    L.orbx_multi_shard_range.argtypes = [i32, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.orbx_multi_extract_match_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, sz, vp, vp, i32, vp, ctypes.POINTER(_Bounds), i32,
+                                                        f32, i32, vp, vp, vp]
     L.orbx_profile_enable.argtypes = [vp, i32]
     L.orbx_profile_reset.argtypes = [vp]
     L.orbx_profile_get.argtypes = [vp, vp, vp]

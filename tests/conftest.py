@@ -35,6 +35,11 @@ def oracle():
 @pytest.fixture(scope="session")
 def orbx():
     """The product package with liborbx.so built (CPU-side checks may load it without a GPU)."""
+    try:
+        import torch  # noqa: F401  -- load order: torch bundles its own libamdhip64; whichever copy is loaded first serves the
+        # whole process, and torch does not find the GPU on the system's copy (INTEGRATION.md section 5)
+    except ImportError:
+        pass
     import orb_slam_tracking_amd as pkg
     if not os.path.exists(pkg.lib_path()):
         import __graft_entry__

@@ -99,3 +99,88 @@ def test_config4_rccl(orbx, c4_oracle, tmp_path):
           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "c4_worker.py"), "--backend", "nccl", "--out", out],
          env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     _check([out] + ["%s.rank%d.npz" % (out, r) for r in range(1, world)], c4_oracle, orbx)
+
+
+def _multi_run(orbx, devices, n_frames, c4_oracle):
+    """orbx_multi_* (the C ABI a C++ host uses) on `devices`: blocks resident per device, fused extract + match per block, counts
+    all-gathered (RCCL when more than one device); everything against the oracle."""
+    import ctypes
+    import torch
+    from orb_slam_tracking_amd import synth
+    torch.cuda.init()  # torch's bundled HIP runtime first: a process that initialises the system's copy (liborbx.so) before it
+    # leaves torch without devices (two libamdhip64 builds, one process); the other GPU tests get this order from their fixtures
+    L = orbx.lib()
+    ext, pairs = c4_oracle
+    p = orbx._Params(*PARAMS)
+    h = ctypes.c_void_p(0)
+    devs = (ctypes.c_int * len(devices))(*devices)
+    nd = len(devices)
+    per = -(-(-(-n_frames // 2) // nd)) * 2  # block size = shard_range's
+    r = L.orbx_multi_create(ctypes.byref(p), nd, devs, W, H, per, ctypes.byref(h))
+    assert r == 0, r
+    try:
+        assert L.orbx_multi_size(h) == nd and L.orbx_multi_ctx(h, 0)
+        vp = ctypes.c_void_p
+        arrs = {k: [] for k in "ikdnmq"}
+        blocks = []
+        for i, dv in enumerate(devices):
+            lo, hi = ctypes.c_int(0), ctypes.c_int(0)
+            L.orbx_multi_shard_range(n_frames, nd, i, ctypes.byref(lo), ctypes.byref(hi))
+            blocks.append((lo.value, hi.value))
+            nb = max(hi.value - lo.value, 1)
+            dev = torch.device("cuda", dv)
+            fr = np.stack([synth.synth(W, H, 1000 + g) for g in range(lo.value, hi.value)]) if hi.value > lo.value else np.zeros((1, H, W), np.uint8)
+            arrs["i"].append(torch.from_numpy(fr).to(dev))
+            arrs["k"].append(torch.zeros(nb * CAP * 28, dtype=torch.uint8, device=dev))
+            arrs["d"].append(torch.zeros(nb * CAP * 32, dtype=torch.uint8, device=dev))
+            arrs["n"].append(torch.zeros(nb, dtype=torch.int32, device=dev))
+            arrs["m"].append(torch.zeros(max(nb // 2, 1) * CAP, dtype=torch.int32, device=dev))
+            arrs["q"].append(torch.zeros(max(nb // 2, 1), dtype=torch.int32, device=dev))
+        torch.cuda.synchronize()
+        ptrs = {k: (vp * nd)(*[t.data_ptr() for t in v]) for k, v in arrs.items()}
+        b = orbx._Bounds(0, W, 0, H)
+        counts = np.full(n_frames, -7, np.int32)
+        r = L.orbx_multi_extract_match_batch_device(h, n_frames, ptrs["i"], W, H, W, W * H, ptrs["k"], ptrs["d"], CAP, ptrs["n"], ctypes.byref(b),
+                                                    100, 0.9, 1, ptrs["m"], ptrs["q"], counts.ctypes.data)
+        assert r == 0, (r, L.orbx_multi_last_error(h))
+        assert np.array_equal(counts, np.array([len(ext[g][1]) for g in range(n_frames)], np.int32))
+        for i, (lo, hi) in enumerate(blocks):
+            nb = hi - lo
+            if nb == 0:
+                continue
+            n = arrs["n"][i].cpu().numpy()
+            kk = arrs["k"][i].cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(nb, CAP)
+            dd = arrs["d"][i].cpu().numpy().reshape(nb, CAP, 32)
+            mm = arrs["m"][i].cpu().numpy().reshape(-1, CAP)
+            nm = arrs["q"][i].cpu().numpy()
+            for f in range(nb):
+                _, ko, do = ext[lo + f]
+                assert n[f] == len(ko) and kk[f, :n[f]].tobytes() == ko.tobytes() and np.array_equal(dd[f, :n[f]], do)
+            for pp in range(nb // 2):
+                onm, om12, _ = pairs[(lo // 2) + pp]
+                assert nm[pp] == onm and np.array_equal(mm[pp, :len(om12)], om12)
+    finally:
+        L.orbx_multi_destroy(h)
+
+
+def test_multi_c_abi_one_device(orbx, c4_oracle):
+    """orbx_multi_create / orbx_multi_extract_match_batch_device with one device: the same entry points a C++ host uses for
+    eight (no collective needed for one; duplicate device ids are refused)."""
+    import ctypes
+    import torch
+    torch.cuda.init()
+    _multi_run(orbx, [0], 64, c4_oracle)
+    _multi_run(orbx, [0], 7, c4_oracle)  # odd count: the last frame has no partner
+    L = orbx.lib()
+    p = orbx._Params(*PARAMS)
+    h = ctypes.c_void_p(0)
+    assert L.orbx_multi_create(ctypes.byref(p), 2, (ctypes.c_int * 2)(0, 0), W, H, 32, ctypes.byref(h)) == orbx.E_BADARG
+
+
+def test_multi_c_abi_rccl(orbx, c4_oracle):
+    """More than one GPU: ncclCommInitAll + ncclAllGather of the counts inside liborbx.so (librccl.so through dlopen)."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs more than one GPU (this box has %d)" % n)
+    _multi_run(orbx, list(range(min(n, 8))), N_FRAMES, c4_oracle)

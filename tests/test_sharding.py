@@ -65,3 +65,24 @@ def test_gather_counts_world2_gloo(n_frames):
     exp = [(7 * i) % 1000 + 1 for i in range(n_frames)]
     for _, got in res:
         assert got == exp
+
+
+def test_c_abi_shard_range_equals_python():
+    """orbx_multi_shard_range (the split a C++ host gets, orbx_multi.cpp) == sharding.shard_range for every batch size and
+    device count: contiguous, covering, even-sized blocks (pairs never straddle devices)."""
+    import ctypes
+    import orb_slam_tracking_amd as orbx
+    L = orbx.lib()
+    for n_dev in (1, 2, 3, 4, 7, 8):
+        for n_frames in list(range(0, 40)) + [255, 256, 257, 1000]:
+            prev = 0
+            for r in range(n_dev):
+                lo, hi = ctypes.c_int(-1), ctypes.c_int(-1)
+                assert L.orbx_multi_shard_range(n_frames, n_dev, r, ctypes.byref(lo), ctypes.byref(hi)) == 0
+                assert (lo.value, hi.value) == sharding.shard_range(n_frames, n_dev, r)
+                assert lo.value == prev and (lo.value % 2 == 0 or lo.value == hi.value)
+                prev = hi.value
+            assert prev == n_frames
+    lo, hi = ctypes.c_int(0), ctypes.c_int(0)
+    assert L.orbx_multi_shard_range(10, 0, 0, ctypes.byref(lo), ctypes.byref(hi)) == orbx.E_BADARG
+    assert L.orbx_multi_shard_range(10, 2, 2, ctypes.byref(lo), ctypes.byref(hi)) == orbx.E_BADARG
