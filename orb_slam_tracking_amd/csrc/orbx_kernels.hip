@@ -799,6 +799,32 @@ __device__ __forceinline__ int reflect101(int p, int n) {
   return p;
 }
 
+// cos / sin of x in [0, 2 pi + eps] (a keypoint angle in radians) in f64, ~1 ulp: quadrant reduction with a two-term pi/2
+// and the fdlibm kernel polynomials, fused multiply-adds written out.  The general-range sincos of the device library costs
+// ~110 f64 instructions per call (it also carries the huge-argument path); this one ~35.  What the descriptor needs is the
+// value rounded to f32, cpp:173-174; tests/test_gpu_parity.py::test_sincos_matches_libm sweeps 3 M angles against libm.
+__device__ __forceinline__ void sincosSmall(double x, double* sn, double* cs) {
+  const double k = rint(x * 6.36619772367581382433e-01);                   // nearest multiple of pi/2: 0 .. 4
+  double r = fma(-k, 1.57079632679489655800e+00, x);                       // pi/2 high part: exact product for k <= 4
+  r = fma(-k, 6.12323399573676603587e-17, r);                              // pi/2 low part
+  const double z = r * r;
+  // __kernel_sin / __kernel_cos (fdlibm), |r| <= pi/4
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2), S1);
+  const double sr = fma(z * r, ps, r);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double cr = w + (((1.0 - w) - hz) + fma(z * z, pc, 0.0));
+  const int q = (int)k & 3;
+  const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+  *sn = (q & 2) ? -s0 : s0;
+  *cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
 // cv::fastAtan2: plain f32 mul/add/div, no contraction
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
@@ -1053,7 +1079,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   const uint8_t* bl = reinterpret_cast<const uint8_t*>(bl32);
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   double sd, cd;
-  sincos((double)(angle * factorPI), &sd, &cd);
+  sincosSmall((double)(angle * factorPI), &sd, &cd);
   const float cs = (float)cd, sn = (float)sd;
   unsigned long long words[4];
 #pragma unroll
@@ -2149,7 +2175,7 @@ __global__ __launch_bounds__(256) void k_debug_sincos(const float* __restrict__ 
   if (i >= n) return;
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   double sd, cd;
-  sincos((double)(angle[i] * factorPI), &sd, &cd);
+  sincosSmall((double)(angle[i] * factorPI), &sd, &cd);
   c[i] = (float)cd;
   s[i] = (float)sd;
 }
