@@ -247,6 +247,14 @@ def main():
             roof["frac"] = roof["achieved"] / roof["peak"]
             roof["valu_wave_instr_per_s"] = pk["valu_instr"] * frames_per_launch / secs
             roof["traffic"] = (pk["fetch_bytes"] + pk["write_bytes"]) * frames_per_launch  # HBM bytes per launch, counters
+            # the kernel alone on the chip (the PMC file's --stats pass with ORBX_NO_SPLIT=1): in the timed steps above it
+            # shares the chip with the other half-batch chain's kernels, so its live share is about half of this
+            if "avg_launch_us_single_stream" in pk:
+                roof["single_stream"] = {"avg_launch_ms": pk["avg_launch_us_single_stream"] / 1e3, "frames_per_launch": pmc["frames_per_launch"],
+                                         "frac": pk.get("valu_frac_single_stream")}
+            # the whole step: VALU issue cycles of every kernel of the path per frame x frames / step time / peak
+            tot_cycles = sum(v["valu_issue_cycles"] for v in pmc["per_frame"].values())
+            roof["step_valu_frac"] = tot_cycles * B * args.steps / dt / VALU_PEAK_SIMD_CYCLES
         else:
             roof["achieved"] = roof["frac"] = roof["traffic"] = None
         # secondary: the HBM view of the same launch (algorithmic bytes of SURVEY 8(d) and counter bytes against 8 TB/s)
