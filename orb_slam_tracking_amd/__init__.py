@@ -147,7 +147,10 @@ def _torch_stream(*arrays):
     for a in arrays:
         if a is not None and hasattr(a, "data_ptr") and getattr(a, "is_cuda", False):
             import torch
-            return int(torch.cuda.current_stream(a.device).cuda_stream)
+            st = torch.cuda.current_stream(a.device)
+            if st.query():  # nothing queued on it: nothing to order behind (saves the event record + two stream waits)
+                return None
+            return int(st.cuda_stream)
     return None
 
 
