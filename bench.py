@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--regions", type=int, default=5, help="timed regions of --steps steps (the first one gives `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame-per-call figure (profiling passes: keeps every launch of a kernel the same size)")
     ap.add_argument("--cpu-reps", type=int, default=30, help="timed repetitions per thread of the CPU baseline (>= 30 by protocol)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 path)")
@@ -301,6 +302,30 @@ def main():
             "stage_ms_source": "warmup steps, every stage bracketed by HIP events (sums over the two half-batch streams); the "
                                "timed steps bracket only the dominant kernel",
         }
+        # second figure: the call the reference actually makes -- one frame per call through the host API
+        # (Frame.cpp:58-60: host image in, keypoints + descriptors back on the host), and one SearchForInitialization per call
+        try:
+            if args.no_single_frame:
+                raise RuntimeError("skipped (--no-single-frame)")
+            e1 = orbx.ORBextractor(*PARAMS, max_width=W, max_height=H, max_batch=1, device=local_rank)
+            fa, fb = orbx.Frame(frames[0], 0.0, e1), orbx.Frame(frames[1], 1.0, e1)
+            mt = orbx.ORBmatcher(0.9, True)
+            for _ in range(10):
+                e1(frames[0]); mt.SearchForInitialization(fa, fb, 100)
+            nrep = 200
+            t0 = time.perf_counter()
+            for _ in range(nrep):
+                e1(frames[0])
+            t1 = time.perf_counter()
+            for _ in range(nrep):
+                mt.SearchForInitialization(fa, fb, 100)
+            t2 = time.perf_counter()
+            out["single_frame"] = {"extract_ms_per_frame": (t1 - t0) / nrep * 1e3, "match_ms_per_pair": (t2 - t1) / nrep * 1e3,
+                                   "frames_per_s_extract_only": nrep / (t1 - t0),
+                                   "note": "synchronous host-buffer calls, one 640x480 frame (orbx_extract) / one pair (orbx_match_init) per call"}
+            e1.close()
+        except Exception as ex:  # never let the second figure break the line
+            out["single_frame"] = {"error": str(ex)[:200]}
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O

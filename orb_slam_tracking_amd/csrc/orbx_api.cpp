@@ -58,6 +58,13 @@ inline int alignUp(int v, int a) { return (v + a - 1) / a * a; }
 
 using namespace orbx;
 
+// k_pyramid_bands' own tables (PyrXGroup per group of 4 output pixels, PyrYRow per output row), appended to the resize
+// tables of the geometry; `ok` = every level meets the kernel's preconditions
+struct PyrTabInfo {
+  int32_t xoff[ORBX_MAX_LEVELS], yoff[ORBX_MAX_LEVELS];  // uint4 units from the table base
+  int ok, dual2;
+};
+
 struct orbx_ctx {
   orbx_params p{};
   int device = 0;
@@ -91,6 +98,7 @@ struct orbx_ctx {
   int* dOverflow = nullptr;
   ResizeTab* dTab = nullptr;
   size_t tabEntries = 0;
+  PyrTabInfo pyrInfo{};   // k_pyramid_bands' tables inside dTab, for the current geometry
   std::vector<FastCell> hCells;  // k_fast_wave's per-cell records of the current geometry (buildFastCells)
   FastCell* dCells = nullptr;
   size_t cellEntries = 0;
@@ -233,7 +241,66 @@ void levelSize(const orbx_ctx* c, int w, int h, int l, int* lw, int* lh) {  // c
 }
 
 // fills c->g for a w x h frame whose level 0 has row stride `stride0`; returns 0 or an error code
-int buildGeometry(orbx_ctx* c, int w, int h, int stride0, Geom* out, std::vector<ResizeTab>* tab) {
+void appendPyrTables(const Geom& g, std::vector<ResizeTab>* tab, PyrTabInfo* info) {
+  static_assert(sizeof(ResizeTab) == 8 && sizeof(PyrXGroup) == 8 * sizeof(ResizeTab) && sizeof(PyrYRow) == 2 * sizeof(ResizeTab), "table units");
+  *info = PyrTabInfo{};
+  info->ok = g.nlevels > 1;
+  for (int l = 1; l < g.nlevels; l++) {
+    const LevelGeom& S = g.L[l - 1];
+    const LevelGeom& D = g.L[l];
+    const int sw = S.w, sh = S.h, ng = (D.w + 3) / 4;
+    if (sw < 8 || D.h >= 32768 || D.w > 2048) info->ok = 0;
+    if (tab->size() & 1) tab->push_back(ResizeTab{0, 0});
+    info->xoff[l] = (int32_t)(tab->size() / 2);
+    const int lim = (sw - 1) & ~3;  // last dword that holds a pixel of the row: never read beyond it
+    for (int gx = 0; gx < ng; gx++) {
+      PyrXGroup x{};
+      const ResizeTab* e = tab->data() + D.xtabOff + 4 * gx;  // padded to a multiple of 4 entries (the pad repeats the last pixel)
+      const int base = e[0].ofs & ~3;
+      x.o[0] = (uint32_t)base;
+      x.o[1] = (uint32_t)std::min(base + 4, lim);
+      x.o[2] = (uint32_t)std::min(base + 8, lim);
+      const uint32_t zero = 0x0c0c0c0cu;
+      for (int i = 0; i < 4; i++) {
+        const int k = e[i].ofs - base, c0 = e[i].coef & 0xffff, c1 = (int)((uint32_t)e[i].coef >> 16);
+        // the right tap is needed only with a weight (cv::resize zeroes the fraction at the last column)
+        const int k1 = c1 ? k + 1 : k;
+        if (k < 0 || k1 > 11 || c0 + c1 > 2048) { info->ok = 0; continue; }
+        const bool second = k1 > 7;            // bytes 4..11 = dwords (1, 2)
+        if (second && k < 4) { info->ok = 0; continue; }
+        const uint32_t sel = 0x0c000c00u | (uint32_t)(second ? k - 4 : k) | ((uint32_t)(second ? k1 - 4 : k1) << 16);
+        if (i < 2) {
+          if (second) info->ok = 0;            // pixels 0 and 1 have one selector (dwords 0, 1): scale <= 2 keeps them there
+          x.sel[i] = sel;
+        } else if (i == 2) {
+          x.sel[2] = second ? zero : sel;
+          x.sel[3] = second ? sel : zero;
+          if (second) info->dual2 = 1;
+        } else {
+          x.sel[4] = second ? zero : sel;
+          x.sel[5] = second ? sel : zero;
+        }
+        x.cf[i] = ((uint32_t)c0 << 4) | (((uint32_t)c1 << 4) << 16);
+      }
+      ResizeTab raw[8];
+      memcpy(raw, &x, sizeof(x));
+      tab->insert(tab->end(), raw, raw + 8);
+    }
+    info->yoff[l] = (int32_t)(tab->size() / 2);
+    for (int dy = 0; dy < D.h; dy++) {
+      const ResizeTab t = (*tab)[D.ytabOff + dy];
+      const int sy0 = std::min(std::max(t.ofs, 0), sh - 1), sy1 = std::min(std::max(t.ofs + 1, 0), sh - 1);
+      const int c0 = t.coef & 0xffff, c1 = (int)((uint32_t)t.coef >> 16);
+      if (c0 + c1 > 2048) info->ok = 0;
+      const PyrYRow y{(uint32_t)sy0 * (uint32_t)S.stride, (uint32_t)sy1 * (uint32_t)S.stride, (uint32_t)c0 << 8, (uint32_t)c1 << 8};
+      ResizeTab raw[2];
+      memcpy(raw, &y, sizeof(y));
+      tab->insert(tab->end(), raw, raw + 2);
+    }
+  }
+}
+
+int buildGeometry(orbx_ctx* c, int w, int h, int stride0, Geom* out, std::vector<ResizeTab>* tab, PyrTabInfo* pyrInfo = nullptr) {
   Geom g{};
   g.nlevels = c->p.nlevels;
   g.iniTh = std::min(std::max(c->p.ini_th_fast, 0), 255);
@@ -330,6 +397,11 @@ int buildGeometry(orbx_ctx* c, int w, int h, int stride0, Geom* out, std::vector
     ph = L.h;
   }
   g.nCellsTotal = cellBase;
+  if (tab) {
+    PyrTabInfo info;
+    appendPyrTables(g, tab, &info);
+    if (pyrInfo) *pyrInfo = info;
+  }
   *out = g;
   return ORBX_OK;
 }
@@ -448,6 +520,7 @@ int allocAll(orbx_ctx* ctx) {
   if (r != ORBX_OK) return r;
   Sizes s = sizesOf(ctx, g, tab.size());
   // row strides grow by at most 63 bytes and tables by a few entries for smaller frames: keep headroom
+  // (+ slack: k_pyramid_bands reads up to 11 bytes beyond the last row of a level)
   ctx->pyrBytes = s.pyrBytes + (size_t)64 * max_height * ctx->p.nlevels * max_batch + 4096;
   {
     // per-level bound of cells * segCap that holds for every frame size up to max_width x max_height:
@@ -549,12 +622,13 @@ int ensureGeometry(orbx_ctx* ctx, int w, int h, int stride0) {
   if (w <= 0 || h <= 0) return ORBX_E_EMPTY;
   Geom g;
   std::vector<ResizeTab> tab;
-  int r = buildGeometry(ctx, w, h, stride0, &g, &tab);  // (before any growth: a frame the path cannot take must not cost one)
+  PyrTabInfo pyrInfo;
+  int r = buildGeometry(ctx, w, h, stride0, &g, &tab, &pyrInfo);  // (before any growth: a frame the path cannot take must not cost one)
   if (r != ORBX_OK) return r;
   if (w > ctx->maxW || h > ctx->maxH) {  // operator() accepts any image (cpp:1531-1545): the context grows
     r = growTo(ctx, w, h, ctx->maxB);
     if (r != ORBX_OK) return r;
-    r = buildGeometry(ctx, w, h, stride0, &g, &tab);  // (offsets depend on maxB only, but keep one source of truth)
+    r = buildGeometry(ctx, w, h, stride0, &g, &tab, &pyrInfo);  // (offsets depend on maxB only, but keep one source of truth)
     if (r != ORBX_OK) return r;
   }
   Sizes s = sizesOf(ctx, g, tab.size());
@@ -576,6 +650,7 @@ int ensureGeometry(orbx_ctx* ctx, int w, int h, int stride0) {
   ctx->g = g;
   ctx->oct = oct;
   ctx->hTab = tab;
+  ctx->pyrInfo = pyrInfo;
   ctx->fastWaveOk = buildFastCells(g, &ctx->hCells);
   if (!tab.empty()) HIPCHK(hipMemcpyAsync(ctx->dTab, ctx->hTab.data(), tab.size() * sizeof(ResizeTab), hipMemcpyHostToDevice, ctx->st));
   if (!ctx->hCells.empty())
@@ -626,6 +701,7 @@ struct ExtractArgs {
   int stride0;
   long long frameStride0;
   int aligned0;
+  int safeFrom;      // first frame of the batch behind whose level 0 nothing is known to follow (the last one, normally)
   orbx_keypoint* dKps;
   uint8_t* dDesc;
   int capacity;
@@ -640,6 +716,8 @@ PyrBands computePyrBands(const orbx_ctx* ctx, int K) {
   const int nl = g.nlevels;
   PyrBands pb{};
   pb.nBands = K = std::min(K, ORBX_PYR_BANDS_MAX);
+  pb.dual2 = ctx->pyrInfo.dual2;
+  for (int l = 0; l < nl; l++) { pb.xoff[l] = ctx->pyrInfo.xoff[l]; pb.yoff[l] = ctx->pyrInfo.yoff[l]; }
   for (int b = 0; b < K; b++) {
     int need0 = 0, need1 = 0;  // rows of level l that the band's rows of level l + 1 read
     for (int l = nl - 1; l >= 1; l--) {
@@ -648,6 +726,7 @@ PyrBands computePyrBands(const orbx_ctx* ctx, int K) {
       if (l < nl - 1 && need1 > need0) { r0 = std::min(r0, need0); r1 = std::max(r1, need1); }
       pb.r0[b][l] = (int16_t)r0;
       pb.r1[b][l] = (int16_t)r1;
+      pb.maxRows = std::max(pb.maxRows, r1 - r0);
       need0 = need1 = 0;
       if (r1 > r0 && l >= 2) {
         const ResizeTab* yt = ctx->hTab.data() + g.L[l].ytabOff;
@@ -672,11 +751,22 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   if (part == 0) {
   // whole pyramid in one launch (k_pyramid_bands) when every level meets the dword path's preconditions and the batch
   // is large enough to fill the device with (bands x frames) workgroups; otherwise one launch per level
-  bool banded = nl > 1 && a.aligned0 && n >= 32 && !getenv("ORBX_NO_BANDS");
-  for (int l = 1; l < nl && banded; l++) banded = g.L[l].resizeSpanOk && g.L[l].h < 32768 && g.L[l].w <= 2048;
+  static const bool noBands = getenv("ORBX_NO_BANDS") != nullptr;  // diagnostics
+  static const int bandsEnv = getenv("ORBX_PYR_BANDS") ? atoi(getenv("ORBX_PYR_BANDS")) : 0;  // diagnostics
+  bool banded = nl > 1 && ctx->pyrInfo.ok && a.aligned0 && n >= 32 && !noBands;  // (dword loads: level 0 rows 4-byte aligned)
+  PyrBands pb{};
+  if (banded) {  // a band's rows of one level are staged by one pass of the workgroup: at most 256
+    // 7 bands: the kernel's 72 VGPRs let 7 workgroups share a CU, so 128 or 256 frames x 7 bands are one resident round
+    // (measured on 256 frames: 4 bands 0.168 ms, 6 0.161, 7 0.160, 8 0.192, 12 0.198; rows that bands share cost 5 % at 4
+    // bands, 11 % at 8, 23 % at 16)
+    int K = bandsEnv > 0 ? bandsEnv : (n >= 64 ? 7 : 14);
+    pb = computePyrBands(ctx, K);
+    while (pb.maxRows > 256 && K < ORBX_PYR_BANDS_MAX) pb = computePyrBands(ctx, K = std::min(2 * K, ORBX_PYR_BANDS_MAX));
+    banded = pb.maxRows <= 256;
+    pb.safeFrom = a.safeFrom;
+  }
   if (banded) {
     StageTimer tm(ctx, ORBX_STAGE_PYRAMID, si, st);
-    const PyrBands pb = computePyrBands(ctx, n >= 64 ? 8 : 16);
     HIPCHK(launch_pyramid_bands(st, n, a.dImg0, a.frameStride0, ctx->dPyr, g, ctx->dTab, pb));
     tm.stop(1);
   } else {
@@ -876,6 +966,8 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
   a.dImg0 = dImg0; a.stride0 = stride0; a.frameStride0 = frameStride0;
   a.aligned0 = (((uintptr_t)dImg0 | (uintptr_t)stride0 | (uintptr_t)frameStride0) & 3) == 0;
   a.dKps = dKps; a.dDesc = dDesc; a.capacity = capacity;
+  // k_pyramid_bands may read a few bytes beyond a level-0 row: harmless while another frame follows in the caller's buffer
+  a.safeFrom = frameStride0 >= (long long)stride0 * h ? B - 1 : 0;
   int* dN = dNout ? dNout : ctx->dNsel;
   const int nPairs = match ? match->nPairs : 0;
   bool pairsCopied = false;

@@ -103,10 +103,27 @@ struct ResizeTab {
 };
 
 // k_pyramid_bands: rows [r0, r1) of level l that band b of a frame produces (host: computePyrBands)
-#define ORBX_PYR_BANDS_MAX 16
+#define ORBX_PYR_BANDS_MAX 32
 struct PyrBands {
-  int32_t nBands;
+  int32_t nBands, dual2;                                 // dual2: pixel 2 of some group needs the second dword pair
+  int32_t safeFrom;                                      // frames >= safeFrom (batch index): nothing is known to follow their level 0
+  int32_t maxRows;                                       // most rows any band has on any level (<= 256)
+  int32_t xoff[ORBX_MAX_LEVELS], yoff[ORBX_MAX_LEVELS];  // the level's PyrXGroup / PyrYRow tables, in uint4 units from the table base
   int16_t r0[ORBX_PYR_BANDS_MAX][ORBX_MAX_LEVELS], r1[ORBX_PYR_BANDS_MAX][ORBX_MAX_LEVELS];
+};
+// column constants of one group of 4 output pixels (host: appendPyrTables).  The group's taps lie in the 12 bytes of three
+// dwords at byte offsets o[0] = (first tap & ~3), o[1], o[2] of a source row (o[1], o[2]: + 4, + 8, but never beyond the
+// row's last dword, which can then only supply bytes of weight 0).
+struct PyrXGroup {
+  uint32_t o[3];
+  uint32_t sel[6];   // v_perm_b32 selectors (bytes k, k + 1 as two u16 halves): pixel 0, 1, 2 in dwords (0, 1); pixel 2 in dwords
+                     // (1, 2); pixel 3 in (0, 1); pixel 3 in (1, 2).  Of a pixel's two, the one that does not apply is 0x0c0c0c0c (zero)
+  uint32_t cf[4];    // Q11 tap pair times 16: (c0 << 4) | (c1 << 4) << 16
+  uint32_t pad[3];
+};
+static_assert(sizeof(PyrXGroup) == 64, "PyrXGroup is read as four uint4");
+struct PyrYRow {     // one output row: byte offsets of its two source rows (already clamped), Q11 weights << 8
+  uint32_t off0, off1, wy0, wy1;
 };
 
 // k_check_model: CheckHomography (kind 0) / CheckFundamental (kind 1) over nModels hypotheses

@@ -23,6 +23,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "../../include/orbx.h"
 #include "orbx_device.h"
@@ -120,119 +121,202 @@ __device__ __forceinline__ uint32_t dot2u16(uint32_t a, uint32_t b, uint32_t c) 
 // workgroup produces its bands level by level, re-reading what it wrote itself a moment ago (L2 hits) behind a fence +
 // barrier; bands of neighbouring workgroups overlap by a few rows and write identical bytes there.  No inter-workgroup
 // synchronisation, no launch gaps, and the small upper levels no longer pay a launch each.
-// Same arithmetic as k_resize_dw (needs its preconditions: 4-byte aligned rows, tap span <= 11 bytes).
+//
+// Arithmetic = k_resize's (cv::resize INTER_LINEAR 8UC1, Q11 taps), arranged for the two budgets that
+// bound it (tools/microbench: valu_rate = vector issue, add / and / shift-right 2 cycles per wave64 instruction, everything
+// else 4; mem_rate = the CU's one texture addresser, 6 cycles per dword load of a wave, 34 per byte-aligned 8-byte load):
+//   * the taps of 4 consecutive outputs lie within 12 source bytes from a 4-aligned start (scale <= 2): three aligned
+//     dword loads per source row and group (measured cheaper than one unaligned 8-byte window: the addresser, not the
+//     vector pipe, bounded that variant).  The byte pair of pixels 0..2 always sits in dwords (0, 1); pixel 3 (and pixel 2
+//     at scales above ~1.3, template DUAL2) may need dwords (1, 2): it takes one v_perm_b32 per dword pair, the one that does
+//     not apply with an all-zero selector, and an OR.  All selectors depend on the column only (host table PyrXGroup)
+//   * horizontal: v_dot2_u32_u16 with the Q11 pair pre-multiplied by 16, t' = 16 t
+//   * vertical: (wy * (t >> 4)) >> 16 == v_mul_hi_u32_u24(wy << 8, t' & ~0xff)  (both operands < 2^24; bits 47:32 of the
+//     product); the row offsets and wy << 8 come ready-made from the host table PyrYRow
+//   * the four sums of a group are rounded, shifted and packed two at a time; no clamp: with tap pairs summing to 2048
+//     (checked on the host, else the per-level kernels run) the result is <= 255
+__device__ __forceinline__ uint32_t mulHiU24(uint32_t a, uint32_t b) {  // v_mul_hi_u32_u24: bits 47:32 of the 24 x 24 bit product
+  return (uint32_t)(((unsigned long long)(a & 0xffffffu) * (unsigned long long)(b & 0xffffffu)) >> 32);
+}
+// Diagnostic build only (-DORBX_PYR_STAMPS): per workgroup, s_memtime at the start, after the first barrier, and per level after
+// the rows and after the barrier; s_memrealtime at start and end; tools/pyr_stamps.py prints where a workgroup's time goes.
+#ifdef ORBX_PYR_STAMPS
+#define PYR_STAMP_WGS (1 << 14)
+__device__ uint32_t g_pyrStamps[PYR_STAMP_WGS * 40];
+#define PYR_STAMP(k)                                                                                          \
+  do {                                                                                                        \
+    if (threadIdx.x == 0 && stampWg_ < PYR_STAMP_WGS) g_pyrStamps[stampWg_ * 40 + (k)] = (uint32_t)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define PYR_STAMP_RT(k)                                                                                       \
+  do {                                                                                                        \
+    if (threadIdx.x == 0 && stampWg_ < PYR_STAMP_WGS) g_pyrStamps[stampWg_ * 40 + (k)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+extern "C" int orbx_diag_pyr_stamps(uint32_t* out, int nWgs) {  // out: nWgs x 40 dwords; nWgs < 0: clear the buffer
+  if (nWgs < 0) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_pyrStamps)) != hipSuccess) return -1;
+    return (int)hipMemset(p, 0, sizeof(uint32_t) * 40 * PYR_STAMP_WGS);
+  }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pyrStamps), sizeof(uint32_t) * 40 * (size_t)nWgs);
+}
+#else
+#define PYR_STAMP(k) do { } while (0)
+#define PYR_STAMP_RT(k) do { } while (0)
+#endif
+#define PYR_R 2   // output rows in flight per thread and step
+struct __attribute__((aligned(4))) PyrU3 { uint32_t a, b, c; };  // 12 bytes from a 4-aligned address: one global_load_dwordx3
+template <int DUAL2>
 __global__ __launch_bounds__(256) void k_pyramid_bands(const uint8_t* __restrict__ img0, long long img0FrameStride,
                                                        uint8_t* __restrict__ pyr, const Geom g,
-                                                       const ResizeTab* __restrict__ tab, const PyrBands pb) {
+                                                       const uint4* __restrict__ ptab, const PyrBands pb) {
+  // the band's PyrYRow entries of the current level (and, filled meanwhile, of the next one): a step's row constants then
+  // cost an LDS read instead of a global load in front of the source loads that depend on them
+  extern __shared__ uint4 yrows[];  // [2][pb.maxRows]
   const int f = blockIdx.y + g.frame0, band = blockIdx.x, tid = threadIdx.x;
-  for (int l = 1; l < g.nlevels; l++) {
+  const int nl = g.nlevels;
+#ifdef ORBX_PYR_STAMPS
+  const unsigned stampWg_ = blockIdx.y * gridDim.x + blockIdx.x;
+#endif
+  PYR_STAMP(0);
+  PYR_STAMP_RT(36);
+  // column constants of this thread for level l
+  struct Cols {
+    uint32_t o[2], sel[2][6], cf[2][4];
+    int G, rpp, rsub, col;
+    bool lanes, haveG[2];
+  };
+  auto loadCols = [&](int l, Cols& c) {
+    const int ng = (g.L[l].w + 3) >> 2;          // groups of 4 output pixels per row
+    // A thread keeps its column(s): it owns G adjacent groups (8 or 4 output pixels) of one thread-column and walks down the
+    // band's rows, so the column constants of its pixels are loaded ONCE per level and stay in registers.  rpp rows are
+    // covered per pass; G (1 or 2) = whichever fills more of the 256 lanes with whole rows (134 groups: 67 thread-columns
+    // x 3 rows = 201 of 256 lanes).  (The host takes this kernel only when every level is at most 2048 pixels wide, i.e.
+    // at most 256 thread-columns of two groups.)
+    const int ngt2 = (ng + 1) >> 1;
+    const int use1 = ng <= 256 ? ng * (256 / ng) : 0, use2 = ngt2 * (256 / ngt2);
+    c.G = use2 > use1 ? 2 : 1;
+    const int ngt = c.G == 2 ? ngt2 : ng;
+    c.rpp = max(256 / ngt, 1);
+    c.rsub = tid / ngt;
+    c.col = tid - c.rsub * ngt;
+    c.lanes = c.rsub < c.rpp;
+    const uint4* xg = ptab + pb.xoff[l];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int gx = c.col * c.G + j;
+      c.haveG[j] = c.lanes && j < c.G && gx < ng;
+      const uint4* e = xg + (unsigned)(c.haveG[j] ? gx : 0) * 4u;
+      const uint4 X0 = e[0], X1 = e[1], X2 = e[2];
+      const uint32_t X3 = e[3].x;
+      c.o[j] = X0.x;
+      c.sel[j][0] = X0.w; c.sel[j][1] = X1.x; c.sel[j][2] = X1.y; c.sel[j][3] = X1.z; c.sel[j][4] = X1.w; c.sel[j][5] = X2.x;
+      c.cf[j][0] = X2.y; c.cf[j][1] = X2.z; c.cf[j][2] = X2.w; c.cf[j][3] = X3;
+    }
+  };
+  Cols C;
+  loadCols(1, C);
+  {
+    const int r0 = pb.r0[band][1], n = pb.r1[band][1] - r0;
+    if (tid < n) yrows[pb.maxRows + tid] = (ptab + pb.yoff[1])[r0 + tid];
+  }
+  __syncthreads();
+  PYR_STAMP(1);
+  for (int l = 1; l < nl; l++) {
     const LevelGeom& S = g.L[l - 1];
     const LevelGeom& D = g.L[l];
     const uint8_t* src = l == 1 ? img0 + (long long)f * img0FrameStride : pyr + S.imgOff + (long long)f * S.frameStride;
     uint8_t* dst = pyr + D.imgOff + (long long)f * D.frameStride;
-    const uint8_t* xtabB = reinterpret_cast<const uint8_t*>(tab + D.xtabOff);
-    const ResizeTab* ytab = tab + D.ytabOff;
+    const uint4* yr = yrows + (l & 1) * pb.maxRows;
     const int r0 = pb.r0[band][l], r1 = pb.r1[band][l];
-    const int sw = S.w, sh = S.h, sstride = S.stride, dstride = D.stride;
-    const int ng = (D.w + 3) >> 2;               // groups of 4 output pixels per row
-    // A thread keeps its column(s): it owns G adjacent groups (8 or 4 output pixels) of one thread-column and walks down the
-    // band's rows, so the x table entries of its pixels are loaded ONCE per level and stay in registers (they were 40 of
-    // the 64 bytes every item pulled through L1).  rpp rows are in flight per pass; G = 2 when a row has more than 128
-    // groups keeps the workgroup's lanes busy (134 groups: 67 thread-columns x 3 rows = 201 of 256 lanes).
-    // G (1 or 2) = whichever fills more of the 256 lanes with whole rows.  (The host takes this kernel only when every
-    // level is at most 2048 pixels wide, i.e. at most 256 thread-columns of two groups.)
-    const int ngt2 = (ng + 1) >> 1;
-    const int use1 = ng <= 256 ? ng * (256 / ng) : 0, use2 = ngt2 * (256 / ngt2);
-    const int G = use2 > use1 ? 2 : 1;
-    const int ngt = G == 2 ? ngt2 : ng;
-    const int rpp = max(256 / ngt, 1);
-    const int rsub = tid / ngt, col = tid - rsub * ngt;
-    const bool lanes = rsub < rpp;
-    const int lim = (sw - 1) & ~3;  // last dword that holds a pixel of the row: never read beyond it
-    uint4 tA[2], tB[2];
-    bool haveG[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int gx = col * G + j;
-      haveG[j] = lanes && j < G && gx < ng;
-      const unsigned dx0 = (unsigned)(haveG[j] ? gx : 0) * 4u;
-      tA[j] = *reinterpret_cast<const uint4*>(xtabB + dx0 * 8u);
-      tB[j] = *reinterpret_cast<const uint4*>(xtabB + dx0 * 8u + 16u);
+    const int dstride = D.stride;
+    // the next level's row constants are fetched now and used after the barrier: their latency runs under this level's rows
+    uint4 nextY = make_uint4(0, 0, 0, 0);
+    int nextN = 0;
+    if (l + 1 < nl) {
+      const int q0 = pb.r0[band][l + 1];
+      nextN = pb.r1[band][l + 1] - q0;
+      if (tid < nextN) nextY = (ptab + pb.yoff[l + 1])[q0 + tid];
     }
-    // what depends on the x tables only is computed once per level: the byte selector of every pixel's tap pair and
-    // whether the pair starts in the first or the second staged dword
-    uint32_t selv[2][4], cfs[2][4];
-    bool upv[2][4];
-    int basev[2];
+    const int G = C.G, rpp = C.rpp;
+    // The three dwords of a group come as ONE 12-byte load (the addresser's cost is per instruction and lane: 18 cycles, against
+    // 3 x 12 for single dwords at this pitch).  At the end of a row that reads up to 11 bytes beyond the last pixel: the next
+    // row, the next level, the next frame, or the slack the pyramid buffer ends with; only behind the last row of the
+    // caller's last frame nothing is known to follow, so frames f >= pb.safeFrom take level 1 with clamped single dwords.
+    auto rows = [&](auto safeTag) {
+    constexpr bool SAFE = decltype(safeTag)::value;
+    for (int dy0 = r0 + C.rsub; dy0 < r1; dy0 += PYR_R * rpp) {  // PYR_R rows per step: their loads are in flight together
+      uint32_t wy[PYR_R][2];
+      bool liveR[PYR_R];
+      PyrU3 ra[PYR_R][2], rb[PYR_R][2];
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int sxs[4] = {(int)tA[j].x, (int)tA[j].z, (int)tB[j].x, (int)tB[j].z};
-      cfs[j][0] = tA[j].y; cfs[j][1] = tA[j].w; cfs[j][2] = tB[j].y; cfs[j][3] = tB[j].w;
-      basev[j] = sxs[0] & ~3;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int k = sxs[i] - basev[j];  // 0..10: byte offset of the left tap inside the 12 staged bytes
-        // taps k, k+1 come from dwords (0,1) when k <= 6, else from dwords (1,2); v_perm_b32 picks the two bytes as the
-        // u16 halves (0x0c = constant 0) and v_dot2_u32_u16 applies the Q11 pair (c0 | c1 << 16)
-        upv[j][i] = k > 6;
-        selv[j][i] = (uint32_t)(upv[j][i] ? k - 4 : k) * 0x00010001u + 0x0c010c00u;
-      }
-    }
-    for (int dy0 = r0 + rsub; dy0 < r1; dy0 += 2 * rpp) {  // two rows per step: their loads are in flight together
-      ResizeTab ty[2];
-      bool liveR[2];
-      uint32_t ra[2][2][3], rb[2][2][3];
-#pragma unroll
-      for (int q = 0; q < 2; q++) {
+      for (int q = 0; q < PYR_R; q++) {
         const int dy = dy0 + q * rpp;
-        liveR[q] = lanes && dy < r1;
-        ty[q] = ytab[(unsigned)(liveR[q] ? dy : r0)];
-      }
+        liveR[q] = C.lanes && dy < r1;
+        const uint4 ty = yr[liveR[q] ? dy - r0 : 0];
+        wy[q][0] = ty.z; wy[q][1] = ty.w;
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
-        const int sy0 = min(max(ty[q].ofs, 0), sh - 1), sy1 = min(max(ty[q].ofs + 1, 0), sh - 1);
-        const unsigned S0 = (unsigned)(sy0 * sstride), S1 = (unsigned)(sy1 * sstride);
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-          // a dword beyond the row's last one is replaced by the last one and can only supply bytes whose weight is 0
-          const int base = basev[j];
-          const unsigned o0 = (unsigned)base, o1 = (unsigned)min(base + 4, lim), o2 = (unsigned)min(base + 8, lim);
+        for (int j = 0; j < 2; j++)
           if (j < G) {
-            ra[q][j][0] = *reinterpret_cast<const uint32_t*>(src + (S0 + o0)); ra[q][j][1] = *reinterpret_cast<const uint32_t*>(src + (S0 + o1));
-            ra[q][j][2] = *reinterpret_cast<const uint32_t*>(src + (S0 + o2));
-            rb[q][j][0] = *reinterpret_cast<const uint32_t*>(src + (S1 + o0)); rb[q][j][1] = *reinterpret_cast<const uint32_t*>(src + (S1 + o1));
-            rb[q][j][2] = *reinterpret_cast<const uint32_t*>(src + (S1 + o2));
+            if (SAFE) {
+              // a dword beyond the row's last one is replaced by the last one and can only supply bytes of weight 0
+              const uint32_t lim = (uint32_t)(S.w - 1) & ~3u, o0 = C.o[j], o1 = min(o0 + 4u, lim), o2 = min(o0 + 8u, lim);
+              ra[q][j].a = *reinterpret_cast<const uint32_t*>(src + (ty.x + o0)); rb[q][j].a = *reinterpret_cast<const uint32_t*>(src + (ty.y + o0));
+              ra[q][j].b = *reinterpret_cast<const uint32_t*>(src + (ty.x + o1)); rb[q][j].b = *reinterpret_cast<const uint32_t*>(src + (ty.y + o1));
+              ra[q][j].c = *reinterpret_cast<const uint32_t*>(src + (ty.x + o2)); rb[q][j].c = *reinterpret_cast<const uint32_t*>(src + (ty.y + o2));
+            } else {
+              ra[q][j] = *reinterpret_cast<const PyrU3*>(src + (ty.x + C.o[j]));
+              rb[q][j] = *reinterpret_cast<const PyrU3*>(src + (ty.y + C.o[j]));
+            }
           }
-        }
       }
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
+      for (int q = 0; q < PYR_R; q++) {
         const int dy = dy0 + q * rpp;
-        const uint32_t wy0 = ty[q].coef & 0xffff, wy1 = (uint32_t)ty[q].coef >> 16;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
           if (j >= G) continue;
-          uint32_t packed = 0;
+          const PyrU3 a = ra[q][j], b = rb[q][j];
+          uint32_t p0[4], p1[4];
+          p0[0] = __builtin_amdgcn_perm(a.b, a.a, C.sel[j][0]); p1[0] = __builtin_amdgcn_perm(b.b, b.a, C.sel[j][0]);
+          p0[1] = __builtin_amdgcn_perm(a.b, a.a, C.sel[j][1]); p1[1] = __builtin_amdgcn_perm(b.b, b.a, C.sel[j][1]);
+          p0[2] = __builtin_amdgcn_perm(a.b, a.a, C.sel[j][2]); p1[2] = __builtin_amdgcn_perm(b.b, b.a, C.sel[j][2]);
+          if (DUAL2) {
+            p0[2] |= __builtin_amdgcn_perm(a.c, a.b, C.sel[j][3]); p1[2] |= __builtin_amdgcn_perm(b.c, b.b, C.sel[j][3]);
+          }
+          p0[3] = __builtin_amdgcn_perm(a.b, a.a, C.sel[j][4]) | __builtin_amdgcn_perm(a.c, a.b, C.sel[j][5]);
+          p1[3] = __builtin_amdgcn_perm(b.b, b.a, C.sel[j][4]) | __builtin_amdgcn_perm(b.c, b.b, C.sel[j][5]);
+          uint32_t u[4];
 #pragma unroll
           for (int i = 0; i < 4; i++) {
-            const bool up = upv[j][i];
-            const uint32_t sel = selv[j][i];
-            const uint32_t p0 = __builtin_amdgcn_perm(up ? ra[q][j][2] : ra[q][j][1], up ? ra[q][j][1] : ra[q][j][0], sel);
-            const uint32_t p1 = __builtin_amdgcn_perm(up ? rb[q][j][2] : rb[q][j][1], up ? rb[q][j][1] : rb[q][j][0], sel);
-            const uint32_t t0 = dot2u16(p0, cfs[j][i], 0u), t1 = dot2u16(p1, cfs[j][i], 0u);
-            uint32_t v = (((wy0 * (t0 >> 4)) >> 16) + ((wy1 * (t1 >> 4)) >> 16) + 2) >> 2;
-            v = min(v, 255u);
-            packed |= v << (8 * i);
+            const uint32_t t0 = dot2u16(p0[i], C.cf[j][i], 0u) & ~0xffu, t1 = dot2u16(p1[i], C.cf[j][i], 0u) & ~0xffu;
+            u[i] = mulHiU24(wy[q][0], t0) + mulHiU24(wy[q][1], t1);
           }
-          if (liveR[q] && haveG[j]) *reinterpret_cast<uint32_t*>(dst + (unsigned)(dy * dstride + (col * G + j) * 4)) = packed;
+          // (u + 2) >> 2 on two 16-bit fields at a time; bytes 0 and 2 of each pair are the pixels
+          const uint32_t s01 = ((u[0] | (u[1] << 16)) + 0x00020002u) >> 2, s23 = ((u[2] | (u[3] << 16)) + 0x00020002u) >> 2;
+          const uint32_t packed = __builtin_amdgcn_perm(s23, s01, 0x06040200u);
+          if (liveR[q] && C.haveG[j]) *reinterpret_cast<uint32_t*>(dst + (unsigned)(dy * dstride + (C.col * G + j) * 4)) = packed;
         }
       }
     }
+    };
+    if (l == 1 && f >= pb.safeFrom) rows(std::true_type{});
+    else rows(std::false_type{});
+    PYR_STAMP(2 * l);
+    if (tid < nextN) yrows[((l + 1) & 1) * pb.maxRows + tid] = nextY;
+    if (l + 1 < nl) loadCols(l + 1, C);
     // this band of level l is the source of the band of level l + 1 in the same workgroup: the barrier's workgroup-scope
     // release/acquire is all that is needed (the CU's vector L1 is coherent for its own workgroup; an agent-scope
     // fence would write back / invalidate L2 once per level and workgroup and was measured 7x slower)
     __syncthreads();
+    PYR_STAMP(2 * l + 1);
   }
+  PYR_STAMP_RT(37);
+#ifdef ORBX_PYR_STAMPS
+  if (threadIdx.x == 0 && stampWg_ < PYR_STAMP_WGS) {
+    g_pyrStamps[stampWg_ * 40 + 38] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+    g_pyrStamps[stampWg_ * 40 + 39] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
+  }
+#endif
 }
 
 // =================================================================================================
@@ -2216,7 +2300,13 @@ hipError_t launch_pyramid_bands(hipStream_t st, int nFrames, const uint8_t* img0
                                 const Geom& g, const ResizeTab* tab, const PyrBands& pb) {
   if (nFrames <= 0 || g.nlevels <= 1) return hipSuccess;
   dim3 block(256, 1, 1), grid(pb.nBands, nFrames, 1);
-  hipLaunchKernelGGL(k_pyramid_bands, grid, block, 0, st, img0, img0FrameStride, pyr, g, tab, pb);
+  if (pb.maxRows > 256 || pb.maxRows < 1) return hipErrorInvalidValue;  // (the host picks the band count accordingly)
+  if (pb.dual2)
+    hipLaunchKernelGGL(k_pyramid_bands<1>, grid, block, 2 * (size_t)pb.maxRows * sizeof(uint4), st, img0, img0FrameStride, pyr, g,
+                       reinterpret_cast<const uint4*>(tab), pb);
+  else
+    hipLaunchKernelGGL(k_pyramid_bands<0>, grid, block, 2 * (size_t)pb.maxRows * sizeof(uint4), st, img0, img0FrameStride, pyr, g,
+                       reinterpret_cast<const uint4*>(tab), pb);
   return hipGetLastError();
 }
 

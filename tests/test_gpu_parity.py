@@ -757,7 +757,7 @@ def test_banded_pyramid_large_batch(orbx, oracle, nosplit, monkeypatch):
     else:
         monkeypatch.delenv("ORBX_NO_SPLIT", raising=False)
     cap = 1000
-    for (w, h, B) in ((640, 480, 72), (324, 243, 66)):
+    for (w, h, B) in ((640, 480, 72), (324, 243, 66), (322, 243, 40)):  # the last: rows not 4-byte aligned (unaligned 8-byte taps)
         frames = synth.synth_frames(B, w, h, 5200)
         oe = oracle.Extractor(*CANON)
         e = orbx.ORBextractor(*CANON, max_width=w, max_height=h, max_batch=B)
@@ -855,6 +855,34 @@ def test_random_geometries_batched(orbx, oracle):
         compared += 1
         e.close()
     assert compared >= 5
+
+
+@pytest.mark.parametrize("sf,nlev", [(2.0, 3), (1.5, 4), (1.05, 8), (1.01, 3)])
+def test_banded_pyramid_scale_factors(orbx, oracle, sf, nlev):
+    """k_pyramid_bands at the ends of its range: scale 2 (the taps of 4 outputs fill all 8 loaded bytes), a scale close to 1,
+    two scales close to 1; a width that is not a multiple of 4, so the last group of a row is partial."""
+    import torch
+    from orb_slam_tracking_amd import synth
+    w, h, B, cap = 486, 363, 33, 300
+    params = (300, sf, nlev, 20, 7)
+    oe = oracle.Extractor(*params)
+    e = orbx.ORBextractor(*params, max_width=w, max_height=h, max_batch=B)
+    frames = synth.synth_frames(B, w, h, 4100)
+    d_img = torch.from_numpy(frames).cuda()
+    d_k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+    d_d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    e.extract_batch_device(d_img, B, w, h, w, w * h, d_k, d_d, d_n, cap)
+    n = d_n.cpu().numpy()
+    kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, cap)
+    dd = d_d.cpu().numpy().reshape(B, cap, 32)
+    for f in (0, 16, B - 1):
+        _, ko, do = oe(frames[f], cap=cap)
+        assert n[f] == len(ko)
+        _same(kk[f, :n[f]], dd[f, :n[f]], ko, do)
+        for l in range(1, nlev):
+            assert np.array_equal(e.image_pyramid(l, f), oe.level_image(l)), (sf, f, l)
+    e.close()
 
 
 def test_sincos_matches_libm(orbx, ext640, oracle):

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 #define REP 64
@@ -63,6 +64,43 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, unsigned long long* cyc,
       if (OP == 29) OP8_1("v_cvt_f32_u32");
       if (OP == 30) OP8_2("v_sub_u32");
       if (OP == 31) OP8_2("v_xor_b32");
+      if (OP == 32) OP8_2("v_mul_f32");
+      if (OP == 33) OP8_2("v_add_f32");
+      if (OP == 34) OP8_1("v_floor_f32");
+      if (OP == 35) OP8_1("v_cvt_u32_f32");
+      if (OP == 36) OP8_1("v_cvt_f32_ubyte0");
+      if (OP == 37) OP8_1("v_cvt_f32_ubyte2");
+      if (OP == 38) OP8_2("v_mul_hi_u32_u24");
+      if (OP == 39) OP8_3("v_lshl_or_b32");
+      if (OP == 40) OP8_3("v_and_or_b32");
+      if (OP == 41) OP8_3("v_cvt_pk_u8_f32");
+      if (OP == 42) OP8_1("v_rndne_f32");
+      if (OP == 43) OP8_2("v_max_f32");
+      if (OP == 44) OP8_3("v_bfi_b32");
+      if (OP == 45) OP8_3("v_mad_i32_i24");
+      if (OP == 46) OP8_2("v_ashrrev_i32");
+      if (OP == 47) OP8_2("v_lshlrev_b32");
+      if (OP == 48) OP8_2("v_or_b32");
+      if (OP == 49) OP8_2("v_bcnt_u32_b32");
+      if (OP == 50) OP8_3("v_xad_u32");
+      if (OP == 51) OP8_3("v_add_lshl_u32");
+      if (OP == 52) OP8_2("v_mul_hi_u32");
+      if (OP == 53) OP8_1("v_trunc_f32");
+      if (OP == 54) OP8_1("v_cvt_i32_f32");
+      if (OP == 55) OP8_1("v_rcp_f32");
+      if (OP == 56) OP8_2("v_pk_mul_lo_u16");
+      if (OP == 57) OP8_3("v_pk_mad_u16");
+      if (OP == 58) OP8_2("v_pk_lshrrev_b16");
+      if (OP == 59) OP8_1("v_cvt_f32_i32");
+      if (OP == 60) OP8_2("v_ldexp_f32");
+      if (OP == 61) OP8_1("v_not_b32");
+      if (OP == 62) OP8_1("v_fract_f32");
+      if (OP == 63) OP8_2("v_sub_f32");
+      if (OP == 64) OP8_2("v_min_f32");
+      if (OP == 65) OP8_2("v_mul_i32_i24");
+      if (OP == 66) OP8_3("v_fma_f32");
+      if (OP == 100) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k1), "v"(k2));
+      if (OP == 101) asm volatile("v_add_u32_dpp %0, %0, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %1, %1, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %2, %2, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %3, %3, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %4, %4, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %5, %5, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %6, %6, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %7, %7, %8 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k1), "v"(k2));
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -107,5 +145,14 @@ int main() {
   run<1>("v_min3_i32"); run<26>("v_max3_u32"); run<27>("v_med3_i32"); run<2>("v_perm_b32"); run<11>("v_bfe_u32"); run<12>("v_alignbyte_b32");
   run<13>("v_lshl_add_u32"); run<14>("v_add3_u32"); run<24>("v_or3_b32"); run<15>("v_mad_u32_u24"); run<25>("v_sad_u8"); run<6>("v_mul_lo_u32");
   run<3>("v_pk_max_u16"); run<21>("v_pk_add_u16"); run<22>("v_pk_sub_i16"); run<5>("v_dot4_u32_u8"); run<23>("v_dot2_u32_u16");
+  if (getenv("VALU_RATE_MORE")) {
+    run<32>("v_mul_f32"); run<33>("v_add_f32"); run<34>("v_floor_f32"); run<35>("v_cvt_u32_f32"); run<36>("v_cvt_f32_ubyte0"); run<37>("v_cvt_f32_ubyte2");
+    run<38>("v_mul_hi_u32_u24"); run<39>("v_lshl_or_b32"); run<40>("v_and_or_b32"); run<41>("v_cvt_pk_u8_f32"); run<42>("v_rndne_f32"); run<43>("v_max_f32");
+    run<44>("v_bfi_b32"); run<45>("v_mad_i32_i24"); run<46>("v_ashrrev_i32"); run<47>("v_lshlrev_b32"); run<48>("v_or_b32"); run<49>("v_bcnt_u32_b32");
+    run<50>("v_xad_u32"); run<51>("v_add_lshl_u32"); run<52>("v_mul_hi_u32"); run<53>("v_trunc_f32"); run<54>("v_cvt_i32_f32"); run<55>("v_rcp_f32");
+    run<56>("v_pk_mul_lo_u16"); run<57>("v_pk_mad_u16"); run<58>("v_pk_lshrrev_b16"); run<59>("v_cvt_f32_i32"); run<60>("v_ldexp_f32"); run<61>("v_not_b32");
+    run<62>("v_fract_f32"); run<63>("v_sub_f32"); run<64>("v_min_f32"); run<65>("v_mul_i32_i24"); run<66>("v_fma_f32 (again)"); run<100>("v_mov_b32_dpp row_shr");
+    run<101>("v_add_u32_dpp row_shr");
+  }
   return 0;
 }
