@@ -979,6 +979,18 @@ __device__ const IcTables d_ic = makeIcTables();
 // GV = Gaussian Q8 tap set (orbx_set_opencv_variant): 0 = [18,34,48,56,48,34,18] (error diffusion, sum 256: OpenCV >= 4.1.1 /
 // 3.4.7), 1 = [18,34,49,55,49,34,18] (every tap rounded, sum 257: the bit-exact path of 3.4.1 .. 4.1.0 and the integer filter
 // before it; a sum of 2^24 or more saturates to 255)
+// horizontal Gaussian taps as v_dot4 weights: the 7 taps applied to window bytes t .. t + 6 (t = byte shift + column, 0 .. 6),
+// restricted to dword m of the 16 staged bytes
+template <int GV>
+__host__ __device__ constexpr uint32_t descHTap(int t, int m) {
+  const uint32_t T[7] = {18u, 34u, GV ? 49u : 48u, GV ? 55u : 56u, GV ? 49u : 48u, 34u, 18u};
+  uint32_t k = 0;
+  for (int i = 0; i < 4; i++) {
+    const int j = 4 * m + i - t;
+    if (j >= 0 && j < 7) k |= T[j] << (8 * i);
+  }
+  return k;
+}
 template <int GV>
 __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_t* __restrict__ img0, long long img0FrameStride,
                                                        int img0Aligned, const uint8_t* __restrict__ pyr, const Geom g,
@@ -1027,13 +1039,15 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
     const bool active = lane < 4 * PW_WORDS;
     const bool fastx = aligned && xs >= 0 && xs + 4 <= w;
     if (lane == 0) { msum[0] = 0; msum[1] = 0; }
-    if (ky - 21 >= 0 && ky + 21 < h) {  // (uniform) no row of the window is reflected: one address, stepped by 4 rows
-      const uint8_t* p = img + ((ky - 21 + rsub) * stride + xs);
+    if (ky - 21 >= 0 && ky + 21 < h) {  // (uniform) no row of the window is reflected: one lane offset, the base steps by 4 rows
+      // (uniform base + 32-bit lane offset: global_load with an SGPR address, no 64-bit vector arithmetic)
+      const uint32_t voff = (uint32_t)(rsub * stride + xs + 4);  // + 4: xs may be -4
+      const uint8_t* pu = img + ((long long)(ky - 21) * stride - 4);
       const int step = 4 * stride;
 #pragma unroll
       for (int it = 0; it < 11; it++) {
-        if (active && fastx && it * 4 + rsub < PW_ROWS) raw[it * (4 * PW_WORDS) + lane] = *reinterpret_cast<const uint32_t*>(p);
-        p += step;
+        if (active && fastx && it * 4 + rsub < PW_ROWS) raw[it * (4 * PW_WORDS) + lane] = *reinterpret_cast<const uint32_t*>(pu + voff);
+        pu += step;
       }
     } else {
 #pragma unroll
@@ -1090,34 +1104,45 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   const int m10 = msum[0], m01 = msum[1];
   const float angle = fast_atan2_deg((float)m01, (float)m10);
   // ---- horizontal pass: blurred column c (x = kx-18+c) uses window bytes s+c .. s+c+6 of the staged row.
-  //      Item = (row pair, group of 4 columns): 4 dwords per row cover the 10 bytes the 4 columns need; 60 lanes x 4 steps ----
+  //      Item = (row pair, group of 4 columns): 4 dwords per row cover the 10 bytes the 4 columns need; 60 lanes x 4 steps.
+  //      The byte shift s of the window inside its dwords is the same for the whole wave, so instead of shifting the data
+  //      (9 v_alignbyte per row) the TAPS are shifted: for each s the weights of the four dwords are compile-time
+  //      constants (descHTap), zero ones are skipped, and every s costs exactly 10 v_dot4_u32_u8 per row ----
   {
-    constexpr uint32_t T0 = 18u, T1 = 34u, T2 = GV ? 49u : 48u, T3 = GV ? 55u : 56u;
-    constexpr uint32_t K0 = T0 | (T1 << 8) | (T2 << 16) | (T3 << 24), K1 = T2 | (T1 << 8) | (T0 << 16);
     const int rpl = lane / 10, gq = lane - rpl * 10;
+    auto hpass = [&](auto sTag) {
+      constexpr int SH = decltype(sTag)::value;
+#pragma unroll 1
+      for (int it = 0; it < 4; it++) {
+        const int rp = it * 6 + rpl;
+        if (lane < 60 && rp < PW_PAIRS) {
+          uint32_t hs[2][4];
 #pragma unroll
-    for (int it = 0; it < 4; it++) {
-      const int rp = it * 6 + rpl;
-      if (lane < 60 && rp < PW_PAIRS) {
-        uint32_t hs[2][4];
+          for (int h2 = 0; h2 < 2; h2++) {
+            const int row = h2 ? min(2 * rp + 1, PW_ROWS - 1) : 2 * rp;
+            const uint32_t* p = raw + row * PW_WORDS + gq;
+            const uint32_t dd[4] = {p[0], p[1], p[2], p[3]};
 #pragma unroll
-        for (int h2 = 0; h2 < 2; h2++) {
-          const int row = h2 ? min(2 * rp + 1, PW_ROWS - 1) : 2 * rp;
-          const uint32_t* p = raw + row * PW_WORDS + gq;
-          const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
-          const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)s), e1 = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)s),
-                         e2 = __builtin_amdgcn_alignbyte(d3, d2, (uint32_t)s);  // window bytes 4g.., 4g+4.., 4g+8..
-          hs[h2][0] = __builtin_amdgcn_udot4(e0, K0, __builtin_amdgcn_udot4(e1, K1, 0u, false), false);
+            for (int c = 0; c < 4; c++) {
+              uint32_t acc = 0;
 #pragma unroll
-          for (int kk = 1; kk < 4; kk++)
-            hs[h2][kk] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(e1, e0, (uint32_t)kk), K0,
-                                                __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(e2, e1, (uint32_t)kk), K1, 0u, false), false);
+              for (int m = 0; m < 4; m++)
+                if (descHTap<GV>(SH + c, m) != 0u) acc = __builtin_amdgcn_udot4(dd[m], descHTap<GV>(SH + c, m), acc, false);
+              hs[h2][c] = acc;
+            }
+          }
+          uint4 o4;
+          o4.x = hs[0][0] | (hs[1][0] << 16); o4.y = hs[0][1] | (hs[1][1] << 16);
+          o4.z = hs[0][2] | (hs[1][2] << 16); o4.w = hs[0][3] | (hs[1][3] << 16);
+          *reinterpret_cast<uint4*>(&hz2[rp * PW_COLS + 4 * gq]) = o4;
         }
-        uint4 o4;
-        o4.x = hs[0][0] | (hs[1][0] << 16); o4.y = hs[0][1] | (hs[1][1] << 16);
-        o4.z = hs[0][2] | (hs[1][2] << 16); o4.w = hs[0][3] | (hs[1][3] << 16);
-        *reinterpret_cast<uint4*>(&hz2[rp * PW_COLS + 4 * gq]) = o4;
       }
+    };
+    switch (s) {  // wave-uniform
+      case 0: hpass(std::integral_constant<int, 0>{}); break;
+      case 1: hpass(std::integral_constant<int, 1>{}); break;
+      case 2: hpass(std::integral_constant<int, 2>{}); break;
+      default: hpass(std::integral_constant<int, 3>{}); break;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1170,10 +1195,15 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   for (int wq = 0; wq < 4; wq++) {
     const float4 pt = pat[wq];
     const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
-    const int r0 = __float2int_rn(x0 * sn + y0 * cs), c0 = __float2int_rn(x0 * cs - y0 * sn);
-    const int r1 = __float2int_rn(x1 * sn + y1 * cs), c1 = __float2int_rn(x1 * cs - y1 * sn);
-    const int t0 = bl[(18 + r0) * PW_COLS + 18 + c0];
-    const int t1 = bl[(18 + r1) * PW_COLS + 18 + c1];
+    // cvRound of the rotated coordinates (cpp:184-188) and the byte address (18 + r) * 40 + 18 + c in one go: v + 1.5 * 2^23
+    // rounds to nearest-even at integer granularity and leaves 0x4B400000 + rint(v) in the float's bits; the low 24 bits
+    // (0x400000 + r) go through v_mad_u32_u24, the constants are taken off at the end
+    constexpr float MAGIC = 12582912.f;
+    constexpr uint32_t OFF = 40u * 0x400000u + 0x4B400000u - (18u * PW_COLS + 18u);
+    const uint32_t ir0 = __float_as_uint((x0 * sn + y0 * cs) + MAGIC), ic0 = __float_as_uint((x0 * cs - y0 * sn) + MAGIC);
+    const uint32_t ir1 = __float_as_uint((x1 * sn + y1 * cs) + MAGIC), ic1 = __float_as_uint((x1 * cs - y1 * sn) + MAGIC);
+    const int t0 = bl[(ir0 & 0xffffffu) * (uint32_t)PW_COLS + ic0 - OFF];
+    const int t1 = bl[(ir1 & 0xffffffu) * (uint32_t)PW_COLS + ic1 - OFF];
     words[wq] = __ballot(t0 < t1);
   }
   const long long o = (long long)f * capacity + i;
