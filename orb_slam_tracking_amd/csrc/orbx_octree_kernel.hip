@@ -88,22 +88,31 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
                                                      int* __restrict__ maxN, int deferBig) {
   constexpr int MCAP = 4 * QMAX, FCAP = 2 * QMAX;
   static_assert((NMAX & (NMAX - 1)) == 0 && (MCAP & (MCAP - 1)) == 0, "sort buffers must be powers of two");
-  // LDS budget (QMAX 256): NMAX 2048: 16 + 8 + 8 + 12 + 4 + 3 KB = 51 KB -> three workgroups per CU;
-  //                        NMAX 1024:  8 + 8 + 4 + 12 + 2 + 3 KB = 37 KB -> four (launch_octree picks the instance).
-  //   nodes[] is dead once the node records exist, so the partial pass's buffers (sized, pending, childCnt) live in it;
-  //   hiOf[] (steps 3-4) shares its space with the candidate position list (step 1 only).
+  // LDS budget (QMAX 256): NMAX 2048: 16 + 8 + 4 + 6 + 2 + 3 KB = 39 KB -> FOUR workgroups per CU (it was 51 KB and three
+  //                        until sorted positions became 16-bit here and alone[] a function of div[]);
+  //                        NMAX 1024:  8 + 8 + 3.4 + 6 + 1 + 3 KB = 29.4 KB -> five (launch_octree picks the instance).
+  //   nodes[] is dead once the node records exist, so the partial pass's buffers (sized, pending, childCnt) live in it, and
+  //   it is not yet written while step 1 reads the candidate position list, which therefore lives there too;
+  //   hiOf[] (steps 3-4) shares its space with the parallel std::sort replay's scratch (partial pass).
   __shared__ u64 keysNodes[NMAX + MCAP];
   u64* keys = keysNodes;
   u64* nodes = keysNodes + NMAX;
-  __shared__ uint32_t candL[NMAX];
-  __shared__ int nodeLo[MCAP + FCAP], nodeHi[MCAP + FCAP];
-  __shared__ uint8_t div[NMAX + 4], alone[NMAX];
+  static_assert(MCAP * 8 >= NMAX * 4, "the candidate position list must fit into nodes[]");
+  uint32_t* candL = reinterpret_cast<uint32_t*>(nodes);
+  // the sort replay never sees more than QMAX entries here (the partial pass's list is shorter than the quota): 256 keys
+  constexpr int PARCAP = 256;
+  static_assert(QMAX <= PARCAP, "parallel-replay capacity");
+  constexpr int HI_DWORDS = (NMAX / 2 > OCT_PAR_SCR_FOR(PARCAP)) ? NMAX / 2 : OCT_PAR_SCR_FOR(PARCAP);
+  __shared__ uint32_t hiPar[HI_DWORDS];
+  uint16_t* hiOf = reinterpret_cast<uint16_t*>(hiPar);
+  static_assert(NMAX <= 65535, "16-bit sorted positions");
+  __shared__ uint16_t nodeLo[MCAP + FCAP], nodeHi[MCAP + FCAP];
+  __shared__ uint8_t div[NMAX + 4];
   __shared__ uint8_t nodeDepth[MCAP + FCAP], nodeAlive[MCAP + FCAP];
   static_assert(2 * QMAX * 8 + 2 * QMAX * 4 + QMAX * 4 <= MCAP * 8, "partial-pass buffers must fit in nodes[]");
   u64* sized = nodes;                                             // [2 * QMAX]
   int* pending = reinterpret_cast<int*>(nodes + 2 * QMAX);        // [2 * QMAX]
   int* childCnt = pending + 2 * QMAX;                             // [QMAX]
-  uint32_t* hiOf = candL;
   const int level = blockIdx.y, f = blockIdx.x + P.frame0;  // level-major dispatch, see launch_octree
   int* nOut = &nselLevel[f * P.nlevels + level];
   static_assert(NMAX + MCAP >= OCT_SORT_LDS, "keys[] + nodes[] double as the sort exchange buffer of the global-scratch path");
@@ -114,10 +123,8 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   const int n = gatherCandidates(cellCnt, P.lev[level].nCells, P.lev[level].segCap, candL, NMAX, threadIdx.x, gws);
   if (threadIdx.x == 0 && maxN) atomicMax(&maxN[level], n);  // feedback for the next batch's choice of instance
   if (n <= NMAX && P.lev[level].quota <= QMAX) {
-    constexpr int PARCAP = OCT_PAR_SCR_FOR(512) <= NMAX ? 512 : 256;  // what fits into candL[NMAX]
-    static_assert(OCT_PAR_SCR_FOR(PARCAP) <= NMAX, "parallel-replay scratch must fit into the position list's space");
-    OctScratch S{keys, nodes, div, alone, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, childCnt, candL, segBase, nullptr,
-                 candL /* hiOf / position list space: dead during the partial pass */, PARCAP};
+    OctScratchT<uint16_t> S{keys, nodes, div, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, childCnt, candL, segBase, nullptr,
+                            hiPar /* hiOf's space: dead during the partial pass */, PARCAP};
     octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, MCAP, FCAP, QMAX);
     __syncthreads();
     if (threadIdx.x == 0) redo = (*nOut == -2);  // a node table overflowed the LDS layout
