@@ -753,7 +753,8 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   // is large enough to fill the device with (bands x frames) workgroups; otherwise one launch per level
   static const bool noBands = getenv("ORBX_NO_BANDS") != nullptr;  // diagnostics
   static const int bandsEnv = getenv("ORBX_PYR_BANDS") ? atoi(getenv("ORBX_PYR_BANDS")) : 0;  // diagnostics
-  bool banded = nl > 1 && ctx->pyrInfo.ok && a.aligned0 && n >= 32 && !noBands;  // (dword loads: level 0 rows 4-byte aligned)
+  static const int bandsMin = getenv("ORBX_BANDS_MIN_FRAMES") ? atoi(getenv("ORBX_BANDS_MIN_FRAMES")) : 32;  // diagnostics
+  bool banded = nl > 1 && ctx->pyrInfo.ok && a.aligned0 && n >= bandsMin && !noBands;  // (dword loads: level 0 rows 4-byte aligned)
   PyrBands pb{};
   if (banded) {  // a band's rows of one level are staged by one pass of the workgroup: at most 256
     // 7 bands: the kernel's 72 VGPRs let 7 workgroups share a CU, so 128 or 256 frames x 7 bands are one resident round
