@@ -979,6 +979,41 @@ __device__ const IcTables d_ic = makeIcTables();
 // GV = Gaussian Q8 tap set (orbx_set_opencv_variant): 0 = [18,34,48,56,48,34,18] (error diffusion, sum 256: OpenCV >= 4.1.1 /
 // 3.4.7), 1 = [18,34,49,55,49,34,18] (every tap rounded, sum 257: the bit-exact path of 3.4.1 .. 4.1.0 and the integer filter
 // before it; a sum of 2^24 or more saturates to 255)
+// The 512 rotated sample points lie in the disc r^2 + c^2 <= 365 around the keypoint ((13, 13) is the farthest pattern point:
+// 18.38, and rounding moves a point by at most 0.71), not in the whole 37 x 37 square.  A (row pair, 4-column) item of the
+// horizontal pass is needed only if one of the four vertical items it feeds holds a point of the disc: 190 of 220, i.e. three
+// steps of 64 lanes instead of four of 60.  Entry = row pair << 4 | column group, 0xffff = idle.
+struct DescHItems {
+  uint16_t v[192];
+};
+constexpr DescHItems makeDescHItems() {
+  DescHItems t{};
+  bool vneed[19 + 3][10] = {};
+  for (int q = 0; q < 19; q++)
+    for (int g = 0; g < 10; g++)
+      for (int r = 2 * q; r < 2 * q + 2; r++)
+        for (int c = 4 * g; c < 4 * g + 4; c++)
+          if (r <= 36 && c <= 36 && (r - 18) * (r - 18) + (c - 18) * (c - 18) <= 365) vneed[q][g] = true;
+  int n = 0;
+  for (int rp = 0; rp < 22; rp++)
+    for (int g = 0; g < 10; g++) {
+      bool need = false;
+      for (int q = rp - 3; q <= rp; q++)
+        if (q >= 0 && q < 19 && vneed[q][g]) need = true;
+      if (need && n < 192) t.v[n++] = (uint16_t)(rp << 4 | g);
+    }
+  for (; n < 192; n++) t.v[n] = 0xffff;
+  return t;
+}
+__device__ const DescHItems d_descHItems = makeDescHItems();
+constexpr int descHItemCount() {
+  const DescHItems t = makeDescHItems();
+  int n = 0;
+  for (int i = 0; i < 192; i++) n += t.v[i] != 0xffff;
+  return n;
+}
+static_assert(descHItemCount() == 190, "horizontal items of the sampling disc (all of them must fit the three steps)");
+
 // horizontal Gaussian taps as v_dot4 weights: the 7 taps applied to window bytes t .. t + 6 (t = byte shift + column, 0 .. 6),
 // restricted to dword m of the 16 staged bytes
 template <int GV>
@@ -1016,6 +1051,9 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   float4 pat[4];
 #pragma unroll
   for (int wq = 0; wq < 4; wq++) pat[wq] = reinterpret_cast<const float4*>(d_patternf.v)[wq * 64 + lane];
+  uint32_t hitem[3];  // this lane's items of the horizontal pass
+#pragma unroll
+  for (int it = 0; it < 3; it++) hitem[it] = d_descHItems.v[it * 64 + lane];
   uint32_t* raw = lds;                               // [43][13] dwords
   uint32_t* hz2 = raw + PW_RAW_WORDS;                // [22][40] row-pair packed horizontal sums (16-byte aligned rows)
   uint32_t* bl32 = raw;                              // [38][10] dwords = blurred bytes, row stride 40 (raw is dead by then)
@@ -1104,18 +1142,18 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   const int m10 = msum[0], m01 = msum[1];
   const float angle = fast_atan2_deg((float)m01, (float)m10);
   // ---- horizontal pass: blurred column c (x = kx-18+c) uses window bytes s+c .. s+c+6 of the staged row.
-  //      Item = (row pair, group of 4 columns): 4 dwords per row cover the 10 bytes the 4 columns need; 60 lanes x 4 steps.
+  //      Item = (row pair, group of 4 columns): 4 dwords per row cover the 10 bytes the 4 columns need; the 190 items of
+  //      the sampling disc (d_descHItems) in 3 steps.
   //      The byte shift s of the window inside its dwords is the same for the whole wave, so instead of shifting the data
   //      (9 v_alignbyte per row) the TAPS are shifted: for each s the weights of the four dwords are compile-time
   //      constants (descHTap), zero ones are skipped, and every s costs exactly 10 v_dot4_u32_u8 per row ----
   {
-    const int rpl = lane / 10, gq = lane - rpl * 10;
     auto hpass = [&](auto sTag) {
       constexpr int SH = decltype(sTag)::value;
-#pragma unroll 1
-      for (int it = 0; it < 4; it++) {
-        const int rp = it * 6 + rpl;
-        if (lane < 60 && rp < PW_PAIRS) {
+#pragma unroll
+      for (int it = 0; it < 3; it++) {
+        const int rp = (int)(hitem[it] >> 4), gq = (int)(hitem[it] & 15u);
+        if (hitem[it] != 0xffffu) {
           uint32_t hs[2][4];
 #pragma unroll
           for (int h2 = 0; h2 < 2; h2++) {
