@@ -753,14 +753,20 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   // is large enough to fill the device with (bands x frames) workgroups; otherwise one launch per level
   static const bool noBands = getenv("ORBX_NO_BANDS") != nullptr;  // diagnostics
   static const int bandsEnv = getenv("ORBX_PYR_BANDS") ? atoi(getenv("ORBX_PYR_BANDS")) : 0;  // diagnostics
-  static const int bandsMin = getenv("ORBX_BANDS_MIN_FRAMES") ? atoi(getenv("ORBX_BANDS_MIN_FRAMES")) : 32;  // diagnostics
-  bool banded = nl > 1 && ctx->pyrInfo.ok && a.aligned0 && n >= bandsMin && !noBands;  // (dword loads: level 0 rows 4-byte aligned)
+  static const int bandsMin = getenv("ORBX_BANDS_MIN_FRAMES") ? atoi(getenv("ORBX_BANDS_MIN_FRAMES")) : 0;  // diagnostics
+  // from 32 frames per stream, or from 8 when the frames are large (16 frames 1080p: 0.43 -> 0.30 ms; 16 frames 640x480 are
+  // better off with the per-level launches: 0.252 vs 0.263 ms per 32-frame call)
+  const bool enough = bandsMin > 0 ? n >= bandsMin : (n >= 32 || (n >= 8 && (long long)n * g.L[0].w * g.L[0].h >= (16ll << 20)));
+  bool banded = nl > 1 && ctx->pyrInfo.ok && a.aligned0 && enough && !noBands;  // (dword loads: level 0 rows 4-byte aligned)
   PyrBands pb{};
   if (banded) {  // a band's rows of one level are staged by one pass of the workgroup: at most 256
-    // 7 bands: the kernel's 72 VGPRs let 7 workgroups share a CU, so 128 or 256 frames x 7 bands are one resident round
-    // (measured on 256 frames: 4 bands 0.168 ms, 6 0.161, 7 0.160, 8 0.192, 12 0.198; rows that bands share cost 5 % at 4
-    // bands, 11 % at 8, 23 % at 16)
-    int K = bandsEnv > 0 ? bandsEnv : (n >= 64 ? 7 : 14);
+    // Bands: rows that neighbouring bands share cost ~8 rows of level 1 per band, so a band should own >= ~60 of them (7 bands
+    // for 640x480: the kernel's 72 VGPRs let 7 workgroups share a CU, and 128 or 256 frames x 7 bands are one resident round;
+    // measured on 256 frames: 4 bands 0.168 ms, 6 0.161, 7 0.160, 8 0.192, 12 0.198; shared rows 5 % at 4 bands, 11 % at 8,
+    // 23 % at 16); a small batch takes more, thinner bands instead, to give every CU a workgroup or two
+    const int rowBands = std::min(std::max(g.L[1].h / 60, 7), ORBX_PYR_BANDS_MAX);
+    int K = n * rowBands >= 512 ? rowBands : std::min(ORBX_PYR_BANDS_MAX, std::max(rowBands, (512 + n - 1) / n));
+    if (bandsEnv > 0) K = bandsEnv;
     pb = computePyrBands(ctx, K);
     while (pb.maxRows > 256 && K < ORBX_PYR_BANDS_MAX) pb = computePyrBands(ctx, K = std::min(2 * K, ORBX_PYR_BANDS_MAX));
     banded = pb.maxRows <= 256;
