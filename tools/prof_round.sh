@@ -6,7 +6,6 @@ TAG=$1
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT $R/profiles
 cd /tmp && export TMPDIR=/tmp
 cd $R
-python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats2 -- python3 bench.py --steps 20 --warmup 2 --regions 1 --no-cpu-baseline --no-single-frame > $OUT/stats2.log 2>&1
 export ORBX_NO_SPLIT=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 2 --regions 1 --no-cpu-baseline --no-single-frame > $OUT/stats.log 2>&1
@@ -20,6 +19,9 @@ cp $OUT/pmc_table.txt $R/profiles/${TAG}_pmc_table.txt
 python3 tools/pmc_summary.py $OUT/sq $OUT/sq4 $OUT/fetch $OUT/write > $R/profiles/${TAG}_pmc_counters.txt
 cp $OUT/stats/*/*kernel_stats.csv $R/profiles/${TAG}_kernel_stats_single_stream.csv
 cp $OUT/stats2/*/*kernel_stats.csv $R/profiles/${TAG}_kernel_stats.csv
+# the bench line last: its roofline object reads the newest profiles/r*_pmc.json, i.e. the counters collected just above
+unset ORBX_NO_SPLIT
+python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 cp $OUT/bench.json $R/profiles/${TAG}_bench.json
 mkdir -p $R/gpurun_out/profiles_$TAG && cp $R/profiles/${TAG}_* $R/gpurun_out/profiles_$TAG/
 cat $OUT/pmc_table.txt
