@@ -260,8 +260,8 @@ class ORBextractor:
         if image.strides[1] != 1:
             image = np.ascontiguousarray(image)
         h, w = image.shape
-        kps = np.zeros(self.capacity, KEYPOINT_DTYPE)
-        desc = np.zeros((self.capacity, 32), np.uint8)
+        kps = np.empty(self.capacity, KEYPOINT_DTYPE)   # (the first n entries are written, only those are returned)
+        desc = np.empty((self.capacity, 32), np.uint8)
         n = ctypes.c_int(0)
         r = self._L.orbx_extract(self._h, _ptr(image), w, h, image.strides[0], int(vLappingArea[0]), int(vLappingArea[1]),
                                  _ptr(kps), _ptr(desc), self.capacity, ctypes.byref(n))

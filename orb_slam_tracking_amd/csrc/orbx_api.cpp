@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -141,6 +142,13 @@ struct orbx_ctx {
   uint8_t* dDesc = nullptr;
   // pinned host mirrors
   int* hNsel = nullptr;
+  // results of a call on a few host frames are written by the descriptor kernel straight into mapped page-locked memory
+  // (no copy commands, no second synchronisation behind them): orbx_extract_batch with at most pinFrames frames
+  orbx_keypoint* hKpsPin = nullptr;
+  orbx_keypoint* hKpsPinDev = nullptr;
+  uint8_t* hDescPin = nullptr;
+  uint8_t* hDescPinDev = nullptr;
+  int pinFrames = 0;
   // matcher
   int* dMatchScratch = nullptr;
   size_t matchScratchInts = 0;
@@ -499,13 +507,14 @@ void freeAll(orbx_ctx* ctx) {
                  ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, ctx->dIn, ctx->dKps, ctx->dDesc};
   for (void* p : dev)
     if (p) (void)hipFree(p);
-  void* host[] = {ctx->hNsel, ctx->hFlags, ctx->hMaxN, ctx->hWide};
+  void* host[] = {ctx->hNsel, ctx->hFlags, ctx->hMaxN, ctx->hWide, ctx->hKpsPin, ctx->hDescPin};
   for (void* p : host)
     if (p) (void)hipHostFree(p);
   ctx->dPyr = nullptr; ctx->dCand = nullptr; ctx->dCandCount = nullptr; ctx->dCellCount = nullptr; ctx->dMaxN = nullptr;
   ctx->dTab = nullptr; ctx->dCells = nullptr; ctx->dSel = nullptr; ctx->dNsel = nullptr; ctx->dSelStage = nullptr; ctx->dNselLevel = nullptr;
   ctx->dOctScratch = nullptr; ctx->dIn = nullptr; ctx->dKps = nullptr; ctx->dDesc = nullptr;
   ctx->hNsel = nullptr; ctx->hFlags = nullptr; ctx->hMaxN = nullptr; ctx->hWide = nullptr;
+  ctx->hKpsPin = nullptr; ctx->hDescPin = nullptr; ctx->hKpsPinDev = nullptr; ctx->hDescPinDev = nullptr; ctx->pinFrames = 0;
   ctx->hNselDev = nullptr; ctx->hFlagsDev = nullptr; ctx->hMaxNDev = nullptr; ctx->hWideDev = nullptr;
   ctx->curW = ctx->curH = ctx->curStride0 = 0;  // the tables on the device are gone with dTab
   ctx->lastB = 0;
@@ -580,6 +589,11 @@ int allocAll(orbx_ctx* ctx) {
   if (hipHostGetDevicePointer((void**)&ctx->hMaxNDev, ctx->hMaxN, 0) != hipSuccess) return ORBX_E_HIP;
   if (hipHostGetDevicePointer((void**)&ctx->hNselDev, ctx->hNsel, 0) != hipSuccess) return ORBX_E_HIP;
   if (hipHostGetDevicePointer((void**)&ctx->hFlagsDev, ctx->hFlags, 0) != hipSuccess) return ORBX_E_HIP;
+  ctx->pinFrames = (int)std::min<size_t>(B, 4);
+  ALLOCH(ctx->hKpsPin, (size_t)ctx->pinFrames * cap * sizeof(orbx_keypoint));
+  ALLOCH(ctx->hDescPin, (size_t)ctx->pinFrames * cap * 32);
+  if (hipHostGetDevicePointer((void**)&ctx->hKpsPinDev, ctx->hKpsPin, 0) != hipSuccess) return ORBX_E_HIP;
+  if (hipHostGetDevicePointer((void**)&ctx->hDescPinDev, ctx->hDescPin, 0) != hipSuccess) return ORBX_E_HIP;
   ALLOCH(ctx->hWide, 16);
   ctx->hWide[0] = ctx->hWide[1] = 0;
   if (hipHostGetDevicePointer((void**)&ctx->hWideDev, ctx->hWide, 0) != hipSuccess) return ORBX_E_HIP;
@@ -1208,6 +1222,12 @@ int orbx_extract_batch(orbx_ctx* ctx, int n_frames, const uint8_t* imgs, int wid
   const int dstride = alignUp(width, 64);
   const size_t dfs = (size_t)dstride * height;
   const int cap = std::max(ctx->selCap, 1);
+  static const bool latTrace = getenv("ORBX_LAT_TRACE") != nullptr;
+  static double latAcc[5] = {0, 0, 0, 0, 0};
+  static long latN = 0;
+  auto nowUs = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
+  double tt[5] = {0, 0, 0, 0, 0};
+  if (latTrace) tt[0] = nowUs();
   for (int f0 = 0; f0 < n_frames; f0 += ctx->maxB) {
     const int B = std::min(ctx->maxB, n_frames - f0);
     if (frame_stride_bytes == (size_t)stride * height || B == 1) {
@@ -1219,12 +1239,25 @@ int orbx_extract_batch(orbx_ctx* ctx, int n_frames, const uint8_t* imgs, int wid
         HIPCHK(hipMemcpy2DAsync(ctx->dIn + f * dfs, dstride, imgs + (size_t)(f0 + f) * frame_stride_bytes, stride, width, height,
                                 hipMemcpyHostToDevice, ctx->st));
     }
-    int r = extractCore(ctx, B, ctx->dIn, width, height, dstride, (long long)dfs, ctx->dKps, ctx->dDesc, cap, nullptr, nullptr);
+    if (latTrace) tt[1] = nowUs();
+    static const bool noDirect = getenv("ORBX_NO_DIRECT_OUT") != nullptr;  // diagnostics
+    const bool direct = B <= ctx->pinFrames && !noDirect;
+    int r = extractCore(ctx, B, ctx->dIn, width, height, dstride, (long long)dfs, direct ? ctx->hKpsPinDev : ctx->dKps,
+                        direct ? ctx->hDescPinDev : ctx->dDesc, cap, nullptr, nullptr);
     if (r != ORBX_OK) return r;
+    if (latTrace) tt[2] = nowUs();
     int maxN = 0;
     for (int f = 0; f < B; f++) {
       n_out[f0 + f] = ctx->hNsel[f];
       maxN = std::max(maxN, ctx->hNsel[f]);
+    }
+    if (direct) {  // the synchronous extractCore has waited for the descriptor kernel: the results are in host memory
+      for (int f = 0; f < B; f++) {
+        const size_t nf = (size_t)ctx->hNsel[f];
+        memcpy(kps + (size_t)(f0 + f) * capacity, ctx->hKpsPin + (size_t)f * cap, nf * sizeof(orbx_keypoint));
+        memcpy(desc32 + (size_t)(f0 + f) * capacity * 32, ctx->hDescPin + (size_t)f * cap * 32, nf * 32);
+      }
+      maxN = 0;
     }
     if (maxN > 0) {
       // one strided copy per array: row f = the first maxN entries of frame f (entries between n_out[f] and maxN are
@@ -1235,7 +1268,15 @@ int orbx_extract_batch(orbx_ctx* ctx, int n_frames, const uint8_t* imgs, int wid
       HIPCHK(hipMemcpy2DAsync(desc32 + (size_t)f0 * capacity * 32, (size_t)32 * capacity, ctx->dDesc, (size_t)32 * cap,
                               (size_t)32 * maxN, B, hipMemcpyDeviceToHost, ctx->st));
     }
-    HIPCHK(hipStreamSynchronize(ctx->st));
+    if (latTrace) tt[3] = nowUs();
+    if (!direct) HIPCHK(hipStreamSynchronize(ctx->st));
+    if (latTrace) {
+      tt[4] = nowUs();
+      for (int i = 1; i < 5; i++) latAcc[i] += tt[i] - tt[i - 1];
+      if (++latN % 100 == 0)
+        fprintf(stderr, "orbx lat trace (us, mean of %ld): h2d enqueue %.1f, extractCore %.1f, d2h enqueue %.1f, final sync %.1f\n", latN,
+                latAcc[1] / latN, latAcc[2] / latN, latAcc[3] / latN, latAcc[4] / latN);
+    }
     for (int f = 0; f < B; f++) {
       const int n = n_out[f0 + f];
       int mono = n;
