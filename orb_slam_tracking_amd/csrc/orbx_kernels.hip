@@ -979,6 +979,27 @@ __device__ const IcTables d_ic = makeIcTables();
 // GV = Gaussian Q8 tap set (orbx_set_opencv_variant): 0 = [18,34,48,56,48,34,18] (error diffusion, sum 256: OpenCV >= 4.1.1 /
 // 3.4.7), 1 = [18,34,49,55,49,34,18] (every tap rounded, sum 257: the bit-exact path of 3.4.1 .. 4.1.0 and the integer filter
 // before it; a sum of 2^24 or more saturates to 255)
+// Diagnostic build only (-DORBX_DESC_STAMPS): per wave, s_memtime at the start, when the window loads have landed, after
+// IC_Angle, after the horizontal / vertical blur passes and at the end; tools/desc_stamps.py prints the shares.
+#ifdef ORBX_DESC_STAMPS
+#define DS_STAMP_WAVES (1 << 18)
+__device__ uint32_t g_descStamps[DS_STAMP_WAVES * 8];
+#define DS_STAMP(k)                                                                                     \
+  do {                                                                                                  \
+    if (lane == 0 && dsWave_ < DS_STAMP_WAVES) g_descStamps[dsWave_ * 8 + (k)] = (uint32_t)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+extern "C" int orbx_diag_desc_stamps(uint32_t* out, int nWaves) {  // out: nWaves x 8 dwords; nWaves < 0: clear the buffer
+  if (nWaves < 0) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_descStamps)) != hipSuccess) return -1;
+    return (int)hipMemset(p, 0, sizeof(uint32_t) * 8 * DS_STAMP_WAVES);
+  }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_descStamps), sizeof(uint32_t) * 8 * (size_t)nWaves);
+}
+#else
+#define DS_STAMP(k) do { } while (0)
+#endif
+
 // The 512 rotated sample points lie in the disc r^2 + c^2 <= 365 around the keypoint ((13, 13) is the farthest pattern point:
 // 18.38, and rounding moves a point by at most 0.71), not in the whole 37 x 37 square.  A (row pair, 4-column) item of the
 // horizontal pass is needed only if one of the four vertical items it feeds holds a point of the disc: 190 of 220, i.e. three
@@ -1043,6 +1064,10 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   const int grp = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int i = grp * DESC_WAVES + (threadIdx.x >> 6);
   if (i >= nsel[f]) return;  // wave-uniform; the waves of a workgroup never synchronise with each other
+#ifdef ORBX_DESC_STAMPS
+  const unsigned dsWave_ = (unsigned)((blockIdx.y * gridDim.x + blockIdx.x) * DESC_WAVES + (threadIdx.x >> 6));
+#endif
+  DS_STAMP(0);
   // Loads that do not depend on the keypoint are issued first, so that their latency runs under the window fetch: the
   // disc-row weights of IC_Angle (lane = disc row) and this lane's four point pairs of the BRIEF pattern.
   const int icRow = min(lane, 30), icAv = icRow < 15 ? 15 - icRow : icRow - 15;
@@ -1114,6 +1139,10 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
       }
     }
   }
+#ifdef ORBX_DESC_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);  // charge the staging phase with its loads
+#endif
+  DS_STAMP(1);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   // ---- IC_Angle (cpp:103-159) on the un-blurred window: pixel (u, v) is row 21+v, byte s+21+u.  Lane = disc row v;
@@ -1141,6 +1170,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   __builtin_amdgcn_wave_barrier();
   const int m10 = msum[0], m01 = msum[1];
   const float angle = fast_atan2_deg((float)m01, (float)m10);
+  DS_STAMP(2);
   // ---- horizontal pass: blurred column c (x = kx-18+c) uses window bytes s+c .. s+c+6 of the staged row.
   //      Item = (row pair, group of 4 columns): 4 dwords per row cover the 10 bytes the 4 columns need; the 190 items of
   //      the sampling disc (d_descHItems) in 3 steps.
@@ -1183,6 +1213,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
       default: hpass(std::integral_constant<int, 3>{}); break;
     }
   }
+  DS_STAMP(3);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   // ---- vertical pass + rounding with v_dot2_u32_u16 on row pairs: blurred rows 2q and 2q+1 both use pairs q..q+3,
@@ -1220,6 +1251,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
       if (gq >= 10) { gq -= 10; q++; }
     }
   }
+  DS_STAMP(4);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   // ---- steered BRIEF (cpp:169-228).  cos/sin of the f32 argument are evaluated in f64 and rounded to f32 ----
@@ -1258,6 +1290,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
     kp.class_id = -1;
     kps[o] = kp;
   }
+  DS_STAMP(5);
 }
 
 // =================================================================================================
