@@ -1063,6 +1063,9 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   // XCDs stay balanced.
   const int grp = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int i = grp * DESC_WAVES + (threadIdx.x >> 6);
+  // (the keypoint record is fetched together with the frame's count, not behind it: count, record and window were three
+  // dependent global loads and, by tools/desc_stamps.py, 63 % of a wave's lifetime)
+  const SelKp k = sel[(long long)f * g.selCap + min(i, g.selCap - 1)];
   if (i >= nsel[f]) return;  // wave-uniform; the waves of a workgroup never synchronise with each other
 #ifdef ORBX_DESC_STAMPS
   const unsigned dsWave_ = (unsigned)((blockIdx.y * gridDim.x + blockIdx.x) * DESC_WAVES + (threadIdx.x >> 6));
@@ -1085,7 +1088,6 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   int* msum = reinterpret_cast<int*>(hz2 + PW_PAIRS * PW_COLS);  // [2] moment sums of IC_Angle
   static_assert(BL_ROWS_PAD * (PW_COLS / 4) <= PW_ROWS * PW_WORDS, "blurred bytes must fit in the raw window");
   static_assert(PW_ROWS * PW_WORDS <= PW_RAW_WORDS && PW_RAW_WORDS % 4 == 0, "raw window padding");
-  const SelKp k = sel[(long long)f * g.selCap + i];
   // the keypoint is wave-uniform: keep its fields in SGPRs so that the level geometry comes through scalar loads
   const int level = __builtin_amdgcn_readfirstlane((int)k.level);
   const int kx = __builtin_amdgcn_readfirstlane((int)k.x), ky = __builtin_amdgcn_readfirstlane((int)k.y);
