@@ -219,7 +219,7 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
   // batch) they are deferred to k_octree_global, which gives each of them 1024 threads; otherwise the LDS kernel's own
   // workgroup handles the rare outlier and no second kernel is launched.
   // nHint = largest candidate count of a unit in the previous batch (0 = unknown): with 6 % headroom below 1024 the
-  // smaller instance runs four workgroups per CU instead of three.
+  // smaller instance (30 KB of LDS) runs five workgroups per CU instead of four.
   static const bool noSmall = getenv("ORBX_OCT_NO_SMALL") != nullptr;  // diagnostics: always the 2048-candidate instance
   if (maxQuota >= (1 << 30)) {  // test hook (orbx_debug_distribute_device variant 1): every unit on global scratch
     hipLaunchKernelGGL(k_octree_global, grid, dim3(1024), 0, st, cand, cellCount, P, selStage, nselLevel, scratch, 1);
