@@ -782,12 +782,12 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   bool banded = nl > 1 && ctx->pyrInfo.ok && a.aligned0 && enough && !noBands;  // (dword loads: level 0 rows 4-byte aligned)
   PyrBands pb{};
   if (banded) {  // a band's rows of one level are staged by one pass of the workgroup: at most 256
-    // Bands: rows that neighbouring bands share cost ~8 rows of level 1 per band, so a band should own >= ~60 of them (7 bands
-    // for 640x480: the kernel's 72 VGPRs let 7 workgroups share a CU, and 128 or 256 frames x 7 bands are one resident round;
-    // measured on 256 frames: 4 bands 0.168 ms, 6 0.161, 7 0.160, 8 0.192, 12 0.198; shared rows 5 % at 4 bands, 11 % at 8,
-    // 23 % at 16); a small batch takes more, thinner bands instead, to give every CU a workgroup or two
-    const int rowBands = std::min(std::max(g.L[1].h / 60, 7), ORBX_PYR_BANDS_MAX);
-    int K = n * rowBands >= 512 ? rowBands : std::min(ORBX_PYR_BANDS_MAX, std::max(rowBands, (512 + n - 1) / n));
+    // Bands: neighbouring bands share ~8 rows of level 1 per band, so bands should be fat: 3 per 640x480 frame (512 threads
+    // per workgroup, 72 VGPRs -> three workgroups per CU; 128 or 256 frames x 3 bands = one resident round or two).  Measured on
+    // 256 frames: 2 bands 0.158 ms, 3 0.151, 4 0.170, 6 0.190 (with 256-thread workgroups: 4 0.168, 7 0.160, 8 0.192, 12 0.198).
+    // A small batch takes more, thinner bands instead, to give every CU a workgroup
+    const int rowBands = std::min(std::max(g.L[1].h / 130, 3), ORBX_PYR_BANDS_MAX);
+    int K = n * rowBands >= 256 ? rowBands : std::min(ORBX_PYR_BANDS_MAX, std::max(rowBands, (256 + n - 1) / n));
     if (bandsEnv > 0) K = bandsEnv;
     pb = computePyrBands(ctx, K);
     while (pb.maxRows > 256 && K < ORBX_PYR_BANDS_MAX) pb = computePyrBands(ctx, K = std::min(2 * K, ORBX_PYR_BANDS_MAX));
