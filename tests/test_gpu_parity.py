@@ -885,6 +885,33 @@ def test_banded_pyramid_scale_factors(orbx, oracle, sf, nlev):
     e.close()
 
 
+def test_banded_pyramid_frames_that_overlap(orbx, oracle):
+    """A frame stride smaller than a frame (sliding windows over one tall image): nothing is known to follow any frame's last row,
+    so every frame takes level 1 of k_pyramid_bands through the clamped single-dword loads (PyrBands.safeFrom = 0)."""
+    import torch
+    from orb_slam_tracking_amd import synth
+    w, h, B, cap = 400, 300, 34, 300
+    params = (300, 1.2, 6, 20, 7)
+    step = (h // 2) * w                                     # frame f starts half a frame after frame f - 1
+    tall = synth.synth_frames(1, w, (B - 1) * (h // 2) + h, 4300)[0]
+    d_img = torch.from_numpy(tall).cuda()
+    oe = oracle.Extractor(*params)
+    e = orbx.ORBextractor(*params, max_width=w, max_height=h, max_batch=B)
+    d_k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+    d_d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    e.extract_batch_device(d_img, B, w, h, w, step, d_k, d_d, d_n, cap)
+    n = d_n.cpu().numpy()
+    kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, cap)
+    dd = d_d.cpu().numpy().reshape(B, cap, 32)
+    for f in (0, 1, 17, B - 1):
+        frame = tall[f * (h // 2):f * (h // 2) + h]
+        _, ko, do = oe(frame, cap=cap)
+        assert n[f] == len(ko), f
+        _same(kk[f, :n[f]], dd[f, :n[f]], ko, do)
+    e.close()
+
+
 def test_sincos_matches_libm(orbx, ext640, oracle):
     """The descriptor's cos / sin (f64 evaluation of the f32 angle, rounded to f32, cpp:173-174): the device's f64 sincos and
     the host libm agree after the rounding for every angle fastAtan2 can produce that is tried here -- all 360 * 2^7
