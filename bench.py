@@ -3,8 +3,9 @@
 
 One step = one pass of the hot path over one batch of synthetic 640x480 frames that are already resident in HBM:
   orbx_extract_match_batch_device_async: extraction of B frames -> SearchForInitialization of the B/2 consecutive pairs
-  (window 100, ratio 0.9), issued stream-ordered with at most two batches in flight (every batch is complete when the
-  clock stops)  ->  (N > 1) RCCL all_gather of the per-frame keypoint counts.
+  (window 100, ratio 0.9), issued stream-ordered, whole batches on the three lanes of the context (orbx_set_pipeline_depth:
+  at most three batches in flight; every batch is complete when the clock stops)  ->  (N > 1) RCCL all_gather of the
+  per-frame keypoint counts.
 Frames are sharded per rank (weak scaling: B frames per GPU), one process per GPU.  The steps rotate through four distinct
 input sets (315 MB per GPU, more than the 256 MB Infinity Cache), so no step finds its input cache-resident.
 Prints ONE JSON line on rank 0 (see the task contract): metric / value / roofline / cpu_baseline.
@@ -87,6 +88,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--regions", type=int, default=5, help="timed regions of --steps steps (the first one gives `value`)")
+    ap.add_argument("--depth", type=int, default=3, help="pipeline depth of the stream-ordered call (orbx_set_pipeline_depth): whole "
+                    "batches on this many lanes; 0 = the two-half-batches mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame-per-call figure (profiling passes: keeps every launch of a kernel the same size)")
     ap.add_argument("--cpu-reps", type=int, default=30, help="timed repetitions per thread of the CPU baseline (>= 30 by protocol)")
@@ -127,10 +130,13 @@ def main():
     # four input sets: the frames, and their vertical / horizontal / both mirror images (pairs stay pairs of one scene)
     host_sets = [frames, frames[:, ::-1, :], frames[:, :, ::-1], frames[:, ::-1, ::-1]]
     d_imgs = [torch.from_numpy(np.ascontiguousarray(s)).to(dev) for s in host_sets]
-    # two sets of output arrays: the batches are issued stream-ordered (orbx_extract_match_batch_device_async), batch k + 1
-    # is issued while batch k runs, and two batches in flight must not share their outputs
+    # one set of output arrays per batch in flight: the batches are issued stream-ordered
+    # (orbx_extract_match_batch_device_async), and batches in flight together must not share their outputs
+    # pipeline depth: whole batches on `depth` lanes of the context (orbx_set_pipeline_depth); 0 = two half batches on two streams
+    depth = args.depth
+    nout = max(2, depth)
     outs = []
-    for _ in range(2):
+    for _ in range(nout):
         outs.append(dict(k=torch.zeros(B * cap * 28, dtype=torch.uint8, device=dev),
                          d=torch.zeros(B * cap * 32, dtype=torch.uint8, device=dev),
                          n=torch.zeros(B, dtype=torch.int32, device=dev),
@@ -141,6 +147,8 @@ def main():
     counts_all = torch.zeros(B * world, dtype=torch.int32, device=cdev)
 
     ext = orbx.ORBextractor(*PARAMS, max_width=W, max_height=H, max_batch=B, device=local_rank)
+    if depth > 0:
+        ext.set_pipeline_depth(depth)
 
     # N > 1: the all_gather of batch k's counts (RCCL over xGMI) is issued asynchronously from a snapshot of the counts once
     # batch k has been waited for, i.e. it runs under the kernels of batch k + 1; it is waited for before the next one is
@@ -158,28 +166,28 @@ def main():
     def gather_counts(k):
         finish_gather()
         snap = snaps[k & 1]
-        snap.copy_(outs[k & 1]["n"])  # batch k has been waited for: its counts are final.  (The copy runs on torch's stream;
+        snap.copy_(outs[k % nout]["n"])  # batch k has been waited for: its counts are final.  (The copy runs on torch's stream;
         # the binding orders the context's streams behind it before the next batch rewrites that array: orbx_order_after.)
         pending[0] = dist.all_gather_into_tensor(counts_all, snap, async_op=True)
 
     def step():
         # one call = the whole hot path of the batch: extraction of B frames and SearchForInitialization of the B/2
-        # consecutive pairs, issued behind the previous batch (at most two in flight)
+        # consecutive pairs, issued behind the previous batches (at most `nout` in flight)
         k = nstep[0]
-        o = outs[k & 1]
+        o = outs[k % nout]
         ext.extract_match_batch_device_async(d_imgs[k & 3], B, W, H, W, W * H, o["k"], o["d"], o["n"], first, second, (0, W, 0, H),
                                              o["m"], o["nm"], None, 100, 0.9, True, cap)
         nstep[0] = k + 1
-        if world > 1 and ngathered[0] < k:  # batch k - 1 is the oldest in flight: wait for it, gather its counts
-            ext.wait_one()
-            gather_counts(k - 1)
-            ngathered[0] = k
+        if world > 1 and k + 1 - ngathered[0] >= nout:  # as many in flight as there are output sets: wait for the oldest
+            ext.wait_one()                              # (batch ngathered) and gather its counts
+            gather_counts(ngathered[0])
+            ngathered[0] += 1
 
     def barrier():
         ext.wait()  # every batch issued so far is complete
-        if world > 1 and ngathered[0] < nstep[0]:
-            gather_counts(nstep[0] - 1)  # the last batch's counts (the earlier ones were gathered in step())
-            ngathered[0] = nstep[0]
+        while world > 1 and ngathered[0] < nstep[0]:  # the counts of the last batches (the earlier ones were gathered in step())
+            gather_counts(ngathered[0])
+            ngathered[0] += 1
         finish_gather()
         torch.cuda.synchronize()
         if world > 1:
@@ -222,7 +230,7 @@ def main():
     ext.profile_enable(False)
     if stage_prof is None:
         stage_prof, stage_steps = prof, args.steps
-    d_n, d_nm = outs[(nstep[0] - 1) & 1]["n"], outs[(nstep[0] - 1) & 1]["nm"]
+    d_n, d_nm = outs[(nstep[0] - 1) % nout]["n"], outs[(nstep[0] - 1) % nout]["nm"]
 
     if rank == 0:
         n_kp = float(d_n.float().mean().item())
@@ -293,13 +301,14 @@ def main():
                                    "HBM (4 input sets rotating, 315 MB per GPU), %d consecutive-pair SearchForInitialization "
                                    "(window 100, ratio 0.9)" % (B, B // 2),
                        "frames_per_gpu": B, "pairs_per_gpu": B // 2, "mean_keypoints": n_kp, "mean_nmatches": nm_mean,
+                       "pipeline_depth": depth,
                        "parallelism": "frames sharded per GPU (%d ranks), RCCL all_gather of keypoint counts" % world},
             "spread": {"regions": len(region_dts), "steps_per_region": args.steps, "median": rates[len(rates) // 2],
                        "min": rates[0], "max": rates[-1], "note": "`value` is the first region; the others follow it back to back"},
             "roofline": roof,
             "roofline_other_kernels": others,
             "stage_ms_per_step": {s: stage_prof[s][0] / stage_steps for s in stage_prof},
-            "stage_ms_source": "warmup steps, every stage bracketed by HIP events (sums over the two half-batch streams); the "
+            "stage_ms_source": "warmup steps, every stage bracketed by HIP events (sums over the lanes / half-batch streams); the "
                                "timed steps bracket only the dominant kernel",
         }
         # second figure: the call the reference actually makes -- one frame per call through the host API

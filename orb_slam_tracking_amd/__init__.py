@@ -96,6 +96,7 @@ def lib() -> ctypes.CDLL:
     L.orbx_extract_match_batch_device_async.argtypes = [vp, i32, vp, i32, i32, i32, sz, vp, vp, i32, vp, i32, vp, vp,
                                                   ctypes.POINTER(_Bounds), i32, f32, i32, vp, vp, vp]
     L.orbx_set_opencv_variant.argtypes = [vp, i32, i32]
+    L.orbx_set_pipeline_depth.argtypes = [vp, i32]
     L.orbx_wait_one.argtypes = [vp]
     L.orbx_wait.argtypes = [vp]
     L.orbx_order_after.argtypes = [vp, vp]
@@ -339,6 +340,11 @@ class ORBextractor:
                                                           _ptr(second), ctypes.byref(b), int(windowSize), float(nnratio),
                                                           int(bool(checkOri)), _ptr(d_matches12), _ptr(d_nmatches), _ptr(d_stats))
         self._check(r, "orbx_extract_match_batch_device_async")
+
+    def set_pipeline_depth(self, depth: int) -> None:
+        """depth >= 1: every stream-ordered batch goes, whole, to the next of `depth` lanes (own stream, own buffers); at most `depth`
+        batches in flight, which need `depth` different output arrays.  0 (default): two half batches on the context's two streams."""
+        self._check(self._L.orbx_set_pipeline_depth(self._h, int(depth)), "orbx_set_pipeline_depth")
 
     def wait_one(self) -> None:
         """Waits for the oldest batch in flight."""

@@ -188,6 +188,11 @@ struct orbx_ctx {
   hipEvent_t evDone[2]{};   // end of the batch with that parity on st
   hipEvent_t evDone2[2]{};  // ... and on st2 (only when the batch used it: done2Used)
   bool done2Used[2]{};
+  // orbx_set_pipeline_depth: the stream-ordered batches go, whole, to the next of `depth` LANES -- child contexts with their own
+  // buffers and stream -- instead of as two half batches onto this context's two streams
+  std::vector<orbx_ctx*> lanes;
+  unsigned laneIssue = 0, laneDone = 0;  // batches issued to / waited for on the lanes (round-robin in issue order)
+  bool noSplit = false;                  // (a lane) never cuts a batch into halves
   unsigned seqIssue = 0;   // batches issued so far
   int pending = 0;         // issued and not yet waited for (0 .. 2)
   int parity = 0;          // of the batch being issued
@@ -953,8 +958,23 @@ int waitOldest(orbx_ctx* ctx) {
   }
   return ORBX_OK;
 }
+int laneWaitOne(orbx_ctx* ctx) {  // the oldest batch issued to the lanes
+  if (ctx->lanes.empty() || ctx->laneDone == ctx->laneIssue) return ORBX_OK;
+  orbx_ctx* c = ctx->lanes[ctx->laneDone % ctx->lanes.size()];
+  const int r = waitOldest(c);
+  if (r != ORBX_OK) ctx->err = c->err;
+  if (r != ORBX_E_HIP || c->pending == 0) ctx->laneDone++;
+  return r;
+}
+
 int waitAll(orbx_ctx* ctx) {
   int r = ORBX_OK;
+  while (ctx->laneDone != ctx->laneIssue) {
+    const unsigned before = ctx->laneDone;
+    const int q = laneWaitOne(ctx);
+    if (q == ORBX_E_HIP && ctx->laneDone == before) return q;
+    if (r == ORBX_OK) r = q;
+  }
   while (ctx->pending > 0) {
     const int q = waitOldest(ctx);
     if (q == ORBX_E_HIP) return q;  // (pending may not have moved)
@@ -1015,7 +1035,7 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
   if (nPairs > 0) armMatch(ctx, *match, dKps, dDesc, dN, capacity);
 
   static const int splitMin = getenv("ORBX_NO_SPLIT") ? (1 << 30) : 16;
-  const bool split = ctx->st2 != nullptr && B >= splitMin;
+  const bool split = ctx->st2 != nullptr && B >= splitMin && !ctx->noSplit;
   const int n0 = split ? ((B / 2) & ~1) : B;
   // pairs whose frames both lie in one half can run right behind that half's extraction, on its stream; this needs
   // the pair list to be ordered [half 0][half 1][rest] (true for consecutive pairs (2k, 2k+1))
@@ -1145,6 +1165,8 @@ int orbx_create(const orbx_params* params, int device_id, int max_width, int max
 
 void orbx_destroy(orbx_ctx* ctx) {
   if (!ctx) return;
+  for (orbx_ctx* c : ctx->lanes) orbx_destroy(c);
+  ctx->lanes.clear();
   (void)hipSetDevice(ctx->device);
   if (ctx->st) (void)hipStreamSynchronize(ctx->st);
   if (ctx->st2) (void)hipStreamSynchronize(ctx->st2);
@@ -1178,6 +1200,7 @@ int orbx_set_opencv_variant(orbx_ctx* ctx, int gaussian_variant, int gray_varian
   if (w == ORBX_E_HIP) return w;
   ctx->gaussVariant = gaussian_variant;
   ctx->grayVariant = gray_variant;
+  for (orbx_ctx* c : ctx->lanes) { c->gaussVariant = gaussian_variant; c->grayVariant = gray_variant; }
   return ORBX_OK;
 }
 
@@ -1495,13 +1518,55 @@ int orbx_extract_match_batch_device_async(orbx_ctx* ctx, int n_frames, const uin
                                           int32_t* d_n_out, int n_pairs, const int32_t* h_first, const int32_t* h_second,
                                           const orbx_bounds* bounds, int window_size, float nnratio, int check_orientation,
                                           int32_t* d_matches12, int32_t* d_nmatches, int32_t* d_stats) {
+  if (ctx && !ctx->lanes.empty()) {  // pipeline mode: the whole batch to the next lane, at most one batch per lane in flight
+    if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+    const unsigned L = (unsigned)ctx->lanes.size();
+    if (ctx->laneIssue - ctx->laneDone >= L) {
+      const int w = laneWaitOne(ctx);  // (an error of that earlier batch is returned by the call that has to wait for it)
+      if (w != ORBX_OK) return w;
+    }
+    orbx_ctx* c = ctx->lanes[ctx->laneIssue % L];
+    const int r = extractMatch(c, n_frames, d_imgs, width, height, stride, frame_stride_bytes, d_kps, d_desc32, capacity, d_n_out,
+                               n_pairs, h_first, h_second, bounds, window_size, nnratio, check_orientation, d_matches12, d_nmatches,
+                               d_stats, true);
+    if (r != ORBX_OK) { ctx->err = c->err; return r; }
+    ctx->laneIssue++;
+    return ORBX_OK;
+  }
   return extractMatch(ctx, n_frames, d_imgs, width, height, stride, frame_stride_bytes, d_kps, d_desc32, capacity, d_n_out, n_pairs,
                       h_first, h_second, bounds, window_size, nnratio, check_orientation, d_matches12, d_nmatches, d_stats, true);
+}
+
+int orbx_set_pipeline_depth(orbx_ctx* ctx, int depth) {
+  if (!ctx || depth < 0 || depth > 8) return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  const int w = waitAll(ctx);
+  if (w == ORBX_E_HIP) return w;
+  for (orbx_ctx* c : ctx->lanes) orbx_destroy(c);
+  ctx->lanes.clear();
+  ctx->laneIssue = ctx->laneDone = 0;
+  for (int i = 0; i < depth; i++) {
+    orbx_ctx* c = nullptr;
+    const int r = orbx_create(&ctx->p, ctx->device, ctx->maxW, ctx->maxH, ctx->maxB, nullptr, &c);
+    if (r != ORBX_OK) {
+      ctx->err = "orbx_set_pipeline_depth: a lane could not be created";
+      for (orbx_ctx* q : ctx->lanes) orbx_destroy(q);
+      ctx->lanes.clear();
+      return r;
+    }
+    c->noSplit = true;
+    c->gaussVariant = ctx->gaussVariant;
+    c->grayVariant = ctx->grayVariant;
+    c->profMask = ctx->profMask;
+    ctx->lanes.push_back(c);
+  }
+  return ORBX_OK;
 }
 
 int orbx_wait_one(orbx_ctx* ctx) {
   if (!ctx) return ORBX_E_BADARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  if (ctx->laneDone != ctx->laneIssue) return laneWaitOne(ctx);
   return waitOldest(ctx);
 }
 
@@ -1520,6 +1585,7 @@ int orbx_order_after(orbx_ctx* ctx, void* stream) {
   HIPCHK(hipEventRecord(ctx->evOrder, s));
   HIPCHK(hipStreamWaitEvent(ctx->st, ctx->evOrder, 0));
   if (ctx->st2) HIPCHK(hipStreamWaitEvent(ctx->st2, ctx->evOrder, 0));
+  for (orbx_ctx* c : ctx->lanes) HIPCHK(hipStreamWaitEvent(c->st, ctx->evOrder, 0));
   return ORBX_OK;
 }
 
@@ -1534,6 +1600,10 @@ int orbx_order_before(orbx_ctx* ctx, void* stream) {
   if (ctx->st2) {
     HIPCHK(hipEventRecord(ctx->evOrder, ctx->st2));
     HIPCHK(hipStreamWaitEvent(s, ctx->evOrder, 0));
+  }
+  for (orbx_ctx* c : ctx->lanes) {
+    HIPCHK(hipEventRecord(c->evOrder, c->st));
+    HIPCHK(hipStreamWaitEvent(s, c->evOrder, 0));
   }
   return ORBX_OK;
 }
@@ -1822,23 +1892,30 @@ int orbx_to_gray(orbx_ctx* ctx, const uint8_t* img, int width, int height, int s
 int orbx_profile_enable(orbx_ctx* ctx, int on) {
   if (!ctx) return ORBX_E_BADARG;
   ctx->profMask = on ? (1u << ORBX_STAGE_COUNT) - 1u : 0u;
+  for (orbx_ctx* c : ctx->lanes) c->profMask = ctx->profMask;
   return ORBX_OK;
 }
 int orbx_profile_stages(orbx_ctx* ctx, unsigned stage_mask) {
   if (!ctx) return ORBX_E_BADARG;
   ctx->profMask = stage_mask & ((1u << ORBX_STAGE_COUNT) - 1u);
+  for (orbx_ctx* c : ctx->lanes) c->profMask = ctx->profMask;
   return ORBX_OK;
 }
 int orbx_profile_reset(orbx_ctx* ctx) {
   if (!ctx) return ORBX_E_BADARG;
   for (int s = 0; s < ORBX_STAGE_COUNT; s++) { ctx->ms[s] = 0; ctx->launches[s] = 0; }
+  for (orbx_ctx* c : ctx->lanes)
+    for (int s = 0; s < ORBX_STAGE_COUNT; s++) { c->ms[s] = 0; c->launches[s] = 0; }
   return ORBX_OK;
 }
 int orbx_profile_get(orbx_ctx* ctx, double* ms, int64_t* launches) {
   if (!ctx) return ORBX_E_BADARG;
-  for (int s = 0; s < ORBX_STAGE_COUNT; s++) {
-    if (ms) ms[s] = ctx->ms[s];
-    if (launches) launches[s] = ctx->launches[s];
+  for (int s = 0; s < ORBX_STAGE_COUNT; s++) {  // (this context's own calls plus what its lanes ran)
+    double m = ctx->ms[s];
+    int64_t n = ctx->launches[s];
+    for (const orbx_ctx* c : ctx->lanes) { m += c->ms[s]; n += c->launches[s]; }
+    if (ms) ms[s] = m;
+    if (launches) launches[s] = n;
   }
   return ORBX_OK;
 }

@@ -545,6 +545,86 @@ def test_async_batches_equal_sync(orbx):
     e.close()
 
 
+def test_pipeline_lanes_equal_sync(orbx):
+    """orbx_set_pipeline_depth(3): seven stream-ordered batches go, whole, to three lanes (three in flight, a fourth call waits for
+    the oldest) and give what the synchronous call gives; batch size, pair list and frame size change on the way; synchronous
+    calls in between; depth back to 0; stage profiling sums over the lanes."""
+    import torch
+    from orb_slam_tracking_amd import synth
+    B, cap, w, h = 34, 1000, 640, 480
+    e = orbx.ORBextractor(*CANON, max_width=w, max_height=h, max_batch=B)
+    first = np.arange(0, B - 1, 2, dtype=np.int32)
+    imgs = [torch.from_numpy(synth.synth_frames(B, w, h, seed0=700 + 40 * i)).cuda() for i in range(4)]
+
+    def outs():
+        return dict(k=torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"), d=torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda"),
+                    n=torch.zeros(B, dtype=torch.int32, device="cuda"), m=torch.full(((B // 2) * cap,), -5, dtype=torch.int32, device="cuda"),
+                    nm=torch.zeros(B // 2, dtype=torch.int32, device="cuda"))
+
+    def same(got, ref, nb=B):
+        g = {k: v.cpu().numpy() for k, v in got.items()}
+        n = g["n"][:nb]
+        assert np.array_equal(n, ref["n"][:nb]) and np.array_equal(g["nm"][:nb // 2], ref["nm"][:nb // 2])
+        kk, rk = g["k"].reshape(B, cap * 28), ref["k"].reshape(B, cap * 28)
+        dd, rd = g["d"].reshape(B, cap * 32), ref["d"].reshape(B, cap * 32)
+        mm, rm = g["m"].reshape(B // 2, cap), ref["m"].reshape(B // 2, cap)
+        for f in range(nb):
+            assert np.array_equal(kk[f, :n[f] * 28], rk[f, :n[f] * 28]) and np.array_equal(dd[f, :n[f] * 32], rd[f, :n[f] * 32])
+        for p_ in range(nb // 2):
+            assert np.array_equal(mm[p_, :n[2 * p_]], rm[p_, :n[2 * p_]])
+
+    ref = []
+    for im in imgs:
+        o = outs()
+        e.extract_match_batch_device(im, B, w, h, w, w * h, o["k"], o["d"], o["n"], first, first + 1, (0, w, 0, h), o["m"], o["nm"],
+                                     None, 100, 0.9, True, cap)
+        ref.append({k: v.cpu().numpy().copy() for k, v in o.items()})
+    e.set_pipeline_depth(3)
+    e.profile_enable(True)
+    e.profile_reset()
+    sets = [outs() for _ in range(3)]
+    order = [0, 1, 2, 3, 1, 0, 2]
+    done = []
+    for j, i in enumerate(order):
+        o = sets[j % 3]
+        if j >= 3:  # the set is about to be reused: its batch (j - 3) is the oldest in flight
+            e.wait_one()
+            same(o, ref[order[j - 3]])
+            done.append(j - 3)
+        e.extract_match_batch_device_async(imgs[i], B, w, h, w, w * h, o["k"], o["d"], o["n"], first, first + 1, (0, w, 0, h), o["m"],
+                                           o["nm"], None, 100, 0.9, True, cap)
+    e.wait()
+    for j in range(len(order) - 3, len(order)):
+        same(sets[j % 3], ref[order[j]])
+    prof = e.profile_get()
+    e.profile_enable(False)
+    assert all(prof[s][1] > 0 and prof[s][0] > 0 for s in ("pyramid", "fast", "select", "describe", "match"))
+    # a synchronous call between stream-ordered ones; then a smaller batch with another pair list on the lanes
+    o = outs()
+    e.extract_match_batch_device_async(imgs[3], B, w, h, w, w * h, sets[0]["k"], sets[0]["d"], sets[0]["n"], first, first + 1,
+                                       (0, w, 0, h), sets[0]["m"], sets[0]["nm"], None, 100, 0.9, True, cap)
+    e.extract_match_batch_device(imgs[1], B, w, h, w, w * h, o["k"], o["d"], o["n"], first, first + 1, (0, w, 0, h), o["m"], o["nm"],
+                                 None, 100, 0.9, True, cap)
+    same(o, ref[1])
+    same(sets[0], ref[3])
+    B2 = 20
+    f2 = np.arange(0, B2, 2, dtype=np.int32)
+    e.extract_match_batch_device_async(imgs[2], B2, w, h, w, w * h, sets[1]["k"], sets[1]["d"], sets[1]["n"], f2, f2 + 1, (0, w, 0, h),
+                                       sets[1]["m"], sets[1]["nm"], None, 100, 0.9, True, cap)
+    e.extract_match_batch_device_async(imgs[0], B, w, h, w, w * h, sets[2]["k"], sets[2]["d"], sets[2]["n"], first, first + 1,
+                                       (0, w, 0, h), sets[2]["m"], sets[2]["nm"], None, 100, 0.9, True, cap)
+    e.wait()
+    same(sets[1], ref[2], nb=B2)
+    same(sets[2], ref[0])
+    # back to the two-halves mode
+    e.set_pipeline_depth(0)
+    e.extract_match_batch_device_async(imgs[1], B, w, h, w, w * h, sets[0]["k"], sets[0]["d"], sets[0]["n"], first, first + 1,
+                                       (0, w, 0, h), sets[0]["m"], sets[0]["nm"], None, 100, 0.9, True, cap)
+    e.wait()
+    same(sets[0], ref[1])
+    e.close()
+
+
 def test_wide_matcher_issued_late(orbx, oracle):
     """The wide matcher kernels travel with a batch only while batches need them.  After a run of batches that did not (few
     keypoints), batches that do get them at their wait - also stream-ordered, two in flight - and then with the batch again."""

@@ -17,7 +17,7 @@ def outs():
     return dict(k=torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"), d=torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda"),
                 n=torch.zeros(B, dtype=torch.int32, device="cuda"), m=torch.zeros((B // 2) * cap, dtype=torch.int32, device="cuda"),
                 nm=torch.zeros(B // 2, dtype=torch.int32, device="cuda"))
-for nctx in (1, 2, 3):
+for nctx in [int(x) for x in os.environ.get("EXP_NCTX", "1,2,3").split(",")]:
     ctxs = [orbx.ORBextractor(1000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B) for _ in range(nctx)]
     O = [[outs(), outs()] for _ in range(nctx)]
     cnt = [0] * nctx
