@@ -3,7 +3,7 @@ R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export ORBX_NO_SPLIT=1
 cd $R
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $OUT/grbm -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-single-frame > $OUT/grbm.log 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $OUT/grbm -- python3 bench.py --depth 0 --steps 3 --warmup 1 --no-cpu-baseline --no-single-frame > $OUT/grbm.log 2>&1
 python3 - <<PY
 import csv,glob,collections,re
 f=glob.glob("$OUT/grbm/*/*_counter_collection.csv")[0]

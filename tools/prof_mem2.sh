@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export ORBX_NO_SPLIT=1
 cd $R
-P="python3 bench.py --steps 3 --warmup 1 --regions 1 --no-cpu-baseline --no-single-frame"
+P="python3 bench.py --depth 0 --steps 3 --warmup 1 --regions 1 --no-cpu-baseline --no-single-frame"
 pass() { n=$1; shift; timeout -k 10 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -- $P > $OUT/$n.log 2>&1; echo "pass $n rc=$?" | tee -a $OUT/progress.txt; }
 pass l1 TCP_TCC_READ_REQ_LATENCY TCP_TCC_READ_REQ TCP_TCP_LATENCY TCP_TOTAL_ACCESSES
 pass l2a TCC_HIT TCC_MISS TCC_READ TCC_WRITE
