@@ -178,7 +178,9 @@ int orbx_extract_match_batch_device_async(orbx_ctx* ctx, int n_frames, const uin
  * `depth` batches are in flight (the call that would exceed it first waits for the oldest), so batches in flight together need
  * `depth` different output arrays.  Whole batches on three lanes measure 305 k frames/s against 285 k with the two halves
  * (256 frames 640x480 per batch, MI355X).  Waits for everything in flight; 0 <= depth <= 8; costs depth times the context's
- * device memory.  (The reference has no counterpart: it extracts one frame per call, Frame.cpp:58-60.) */
+ * device memory.  orbx_download_pyramid and the profile / debug hooks of the context keep referring to the batches the context
+ * ran itself (synchronous calls, depth 0); orbx_profile_get adds what the lanes ran.  (The reference has no counterpart: it
+ * extracts one frame per call, Frame.cpp:58-60.) */
 int orbx_set_pipeline_depth(orbx_ctx* ctx, int depth);
 int orbx_wait_one(orbx_ctx* ctx); /* the oldest batch in flight (ORBX_OK if there is none) */
 int orbx_wait(orbx_ctx* ctx);     /* all batches in flight */
