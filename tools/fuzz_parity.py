@@ -61,6 +61,9 @@ def stateful(trials):
                   int(rng.integers(5, 30)), int(rng.integers(0, 6)))
         MW, MH, MB = 900, 700, 36
         e = orbx.ORBextractor(*params, max_width=MW, max_height=MH, max_batch=MB)
+        depth = int(rng.choice([0, 0, 2, 3]))   # pipeline lanes for the stream-ordered calls of this context (two sets in flight at most)
+        if depth:
+            e.set_pipeline_depth(depth)
         oe = O.Extractor(*params)
         cap = params[0] + 64
         sets = [dict(k=torch.zeros(MB * cap * 28, dtype=torch.uint8, device="cuda"), d=torch.zeros(MB * cap * 32, dtype=torch.uint8, device="cuda"),
@@ -136,7 +139,7 @@ def stateful(trials):
         e.wait()
         for it in pend:
             ok &= verify(it)
-        print("context %d: params=%r, %d calls ->" % (c, params, ncalls), "ok" if ok else "MISMATCH", flush=True)
+        print("context %d: params=%r, depth %d, %d calls ->" % (c, params, depth, ncalls), "ok" if ok else "MISMATCH", flush=True)
         bad += not ok
         e.close()
     print("FUZZ %s: %d contexts (stateful), %d mismatching, %.0f s" % ("OK" if bad == 0 else "FAILED", trials, bad, time.time() - t0))
