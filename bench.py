@@ -3,8 +3,8 @@
 
 One step = one pass of the hot path over one batch of synthetic 640x480 frames that are already resident in HBM:
   orbx_extract_match_batch_device_async: extraction of B frames -> SearchForInitialization of the B/2 consecutive pairs
-  (window 100, ratio 0.9), issued stream-ordered, whole batches on the three lanes of the context (orbx_set_pipeline_depth:
-  at most three batches in flight; every batch is complete when the clock stops)  ->  (N > 1) RCCL all_gather of the
+  (window 100, ratio 0.9), issued stream-ordered, whole batches on four lanes of the context (orbx_set_pipeline_depth:
+  at most four batches in flight; every batch is complete when the clock stops)  ->  (N > 1) RCCL all_gather of the
   per-frame keypoint counts.
 Frames are sharded per rank (weak scaling: B frames per GPU), one process per GPU.  The steps rotate through four distinct
 input sets (315 MB per GPU, more than the 256 MB Infinity Cache), so no step finds its input cache-resident.
@@ -88,8 +88,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--regions", type=int, default=5, help="timed regions of --steps steps (the first one gives `value`)")
-    ap.add_argument("--depth", type=int, default=3, help="pipeline depth of the stream-ordered call (orbx_set_pipeline_depth): whole "
+    ap.add_argument("--depth", type=int, default=4, help="pipeline depth of the stream-ordered call (orbx_set_pipeline_depth): whole "
                     "batches on this many lanes; 0 = the two-half-batches mode")
+    ap.add_argument("--input-sets", type=int, default=4, help="distinct input sets the steps rotate through (default 4 = 315 MB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame-per-call figure (profiling passes: keeps every launch of a kernel the same size)")
     ap.add_argument("--cpu-reps", type=int, default=30, help="timed repetitions per thread of the CPU baseline (>= 30 by protocol)")
@@ -129,6 +130,10 @@ def main():
     frames = synth.synth_frames(hi - lo, W, H, seed0=1000 + lo // 2)
     # four input sets: the frames, and their vertical / horizontal / both mirror images (pairs stay pairs of one scene)
     host_sets = [frames, frames[:, ::-1, :], frames[:, :, ::-1], frames[:, ::-1, ::-1]]
+    if args.input_sets == 5:  # (experiments: a rotation length that no lane count divides)
+        host_sets.append(np.ascontiguousarray(frames[::-1]))
+    host_sets = host_sets[:max(1, min(args.input_sets, 5))]
+    nsets = len(host_sets)
     d_imgs = [torch.from_numpy(np.ascontiguousarray(s)).to(dev) for s in host_sets]
     # one set of output arrays per batch in flight: the batches are issued stream-ordered
     # (orbx_extract_match_batch_device_async), and batches in flight together must not share their outputs
@@ -175,7 +180,7 @@ def main():
         # consecutive pairs, issued behind the previous batches (at most `nout` in flight)
         k = nstep[0]
         o = outs[k % nout]
-        ext.extract_match_batch_device_async(d_imgs[k & 3], B, W, H, W, W * H, o["k"], o["d"], o["n"], first, second, (0, W, 0, H),
+        ext.extract_match_batch_device_async(d_imgs[k % nsets], B, W, H, W, W * H, o["k"], o["d"], o["n"], first, second, (0, W, 0, H),
                                              o["m"], o["nm"], None, 100, 0.9, True, cap)
         nstep[0] = k + 1
         if world > 1 and k + 1 - ngathered[0] >= nout:  # as many in flight as there are output sets: wait for the oldest

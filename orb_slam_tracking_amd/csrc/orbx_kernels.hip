@@ -1419,10 +1419,11 @@ __device__ void matchWidePrep(const int pair, const int* __restrict__ pairFirst,
 // All threads walk the trains together, so train data are LDS broadcasts.
 // -------------------------------------------------------------------------------------------------
 // Up to MJ_CAP (256) octave-0 queries / eligible trains per pair, MJ_P (4) threads per query (thread t works for query
-// t % MJ_CAP on the trains e with e % MJ_P == t / MJ_CAP), MJ_CP (8) listed trains (distance below dmax) of one query
-// per part - 32 KB of lists, so that the workgroup finds room beside the other chain's kernels (24 per part = 98 KB
-// measured 0.3 % slower); a larger or fuller pair is marked MATCH_PENDING for the wide path below.
-#define MJ_K 4
+// t % MJ_CAP on the trains e with e % MJ_P == t / MJ_CAP), MJ_CP (16) listed trains (distance below dmax) of one query
+// per part - 64 KB of lists.  (8 per part, 32 KB, let a pair or two of every bench batch overflow into the wide path, whose
+// kernels then travelled with every batch: 302 k frames/s against 305 k with 16; 24 per part = 98 KB was measured 0.3 %
+// slower in round 1.)  A larger or fuller pair is marked MATCH_PENDING for the wide path below.
+#define MJ_K 8   // (4 let two or three pairs of every other bench batch overflow: a train with five claimants)
 #define MJ_SWEEPS 64
 
 template <int MJ_CAP, int MJ_P, int MJ_CP>
@@ -2495,7 +2496,7 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
   const int capl = matchWideCap(capacity);
   const size_t lds = (size_t)capl * 12;  // head + tOrd + nextQ + outD: 48 KB at MW_CAP
   if (wideMode != 2)
-    hipLaunchKernelGGL((k_match_jacobi<256, 4, 8>), dim3(nPairs), dim3(1024), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
+    hipLaunchKernelGGL((k_match_jacobi<256, 4, 16>), dim3(nPairs), dim3(1024), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
                        matches12, nmatches, stats, scratch, stride, capl, hostWide);
   if (wideMode == 2)
     hipLaunchKernelGGL(k_match_wide_prep, dim3(nPairs), dim3(MW_T), 0, st, dFirst, dSecond, kps, nkp, mp, matches12, nmatches,
