@@ -176,8 +176,8 @@ int orbx_extract_match_batch_device_async(orbx_ctx* ctx, int n_frames, const uin
  * streams, at most two batches in flight.  depth >= 1: the context keeps `depth` lanes (each with its own stream and its own
  * copy of the internal buffers, sized like the context) and every stream-ordered batch goes, whole, to the next lane; at most
  * `depth` batches are in flight (the call that would exceed it first waits for the oldest), so batches in flight together need
- * `depth` different output arrays.  Whole batches on three lanes measure 305 k frames/s against 285 k with the two halves
- * (256 frames 640x480 per batch, MI355X).  Waits for everything in flight; 0 <= depth <= 8; costs depth times the context's
+ * `depth` different output arrays.  Whole batches on four lanes measure 304 k frames/s against 296 k with the two halves at
+ * 256 frames 640x480 per batch, and 230 k against 126 k at 32 frames per batch on three lanes (MI355X).  Waits for everything in flight; 0 <= depth <= 8; costs depth times the context's
  * device memory.  orbx_download_pyramid and the profile / debug hooks of the context keep referring to the batches the context
  * ran itself (synchronous calls, depth 0); orbx_profile_get adds what the lanes ran.  (The reference has no counterpart: it
  * extracts one frame per call, Frame.cpp:58-60.) */
