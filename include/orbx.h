@@ -178,7 +178,8 @@ int orbx_extract_match_batch_device_async(orbx_ctx* ctx, int n_frames, const uin
  * `depth` batches are in flight (the call that would exceed it first waits for the oldest), so batches in flight together need
  * `depth` different output arrays.  Whole batches on four lanes measure 304 k frames/s against 296 k with the two halves at
  * 256 frames 640x480 per batch, and 230 k against 126 k at 32 frames per batch on three lanes (MI355X).  Waits for everything in flight; 0 <= depth <= 8; costs depth times the context's
- * device memory.  orbx_download_pyramid and the profile / debug hooks of the context keep referring to the batches the context
+ * device memory; not available (ORBX_E_BADARG) on a context created on a caller's stream, whose order the lanes' own streams could
+ * not keep.  orbx_download_pyramid and the profile / debug hooks of the context keep referring to the batches the context
  * ran itself (synchronous calls, depth 0); orbx_profile_get adds what the lanes ran.  (The reference has no counterpart: it
  * extracts one frame per call, Frame.cpp:58-60.) */
 int orbx_set_pipeline_depth(orbx_ctx* ctx, int depth);

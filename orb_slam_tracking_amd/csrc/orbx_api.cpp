@@ -1539,6 +1539,10 @@ int orbx_extract_match_batch_device_async(orbx_ctx* ctx, int n_frames, const uin
 
 int orbx_set_pipeline_depth(orbx_ctx* ctx, int depth) {
   if (!ctx || depth < 0 || depth > 8) return ORBX_E_BADARG;
+  if (depth > 0 && !ctx->ownStream) {  // the lanes run on streams of their own: a context tied to a caller's stream cannot promise its order
+    ctx->err = "orbx_set_pipeline_depth: the context was created on a caller's stream";
+    return ORBX_E_BADARG;
+  }
   if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
   const int w = waitAll(ctx);
   if (w == ORBX_E_HIP) return w;

@@ -185,3 +185,19 @@ def test_regression_r01_fault_tiny_units_on_global_scratch(orbx, oracle):
                 got = e.debug_distribute_device(xyr, 16, 16 + W, 16, 16 + H, N, variant)
                 assert got.shape == exp.shape and np.array_equal(got, exp), (n, N, variant)
     e.close()
+
+
+def test_pipeline_depth_needs_an_own_stream(orbx):
+    """orbx_set_pipeline_depth on a context created on a caller's stream is refused (the lanes run on streams of their own)."""
+    import torch
+    st = torch.cuda.Stream()
+    e = orbx.ORBextractor(500, 1.2, 4, 20, 7, max_width=320, max_height=240, max_batch=4, stream=int(st.cuda_stream))
+    with pytest.raises(orbx.OrbxError) as ei:
+        e.set_pipeline_depth(2)
+    assert ei.value.code == orbx.E_BADARG
+    e.set_pipeline_depth(0)
+    e.close()
+    e = orbx.ORBextractor(500, 1.2, 4, 20, 7, max_width=320, max_height=240, max_batch=4)
+    e.set_pipeline_depth(2)
+    e.set_pipeline_depth(0)
+    e.close()
