@@ -120,7 +120,7 @@ struct orbx_ctx {
   // when it hands a pair on); a batch that needed them without having them gets them at its wait (late, prep included).
   int* hWide = nullptr;     // pinned [2]
   int* hWideDev = nullptr;
-  bool wideExpected = true;
+  bool wideExpected = false;  // a batch that needs the wide kernels without having them gets them at its wait, and its successors with them
   int wideIdle = 0;         // consecutive batches that had the wide kernels and did not need them
   bool wideLaunched[2]{};
   struct LateMatch {

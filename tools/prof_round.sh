@@ -6,7 +6,7 @@ TAG=$1
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT $R/profiles
 cd /tmp && export TMPDIR=/tmp
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats2 -- python3 bench.py --steps 20 --warmup 2 --regions 1 --no-cpu-baseline --no-single-frame > $OUT/stats2.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats2 -- python3 bench.py --steps 100 --warmup 3 --regions 1 --no-cpu-baseline --no-single-frame > $OUT/stats2.log 2>&1
 export ORBX_NO_SPLIT=1   # with --depth 0: one stream, one 256-frame launch per kernel and step (every kernel alone on the chip)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --depth 0 --steps 10 --warmup 2 --regions 1 --no-cpu-baseline --no-single-frame > $OUT/stats.log 2>&1
 P="python3 bench.py --depth 0 --steps 3 --warmup 1 --regions 1 --no-cpu-baseline --no-single-frame"
