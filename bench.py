@@ -9,6 +9,9 @@ One step = one pass of the hot path over one batch of synthetic 640x480 frames t
 Frames are sharded per rank (weak scaling: B frames per GPU), one process per GPU.  The steps rotate through four distinct
 input sets (315 MB per GPU, more than the 256 MB Infinity Cache), so no step finds its input cache-resident.
 Prints ONE JSON line on rank 0 (see the task contract): metric / value / roofline / cpu_baseline.
+`python bench.py --gpus N` with N > 1 starts its own N ranks (torch.distributed.run, one process per GPU, RCCL) when it is not
+already running under a launcher; after the timed regions rank 0 compares one complete output set with the CPU oracle
+("checked": true -- outside every timed region).
 
 `value` is the median of the timed regions, each of exactly --steps steps, back to back (five by default, nine when --steps is
 below 100); `spread` carries min / max / the first region and all of them in order.  The roofline of the dominant kernel is the VALU one:
@@ -69,6 +72,63 @@ def load_pmc():
         return None, None
 
 
+def kernel_sources_sha16():
+    """Hash of the device + host sources liborbx.so is built from: tools/pmc_to_json.py records it in profiles/r*_pmc.json, and the
+    roofline object says whether the counters were collected from the code under test (`pmc_stale`)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "orb_slam_tracking_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".inc", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` outside a launcher: N fresh ranks through torch.distributed.run (this process has not touched the
+    GPU and never will), rank 0's JSON line relayed, exit code = the children's."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def oracle_check(frames, got, cores):
+    """Not timed: one complete output set (host copies of k / d / n / m / nm) of the last batch against the CPU oracle -- every
+    frame's count, keypoint bytes and descriptor bytes, every pair's nmatches and matches12.  Returns (ok, what)."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    B, cap = len(frames), 1000
+    threads = max(1, min(cores, 16))
+    bad = []
+
+    def work(t):
+        oe = O.Extractor(*PARAMS)
+        for p_ in range(t, B // 2, threads):
+            a, b = oe(frames[2 * p_]), oe(frames[2 * p_ + 1])
+            nm, m12, _ = O.match_init(a[1], a[2], b[1], b[2], (0, W, 0, H), 100, 0.9, True)
+            for f, (_, ko, do) in ((2 * p_, a), (2 * p_ + 1, b)):
+                n = int(got["n"][f])
+                if n != len(ko) or got["k"][f * cap * 28:(f * cap + n) * 28].tobytes() != ko.tobytes() or \
+                        got["d"][f * cap * 32:(f * cap + n) * 32].tobytes() != do.tobytes():
+                    bad.append("frame %d" % f)
+            if int(got["nm"][p_]) != nm or not np.array_equal(got["m"][p_ * cap:p_ * cap + len(m12)], m12):
+                bad.append("pair %d" % p_)
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(work, range(threads)))
+    return (not bad), ("%d frames (count, keypoint bytes, descriptor bytes) and %d pairs (nmatches, matches12) of the last batch equal "
+                       "the CPU oracle" % (B, B // 2) if not bad else "MISMATCH: " + ", ".join(sorted(bad)[:8]))
+
+
 def cpu_share():
     """Host cores this process may really use: cgroup quota if set, else the affinity mask; capped at 64."""
     n = len(os.sched_getaffinity(0))
@@ -87,7 +147,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
-    ap.add_argument("--regions", type=int, default=5, help="timed regions of --steps steps (the first one gives `value`)")
+    ap.add_argument("--regions", type=int, default=5, help="timed regions of exactly --steps steps, back to back; `value` is their median "
+                    "(at least nine regions when --steps is below 100)")
     ap.add_argument("--depth", type=int, default=4, help="pipeline depth of the stream-ordered call (orbx_set_pipeline_depth): whole "
                     "batches on this many lanes; 0 = the two-half-batches mode")
     ap.add_argument("--prime", type=int, default=16, help="untimed batches right after the context is created (initialisation of "
@@ -99,7 +160,11 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 path)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle comparison of the last batch (after the timed regions)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # before torch is imported or anything touches the GPU: start the ranks as fresh child processes (never an exec)
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -110,8 +175,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.one_device:
@@ -129,14 +193,13 @@ def main():
     cap = 1000
     # this rank's shard of the global batch (frame i -> rank i // B, contiguous blocks; pairs never straddle ranks)
     lo, hi = sharding.shard_range(B * world, world, rank)
-    frames = synth.synth_frames(hi - lo, W, H, seed0=1000 + lo // 2)
-    # four input sets: the frames, and their vertical / horizontal / both mirror images (pairs stay pairs of one scene)
-    host_sets = [frames, frames[:, ::-1, :], frames[:, :, ::-1], frames[:, ::-1, ::-1]]
-    if args.input_sets == 5:  # (experiments: a rotation length that no lane count divides)
-        host_sets.append(np.ascontiguousarray(frames[::-1]))
-    host_sets = host_sets[:max(1, min(args.input_sets, 5))]
+    # four input sets: the frames, and their vertical / horizontal / both mirror images (pairs stay pairs of one scene); a fifth
+    # (experiments: a rotation length that no lane count divides) is the first in reverse order.  tests/test_gpu_headline.py runs
+    # exactly these sets through exactly this call sequence against the oracle.
+    host_sets = synth.bench_input_sets(hi - lo, W, H, 1000 + lo // 2, args.input_sets)
+    frames = host_sets[0]
     nsets = len(host_sets)
-    d_imgs = [torch.from_numpy(np.ascontiguousarray(s)).to(dev) for s in host_sets]
+    d_imgs = [torch.from_numpy(s).to(dev) for s in host_sets]
     # one set of output arrays per batch in flight: the batches are issued stream-ordered
     # (orbx_extract_match_batch_device_async), and batches in flight together must not share their outputs
     # pipeline depth: whole batches on `depth` lanes of the context (orbx_set_pipeline_depth); 0 = two half batches on two streams
@@ -164,6 +227,7 @@ def main():
     pending = [None]
     nstep = [0]
     ngathered = [0]  # batches whose counts have been gathered
+    ngather_calls = [0]
 
     def finish_gather():
         if pending[0] is not None:
@@ -176,6 +240,7 @@ def main():
         snap.copy_(outs[k % nout]["n"])  # batch k has been waited for: its counts are final.  (The copy runs on torch's stream;
         # the binding orders the context's streams behind it before the next batch rewrites that array: orbx_order_after.)
         pending[0] = dist.all_gather_into_tensor(counts_all, snap, async_op=True)
+        ngather_calls[0] += 1
 
     def step():
         # one call = the whole hot path of the batch: extraction of B frames and SearchForInitialization of the B/2
@@ -248,7 +313,12 @@ def main():
     ext.profile_enable(False)
     if stage_prof is None:
         stage_prof, stage_steps = prof, args.steps
-    d_n, d_nm = outs[(nstep[0] - 1) % nout]["n"], outs[(nstep[0] - 1) % nout]["nm"]
+    last = nstep[0] - 1
+    d_n, d_nm = outs[last % nout]["n"], outs[last % nout]["nm"]
+    gathered_ok = None
+    if world > 1:  # the last all_gather's result: every rank's block holds the counts of that rank's last batch
+        ca = counts_all.cpu().numpy()
+        gathered_ok = bool(ngather_calls[0] > 0 and (ca > 0).all() and np.array_equal(ca[lo:hi], d_n.cpu().numpy()))
 
     if rank == 0:
         n_kp = float(d_n.float().mean().item())
@@ -269,6 +339,8 @@ def main():
                 "avg_launch_ms": avg_launch_ms, "frames_per_launch": frames_per_launch,
                 "formula": "achieved = VALU issue cycles per frame [4 x (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2), %s] x frames per "
                            "launch / launch duration [HIP events, live]; peak = 256 CUs x 4 SIMDs x 2.4 GHz" % (pmc_file or "no PMC file")}
+        roof["pmc_file"] = pmc_file
+        roof["pmc_stale"] = None if not pmc else (pmc.get("kernel_sources_sha16") != kernel_sources_sha16())
         if pk and secs > 0:
             roof["achieved"] = pk["valu_issue_cycles"] * frames_per_launch / secs / 1e12
             roof["frac"] = roof["achieved"] / roof["peak"]
@@ -320,6 +392,9 @@ def main():
                                    "(window 100, ratio 0.9)" % (B, B // 2),
                        "frames_per_gpu": B, "pairs_per_gpu": B // 2, "mean_keypoints": n_kp, "mean_nmatches": nm_mean,
                        "pipeline_depth": depth, "prime_steps": args.prime,
+                       "rccl_ranks": (dist.get_world_size() if world > 1 and args.backend == "nccl" else (0 if world > 1 else 1)),
+                       "collective": ({"backend": args.backend, "world_size": dist.get_world_size(), "all_gathers": ngather_calls[0],
+                                       "gathered_counts_ok": gathered_ok} if world > 1 else None),
                        "parallelism": "frames sharded per GPU (%d ranks), RCCL all_gather of keypoint counts" % world},
             "spread": {"regions": len(region_dts), "steps_per_region": args.steps, "median": rates[len(rates) // 2],
                        "min": rates[0], "max": rates[-1], "first_region": B * world * args.steps / dt_first,
@@ -332,6 +407,15 @@ def main():
             "stage_ms_source": "warmup steps, every stage bracketed by HIP events (sums over the lanes / half-batch streams); the "
                                "timed steps bracket only the dominant kernel",
         }
+        # not timed: the last batch's complete output set against the CPU oracle
+        if args.no_check:
+            out["checked"] = False
+            out["check"] = "skipped (--no-check)"
+        else:
+            got = {k_: v.cpu().numpy() for k_, v in outs[last % nout].items()}
+            ok, what = oracle_check(host_sets[last % nsets], got, cpu_share())
+            out["checked"] = bool(ok)
+            out["check"] = what
         # second figure: the call the reference actually makes -- one frame per call through the host API
         # (Frame.cpp:58-60: host image in, keypoints + descriptors back on the host), and one SearchForInitialization per call
         try:

@@ -192,7 +192,13 @@ int orbx_wait(orbx_ctx* ctx);     /* all batches in flight */
  *                              (call it between producing the frames on `s` and the device-resident entry points);
  *   orbx_order_before(ctx, s): work queued on `s` from now on starts after everything issued on ctx so far
  *                              (for a consumer that reads the outputs of an _async batch without a host-side wait).
- * `s` is a hipStream_t as void* (NULL = the legacy default stream).  Both only record / wait on events. */
+ * `s` is a hipStream_t as void* (NULL = the legacy default stream).  Both only record / wait on events, with one exception:
+ * the FIRST orbx_order_before on a context switches it to "event-ordered" mode -- from then on every batch carries all of its
+ * matcher kernels (normally the kernels for pairs beyond the fast matcher's tables are issued only while batches need them, and
+ * a batch that needed them without having them is completed inside its orbx_wait), and batches already in flight that were
+ * issued without them are completed right there with a host-side wait.  After it, outputs (keypoints, descriptors, counts,
+ * matches12, nmatches, statistics) read behind the event are final.  Error codes (ORBX_E_CAPACITY of the selection stage) are
+ * still reported by orbx_wait_one / orbx_wait only, which an event-ordered consumer calls later, at its leisure. */
 int orbx_order_after(orbx_ctx* ctx, void* stream);
 int orbx_order_before(orbx_ctx* ctx, void* stream);
 
@@ -311,6 +317,14 @@ int orbx_debug_std_sort(orbx_ctx* ctx, int32_t* triples, int n);
 /* The (cos, sin) pair the descriptor kernel uses for a keypoint angle in degrees (f64 evaluation rounded to f32,
  * cpp:173-174), for n angles; host pointers. */
 int orbx_debug_sincos(orbx_ctx* ctx, const float* angle_deg, int n, float* cos_out, float* sin_out);
+
+/* How the context's last extraction batch was issued (the kernels behind one entry point depend on batch size, frame size,
+ * alignment and the previous batch's statistics): info8 = { [0] pyramid: 1 = k_pyramid_bands (one launch), 0 = one resize launch
+ * per level; [1] row bands per frame of k_pyramid_bands; [2] FAST: 1 = k_fast_wave, 0 = k_fast; [3] selection: candidate
+ * capacity of the LDS instance the lowest level ran on (0 = every unit on global scratch); [4] 1 = the batch was cut into two
+ * halves on two streams; [5] frames per kernel launch; [6] 1 = the wide matcher kernels went with the batch; [7] lane the batch
+ * went to (1-based; 0 = the context itself) }. */
+int orbx_debug_last_launch(const orbx_ctx* ctx, int32_t* info8);
 
 #ifdef __cplusplus
 }

@@ -318,9 +318,11 @@ class ORBmatcher {
     return search(ext_, F1, F2, vnMatches12, windowSize);
   }
 
-  static const int HISTO_LENGTH = 30;
-  static const int TH_LOW = 50;
-  static const int TH_HIGH = 100;
+  // Features/ORBmatcher.cpp:5-7 defines these out of class; `inline` gives the header-only shim a definition too, so that an
+  // odr-use (std::min(ORBmatcher::TH_LOW, d)) links
+  inline static constexpr int HISTO_LENGTH = 30;
+  inline static constexpr int TH_LOW = 50;
+  inline static constexpr int TH_HIGH = 100;
 
  private:
   int search(ORBextractor* e, const FrameView& F1, const FrameView& F2, std::vector<int>& vnMatches12, int windowSize) {

@@ -128,6 +128,7 @@ def lib() -> ctypes.CDLL:
     L.orbx_debug_distribute_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32]
     L.orbx_debug_std_sort.argtypes = [vp, vp, i32]
     L.orbx_debug_sincos.argtypes = [vp, vp, i32, vp, vp]
+    L.orbx_debug_last_launch.argtypes = [vp, vp]
     _LIB = L
     return L
 
@@ -505,6 +506,13 @@ class ORBextractor:
         c, s = np.zeros(len(a), np.float32), np.zeros(len(a), np.float32)
         self._check(self._L.orbx_debug_sincos(self._h, _ptr(a), len(a), _ptr(c), _ptr(s)))
         return c, s
+
+    def debug_last_launch(self) -> dict:
+        """How the last extraction batch was issued (include/orbx.h: orbx_debug_last_launch)."""
+        v = np.zeros(8, np.int32)
+        self._check(self._L.orbx_debug_last_launch(self._h, _ptr(v)), "orbx_debug_last_launch")
+        return dict(pyramid_banded=int(v[0]), pyramid_bands=int(v[1]), fast_wave=int(v[2]), octree_instance=int(v[3]),
+                    split=int(v[4]), frames_per_launch=int(v[5]), wide_with_batch=int(v[6]), lane=int(v[7]))
 
     def debug_candidates(self, frame: int, level: int) -> np.ndarray:
         n = self._check(self._L.orbx_debug_candidates(self._h, frame, level, None, 0))

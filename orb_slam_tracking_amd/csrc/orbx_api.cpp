@@ -25,7 +25,8 @@ hipError_t launch_resize(hipStream_t st, int nFrames, const uint8_t* src, long l
                          uint8_t* dst, long long dstFrameStride, int dw, int dh, int dstride, const ResizeTab* xtab,
                          const ResizeTab* ytab, int dwordPath);
 hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, int img0Aligned,
-                       const uint8_t* pyr, const Geom& g, uint32_t* cand, int* cellCount, const FastCell* cells, int waveOk);
+                       const uint8_t* pyr, const Geom& g, uint32_t* cand, int* cellCount, const FastCell* cells, int waveOk,
+                       int* usedWave);
 hipError_t launch_pyramid_bands(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, uint8_t* pyr,
                                 const Geom& g, const ResizeTab* tab, const PyrBands& pb);
 hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const uint8_t* img0, long long img0FrameStride,
@@ -35,7 +36,7 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
                         const uint8_t* desc, const int* nkp, int capacity, orbx_bounds b, int window, float nnratio, int checkOri,
                         int* matches12, int* nmatches, int* stats, int* scratch, int pair0, int wideMode, int* hostWide);
 hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, const int* cellCount, const OctLaunch& P,
-                         SelKp* selStage, int* nselLevel, uint8_t* scratch, int maxQuota, int* maxN, int nHint);
+                         SelKp* selStage, int* nselLevel, uint8_t* scratch, int maxQuota, int* maxN, int nHint, int* usedInstance);
 hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage, const int* nselLevel, const OctLaunch& P,
                               SelKp* sel, int* nsel, int* nselUser, int* hostNsel, int selCap, int* hostErr, int* maxN,
                               int* hostMaxN);
@@ -123,6 +124,9 @@ struct orbx_ctx {
   bool wideExpected = false;  // a batch that needs the wide kernels without having them gets them at its wait, and its successors with them
   int wideIdle = 0;         // consecutive batches that had the wide kernels and did not need them
   bool wideLaunched[2]{};
+  bool eventOrdered = false;  // orbx_order_before has been used: a consumer may read a batch's outputs without a host-side wait, so
+                              // the wide kernels travel with every batch (nothing may be left to the wait)
+  int lastLaunch[8]{};        // orbx_debug_last_launch: how the last batch was issued
   struct LateMatch {
     bool valid = false;
     int nPairs = 0, capacity = 0, window = 0, checkOri = 0;
@@ -572,7 +576,10 @@ int allocAll(orbx_ctx* ctx) {
     return ORBX_E_HIP;                                                                            \
   }
 #define ALLOCH(ptr, bytes)                                                                        \
-  if (hipHostMalloc((void**)&(ptr), std::max<size_t>((bytes), 16), hipHostMallocDefault) != hipSuccess) return ORBX_E_HIP
+  if (hipHostMalloc((void**)&(ptr), std::max<size_t>((bytes), 16), hipHostMallocDefault) != hipSuccess) {  \
+    ctx->err = "hipHostMalloc failed for " #ptr;                                                  \
+    return ORBX_E_HIP;                                                                            \
+  }
   ALLOC(ctx->dPyr, ctx->pyrBytes);
   ALLOC(ctx->dCand, ctx->candEntries * 4);
   ALLOC(ctx->dCandCount, (B * nl + 2) * sizeof(int));
@@ -594,20 +601,20 @@ int allocAll(orbx_ctx* ctx) {
   ALLOC(ctx->dIn, ctx->inBytes);
   ALLOC(ctx->dKps, B * cap * sizeof(orbx_keypoint));
   ALLOC(ctx->dDesc, B * cap * 32);
-  ALLOCH(ctx->hNsel, B * sizeof(int));
-  ALLOCH(ctx->hFlags, 2 * sizeof(int));
+  ALLOCH(ctx->hNsel, B * sizeof(int))
+  ALLOCH(ctx->hFlags, 2 * sizeof(int))
   ALLOC(ctx->dMaxN, 2 * ORBX_MAX_LEVELS * sizeof(int));
   if (hipMemset(ctx->dMaxN, 0, 2 * ORBX_MAX_LEVELS * sizeof(int)) != hipSuccess) return ORBX_E_HIP;
-  ALLOCH(ctx->hMaxN, 2 * ORBX_MAX_LEVELS * sizeof(int));
+  ALLOCH(ctx->hMaxN, 2 * ORBX_MAX_LEVELS * sizeof(int))
   if (hipHostGetDevicePointer((void**)&ctx->hMaxNDev, ctx->hMaxN, 0) != hipSuccess) return ORBX_E_HIP;
   if (hipHostGetDevicePointer((void**)&ctx->hNselDev, ctx->hNsel, 0) != hipSuccess) return ORBX_E_HIP;
   if (hipHostGetDevicePointer((void**)&ctx->hFlagsDev, ctx->hFlags, 0) != hipSuccess) return ORBX_E_HIP;
   ctx->pinFrames = (int)std::min<size_t>(B, 4);
-  ALLOCH(ctx->hKpsPin, (size_t)ctx->pinFrames * cap * sizeof(orbx_keypoint));
-  ALLOCH(ctx->hDescPin, (size_t)ctx->pinFrames * cap * 32);
+  ALLOCH(ctx->hKpsPin, (size_t)ctx->pinFrames * cap * sizeof(orbx_keypoint))
+  ALLOCH(ctx->hDescPin, (size_t)ctx->pinFrames * cap * 32)
   if (hipHostGetDevicePointer((void**)&ctx->hKpsPinDev, ctx->hKpsPin, 0) != hipSuccess) return ORBX_E_HIP;
   if (hipHostGetDevicePointer((void**)&ctx->hDescPinDev, ctx->hDescPin, 0) != hipSuccess) return ORBX_E_HIP;
-  ALLOCH(ctx->hWide, 16);
+  ALLOCH(ctx->hWide, 16)
   ctx->hWide[0] = ctx->hWide[1] = 0;
   if (hipHostGetDevicePointer((void**)&ctx->hWideDev, ctx->hWide, 0) != hipSuccess) return ORBX_E_HIP;
   ctx->hFlags[0] = ctx->hFlags[1] = 0;
@@ -624,7 +631,10 @@ int allocAll(orbx_ctx* ctx) {
 int waitAll(orbx_ctx* ctx);
 int growTo(orbx_ctx* ctx, int w, int h, int B) {
   int r = waitAll(ctx);
-  if (r == ORBX_E_HIP) return r;
+  // the outcome of the batches drained here (e.g. ORBX_E_CAPACITY of a stream-ordered batch nobody has waited for yet) is not
+  // swallowed: like every call that has to wait for an earlier batch, this one returns that batch's error (nothing has been
+  // freed or resized yet; everything is drained, so the caller's retry grows the context)
+  if (r != ORBX_OK) return r;
   HIPCHK(hipStreamSynchronize(ctx->st));
   if (ctx->st2) HIPCHK(hipStreamSynchronize(ctx->st2));
   const int oldW = ctx->maxW, oldH = ctx->maxH, oldB = ctx->maxB;
@@ -803,6 +813,8 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
     StageTimer tm(ctx, ORBX_STAGE_PYRAMID, si, st);
     HIPCHK(launch_pyramid_bands(st, n, a.dImg0, a.frameStride0, ctx->dPyr, g, ctx->dTab, pb));
     tm.stop(1);
+    ctx->lastLaunch[0] = 1;
+    ctx->lastLaunch[1] = pb.nBands;
   } else {
     StageTimer tm(ctx, ORBX_STAGE_PYRAMID, si, st);
     for (int l = 1; l < nl; l++) {
@@ -815,12 +827,15 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
                            D.resizeSpanOk && (l > 1 || a.aligned0)));
     }
     if (nl > 1) tm.stop(nl - 1);
+    ctx->lastLaunch[0] = 0;
+    ctx->lastLaunch[1] = 0;
   }
   {
     StageTimer tm(ctx, ORBX_STAGE_FAST, si, st);
     HIPCHK(launch_fast(st, n, a.dImg0, a.frameStride0, a.aligned0, ctx->dPyr, g, ctx->dCand, ctx->dCellCount, ctx->dCells,
-                       ctx->fastWaveOk));
+                       ctx->fastWaveOk, &ctx->lastLaunch[2]));
     tm.stop(1);
+    ctx->lastLaunch[5] = n;
   }
   return ORBX_OK;
   }  // part 0
@@ -829,7 +844,7 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
     // per-level candidate maxima of this stream slot: device accumulators + their pinned host mirror (read after the sync)
     int* dMax = ctx->dMaxN + si * ORBX_MAX_LEVELS;
     HIPCHK(launch_octree(st, n, ctx->dCand, ctx->dCellCount, oct, ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, ctx->maxQuota,
-                         dMax, ctx->candHint));
+                         dMax, ctx->candHint, &ctx->lastLaunch[3]));
     HIPCHK(launch_sel_compact(st, n, ctx->dSelStage, ctx->dNselLevel, oct, ctx->dSel, ctx->dNsel, a.dNuser, ctx->hNselDev, g.selCap,
                               ctx->hFlagsDev + ctx->parity, dMax, ctx->hMaxNDev + si * ORBX_MAX_LEVELS));
     ctx->maxSlotsUsed |= 1 << si;
@@ -875,7 +890,7 @@ int issueMatch(orbx_ctx* ctx, int si, hipStream_t st, int pair0, int n, const Ma
 void armMatch(orbx_ctx* ctx, const MatchArgs& m, const orbx_keypoint* dKps, const uint8_t* dDesc, const int* dN, int capacity) {
   const int par = ctx->parity;
   ctx->hWide[par] = 0;  // (the previous batch of this parity has been waited for)
-  ctx->wideLaunched[par] = ctx->wideExpected;
+  ctx->wideLaunched[par] = ctx->wideExpected || ctx->eventOrdered;
   orbx_ctx::LateMatch& L = ctx->late[par];
   L.valid = true;
   L.nPairs = m.nPairs; L.capacity = capacity; L.window = m.window; L.checkOri = m.checkOri; L.nnratio = m.nnratio; L.b = m.b;
@@ -1046,6 +1061,8 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
     while (p1 < nPairs && match->hFirst[p1] >= n0 && match->hSecond[p1] >= n0) p1++;
   }
   ctx->done2Used[ctx->parity] = split;
+  ctx->lastLaunch[4] = split ? 1 : 0;
+  ctx->lastLaunch[6] = nPairs > 0 && ctx->wideLaunched[ctx->parity] ? 1 : 0;
   // Everything below queues work; a failure in the middle must not leave launches in flight behind an error return (the
   // next call would reuse their buffers and events), so the issue is one unit with one exit.
   auto issue = [&]() -> int {
@@ -1197,7 +1214,7 @@ int orbx_set_opencv_variant(orbx_ctx* ctx, int gaussian_variant, int gray_varian
   if (!ctx || gaussian_variant < 0 || gaussian_variant > 1 || gray_variant < 0 || gray_variant > 1) return ORBX_E_BADARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
   const int w = waitAll(ctx);  // batches in flight keep the constants they were issued with
-  if (w == ORBX_E_HIP) return w;
+  if (w != ORBX_OK) return w;  // (an earlier batch's error is returned by the call that has to wait for it; retry)
   ctx->gaussVariant = gaussian_variant;
   ctx->grayVariant = gray_variant;
   for (orbx_ctx* c : ctx->lanes) { c->gaussVariant = gaussian_variant; c->grayVariant = gray_variant; }
@@ -1530,9 +1547,12 @@ int orbx_extract_match_batch_device_async(orbx_ctx* ctx, int n_frames, const uin
                                n_pairs, h_first, h_second, bounds, window_size, nnratio, check_orientation, d_matches12, d_nmatches,
                                d_stats, true);
     if (r != ORBX_OK) { ctx->err = c->err; return r; }
+    memcpy(ctx->lastLaunch, c->lastLaunch, sizeof ctx->lastLaunch);
+    ctx->lastLaunch[7] = (int)(ctx->laneIssue % L) + 1;
     ctx->laneIssue++;
     return ORBX_OK;
   }
+  ctx->lastLaunch[7] = 0;
   return extractMatch(ctx, n_frames, d_imgs, width, height, stride, frame_stride_bytes, d_kps, d_desc32, capacity, d_n_out, n_pairs,
                       h_first, h_second, bounds, window_size, nnratio, check_orientation, d_matches12, d_nmatches, d_stats, true);
 }
@@ -1545,7 +1565,7 @@ int orbx_set_pipeline_depth(orbx_ctx* ctx, int depth) {
   }
   if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
   const int w = waitAll(ctx);
-  if (w == ORBX_E_HIP) return w;
+  if (w != ORBX_OK) return w;  // (an earlier batch's error is returned by the call that has to wait for it; retry)
   for (orbx_ctx* c : ctx->lanes) orbx_destroy(c);
   ctx->lanes.clear();
   ctx->laneIssue = ctx->laneDone = 0;
@@ -1559,6 +1579,7 @@ int orbx_set_pipeline_depth(orbx_ctx* ctx, int depth) {
       return r;
     }
     c->noSplit = true;
+    c->eventOrdered = ctx->eventOrdered;
     c->gaussVariant = ctx->gaussVariant;
     c->grayVariant = ctx->grayVariant;
     c->profMask = ctx->profMask;
@@ -1597,6 +1618,23 @@ int orbx_order_before(orbx_ctx* ctx, void* stream) {
   if (!ctx) return ORBX_E_BADARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
   hipStream_t s = (hipStream_t)stream;
+  if (!ctx->eventOrdered) {
+    // From now on a consumer may read outputs behind an event only, so nothing of a batch may be left to its host-side wait:
+    // the wide matcher kernels travel with every batch of this context (armMatch).  Batches already in flight that were issued
+    // without them are completed here, once, with a host-side wait (settleMatch runs their late wide kernels if they need them).
+    ctx->eventOrdered = true;
+    for (orbx_ctx* c : ctx->lanes) c->eventOrdered = true;
+    std::vector<orbx_ctx*> all(ctx->lanes);
+    all.push_back(ctx);
+    for (orbx_ctx* c : all)
+      for (int par = 0; par < 2; par++)
+        if (c->late[par].valid && !c->wideLaunched[par]) {
+          HIPCHK(hipEventSynchronize(c->evDone[par]));
+          if (c->done2Used[par]) HIPCHK(hipEventSynchronize(c->evDone2[par]));
+          const int sm = settleMatch(c, par);
+          if (sm != ORBX_OK) { ctx->err = c->err; return sm; }
+        }
+  }
   if (s != ctx->st) {
     HIPCHK(hipEventRecord(ctx->evOrder, ctx->st));
     HIPCHK(hipStreamWaitEvent(s, ctx->evOrder, 0));
@@ -2009,7 +2047,7 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
     HIPCHK(hipMemcpyAsync(dC, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->st));
     int hi[2] = {n, -7};
     HIPCHK(hipMemcpyAsync(dI, hi, sizeof hi, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(launch_octree(ctx->st, 1, dC, dI, P, dS, dI + 1, dScr, variant == 0 ? n_features : (1 << 30), nullptr, variant == 2 ? 1 : 0));
+    HIPCHK(launch_octree(ctx->st, 1, dC, dI, P, dS, dI + 1, dScr, variant == 0 ? n_features : (1 << 30), nullptr, variant == 2 ? 1 : 0, nullptr));
     HIPCHK(hipMemcpyAsync(res, dI, sizeof res, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(sel.data(), dS, sel.size() * sizeof(SelKp), hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));
@@ -2030,7 +2068,12 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
   return res[1];
 }
 
-// runs the device replay of libstdc++'s std::sort on n (count, ulx, id) triples in place
+int orbx_debug_last_launch(const orbx_ctx* ctx, int32_t* info8) {
+  if (!ctx || !info8) return ORBX_E_BADARG;
+  for (int i = 0; i < 8; i++) info8[i] = ctx->lastLaunch[i];
+  return ORBX_OK;
+}
+
 int orbx_debug_sincos(orbx_ctx* ctx, const float* angle_deg, int n, float* cos_out, float* sin_out) {
   if (!ctx || n < 0 || (n > 0 && (!angle_deg || !cos_out || !sin_out))) return ORBX_E_BADARG;
   if (n == 0) return ORBX_OK;

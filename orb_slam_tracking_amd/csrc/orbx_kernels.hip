@@ -728,6 +728,7 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
   const int sh = (xoff + 3) & 3;                       // byte phase of a quad's first pixel inside its dword (wave-uniform)
   const int offA0 = (qy0 + 3) * TS + xoff + 3 - sh + 4 * qc0;  // dword-aligned tile offset of the quad's first pixel
   const int dOffA = dqy * TS + 4 * dqc;
+  const int offIdle = 3 * TS + xoff + 3 - sh;  // quad (0, 0): what idle lanes read
   // v_perm_b32 selectors (SGPRs): two tap bytes -> the halves of a u16 pair (0x0c = constant 0).  Centre / top / bottom bytes
   // sh + {0..3} of the dword pair at the quad; left compass bytes sh + 1 + {0..3} of the pair one dword to the left; right
   // compass bytes sh + 3 + {0..3} of the pair at the quad (sh <= 1) or sh - 1 + {0..3} of the pair one dword to the right
@@ -764,7 +765,10 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
       int qc = qc0, offA = offA0;
       const uint32_t* const t32 = reinterpret_cast<const uint32_t*>(tile);
       for (int idx0 = 0; idx0 < nItems; idx0 += 64) {
-        const int wA = offA >> 2;  // dword index of the quad's first pixel's dword
+        // (idle lanes of the last step would run up to 63 quads beyond the cell -- with one quad per row, beyond the LDS
+        // allocation: they read the cell's first quad instead, their verdicts are masked below)
+        const bool live = idx0 + lane < nItems;
+        const int wA = (live ? offA : offIdle) >> 2;  // dword index of the quad's first pixel's dword
         const uint32_t cM = t32[wA - 1], c0 = t32[wA], c1 = t32[wA + 1], c2 = t32[wA + 2];
         const uint32_t t0 = t32[wA - 3 * (TS / 4)], t1 = t32[wA - 3 * (TS / 4) + 1];
         const uint32_t b0 = t32[wA + 3 * (TS / 4)], b1 = t32[wA + 3 * (TS / 4) + 1];
@@ -786,7 +790,7 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
           fl[hp] = (__builtin_bit_cast(uint32_t, e1) | __builtin_bit_cast(uint32_t, e2)) & 0x80008000u;
         }
         // the quad's four verdicts as bits 0..3, cleared for pixels beyond the row's end and for idle lanes
-        const int nv = (idx0 + lane < nItems) ? min(iw - 4 * qc, 4) : 0;
+        const int nv = live ? min(iw - 4 * qc, 4) : 0;
         const uint32_t bits = (((fl[0] >> 15) & 1u) | ((fl[0] >> 30) & 2u) | ((fl[1] >> 13) & 4u) | ((fl[1] >> 28) & 8u)) & ((1u << nv) - 1u);
         const int offP = offA + sh;  // tile offset of the quad's first pixel
 #pragma unroll
@@ -2419,13 +2423,15 @@ hipError_t launch_pyramid_bands(hipStream_t st, int nFrames, const uint8_t* img0
 }
 
 hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, int img0Aligned,
-                       const uint8_t* pyr, const Geom& g, uint32_t* cand, int* cellCount, const FastCell* cells, int waveOk) {
+                       const uint8_t* pyr, const Geom& g, uint32_t* cand, int* cellCount, const FastCell* cells, int waveOk,
+                       int* usedWave) {
   int cw = 7, ch = 7;  // largest cell image of this geometry (cell + 6 px overlap, cpp:1094-1103)
   for (int l = 0; l < g.nlevels; l++) {
     cw = std::max(cw, std::min(g.L[l].wCell + 6, ORBX_CELL_MAX));
     ch = std::max(ch, std::min(g.L[l].hCell + 6, ORBX_CELL_MAX));
   }
   static const bool forceOld = getenv("ORBX_FAST_WG") != nullptr;  // diagnostics: the workgroup-per-cell kernel
+  if (usedWave) *usedWave = (waveOk && img0Aligned && cells && !forceOld) ? 1 : 0;
   if (waveOk && img0Aligned && cells && !forceOld) {
     // one wave per workgroup, FW_CPW cells per wave; x size padded to whole rounds of 8 runs (XCD-aware order)
     const int groups = ((g.nCellsTotal + FW_CPW - 1) / FW_CPW + 8 * FW_XK - 1) / (8 * FW_XK) * (8 * FW_XK);

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void k_sel_compact(const SelKp* __restrict__ s
 }
 
 hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, const int* cellCount, const OctLaunch& P,
-                         SelKp* selStage, int* nselLevel, uint8_t* scratch, int maxQuota, int* maxN, int nHint) {
+                         SelKp* selStage, int* nselLevel, uint8_t* scratch, int maxQuota, int* maxN, int nHint, int* usedInstance) {
   // workgroups are dispatched x-fastest: all frames of level 0 first, then level 1, ...  The units of the lowest levels
   // run longest (most candidates, largest quota), so this is longest-processing-time-first and keeps the tail short.
   dim3 grid(nFrames, P.nlevels, 1), block(OCT_T, 1, 1);
@@ -221,11 +221,13 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
   // nHint = largest candidate count of a unit in the previous batch (0 = unknown): with 6 % headroom below 1024 the
   // smaller instance (30 KB of LDS) runs five workgroups per CU instead of four.
   static const bool noSmall = getenv("ORBX_OCT_NO_SMALL") != nullptr;  // diagnostics: always the 2048-candidate instance
+  if (usedInstance) *usedInstance = 0;
   if (maxQuota >= (1 << 30)) {  // test hook (orbx_debug_distribute_device variant 1): every unit on global scratch
     hipLaunchKernelGGL(k_octree_global, grid, dim3(1024), 0, st, cand, cellCount, P, selStage, nselLevel, scratch, 1);
     return hipGetLastError();
   }
   const int deferBig = (maxQuota > 256 || nHint > 2048) ? 1 : 0;
+  if (usedInstance) *usedInstance = (nHint > 0 && nHint <= 960 && !noSmall && !deferBig) ? 1024 : 2048;
   if (nHint > 0 && nHint <= 960 && !noSmall && !deferBig)
     hipLaunchKernelGGL((k_octree_lds<1024, 256>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN, 0);
   else

@@ -84,6 +84,15 @@ def synth_frames(n: int, w: int, h: int, seed0: int = 1000) -> np.ndarray:
     return out
 
 
+def bench_input_sets(n: int, w: int, h: int, seed0: int = 1000, nsets: int = 4):
+    """The input sets bench.py rotates through (and tests/test_gpu_headline.py checks against the oracle): the n frames of
+    synth_frames(n, w, h, seed0) and their vertical / horizontal / both mirror images (pairs stay pairs of one scene); a fifth
+    set, for experiments, is the first one in reverse frame order.  Contiguous uint8 arrays [n, h, w]."""
+    frames = synth_frames(n, w, h, seed0=seed0)
+    sets = [frames, frames[:, ::-1, :], frames[:, :, ::-1], frames[:, ::-1, ::-1], frames[::-1]]
+    return [np.ascontiguousarray(s) for s in sets[:max(1, min(nsets, 5))]]
+
+
 def synth_desc(n: int, seed: int, w: int = 3840, h: int = 2160, max_flips: int = 80):
     """Descriptor-set pair for the brute-force match configs: set A = n random 256-bit descriptors with
     uniform positions/angles at octave 0; set B = a permutation of A with k in U[0, max_flips] flipped bits per

@@ -3,6 +3,7 @@
 // usage: shim_demo W H frameA.raw frameB.raw nfeatures iniTh minTh [distort]
 //   distort = 1: the Frame constructor's undistortion + image bounds with the camera of Settings.yaml (Frame.cpp:44,64)
 // prints: N1 N2 nmatches fnv1a(keypoints1) fnv1a(desc1) fnv1a(matches12)
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -48,6 +49,9 @@ int main(int argc, char** argv) {
     ORBmatcher orbMatcher(0.9f, true, &extractor);  // demo :105
     std::vector<int> mvMatches;
     const int nmatches = orbMatcher.SearchForInitialization(f1, f2, mvMatches, 100);  // demo :108
+    // odr-uses of the matcher's constants (Features/ORBmatcher.cpp:5-7 defines them out of class; the shim's are inline)
+    const int& thLow = std::min(ORBmatcher::TH_LOW, ORBmatcher::TH_HIGH);
+    if (thLow != 50 || *&ORBmatcher::HISTO_LENGTH != 30) return 5;
     std::printf("RESULT %zu %zu %d %llu %llu %llu\n", k1.size(), k2.size(), nmatches, fnv(k1.data(), k1.size() * sizeof(orbx::KeyPoint)),
                 fnv(d1.data(), d1.size()), fnv(mvMatches.data(), mvMatches.size() * sizeof(int)));
   } catch (const orbx::Error& e) {

@@ -127,6 +127,58 @@ def test_ordering_against_torch_stream(orbx, oracle):
     e.close()
 
 
+@pytest.mark.parametrize("lanes", [0, 2])
+def test_order_before_with_pairs_beyond_the_fast_matcher(orbx, oracle, lanes):
+    """the event-only contract of orbx_order_before must also hold for batches whose pairs overflow k_match_jacobi
+    (~1100 octave-0 keypoints per frame here) at a moment when the context has stopped issuing the wide matcher kernels with
+    its batches: (a) a batch already in flight without them is completed by the first orbx_order_before; (b) every later batch
+    carries them, so a torch consumer ordered by the event alone reads final nmatches / matches12 -- no host-side wait."""
+    import torch
+    from orb_slam_tracking_amd import synth
+    params = (2000, 1.2, 2, 20, 7)
+    B, cap, w, h = 8, 2000, 640, 480
+    e = orbx.ORBextractor(*params, max_width=w, max_height=h, max_batch=B)
+    if lanes:
+        e.set_pipeline_depth(lanes)
+    oe = oracle.Extractor(*params)
+    rich = synth.synth_frames(B, w, h, seed0=4300)
+    d_rich = torch.from_numpy(rich).cuda()
+    first = np.arange(0, B, 2, dtype=np.int32)
+    exp = []
+    for p_ in range(B // 2):
+        a, b = oe(rich[2 * p_]), oe(rich[2 * p_ + 1])
+        assert (a[1]["octave"] == 0).sum() > 600
+        exp.append(oracle.match_init(a[1], a[2], b[1], b[2], (0, w, 0, h), 100, 0.9, True))
+
+    def outs():
+        return dict(k=torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"), d=torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda"),
+                    n=torch.zeros(B, dtype=torch.int32, device="cuda"), m=torch.full(((B // 2) * cap,), -9, dtype=torch.int32, device="cuda"),
+                    nm=torch.full((B // 2,), -9, dtype=torch.int32, device="cuda"))
+
+    def issue(o):
+        e.extract_match_batch_device_async(d_rich, B, w, h, w, w * h, o["k"], o["d"], o["n"], first, first + 1, (0, w, 0, h), o["m"], o["nm"],
+                                           None, 100, 0.9, True, cap)
+
+    def consume(o):  # a torch consumer behind the event only
+        e.order_before(torch.cuda.current_stream().cuda_stream)
+        nm, m = o["nm"].clone(), o["m"].clone()
+        torch.cuda.current_stream().synchronize()  # (of torch's stream: the context's own waits are not called)
+        nm, m = nm.cpu().numpy(), m.cpu().numpy().reshape(B // 2, cap)
+        for p_, (onm, om12, _) in enumerate(exp):
+            assert nm[p_] == onm and np.array_equal(m[p_, :len(om12)], om12), p_
+    o1, o2, o3 = outs(), outs(), outs()
+    issue(o1)                                        # a fresh context does not issue the wide kernels with its batches
+    assert e.debug_last_launch()["wide_with_batch"] == 0
+    consume(o1)                                      # (a) completed by the first orbx_order_before
+    issue(o2)
+    assert e.debug_last_launch()["wide_with_batch"] == 1
+    issue(o3)
+    consume(o2)                                      # (b) the wide kernels travelled with the batches
+    consume(o3)
+    e.wait()
+    e.close()
+
+
 def _fnv(b):
     h = 1469598103934665603
     for x in bytes(b):

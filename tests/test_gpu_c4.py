@@ -101,6 +101,41 @@ def test_config4_rccl(orbx, c4_oracle, tmp_path):
     _check([out] + ["%s.rank%d.npz" % (out, r) for r in range(1, world)], c4_oracle, orbx)
 
 
+def _bench_line(out):
+    import json
+    lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, out[-3000:]
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks(orbx):
+    """`python bench.py --gpus 2`, started plainly (no launcher, as the driver starts it): bench.py spawns its ranks itself before
+    anything touches the GPU.  Rehearsal on the one-GPU box: gloo, both ranks on cuda:0.  The line says n_gpus 2, the counts were
+    all-gathered and equal the ranks' own, and the last batch equals the oracle."""
+    out = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device", "--steps", "5",
+                "--warmup", "2", "--prime", "4", "--regions", "1", "--no-cpu-baseline", "--no-single-frame"])
+    d = _bench_line(out)
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["checked"] is True, d["check"]
+    c = d["config"]["collective"]
+    assert c["world_size"] == 2 and c["all_gathers"] >= 5 and c["gathered_counts_ok"] is True
+    assert d["config"]["rccl_ranks"] == 0  # gloo rehearsal: RCCL did not run, and the line says so
+
+
+def test_bench_rccl_ranks(orbx):
+    """The same over RCCL, one rank per GPU, whenever the box has more than one."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("RCCL needs more than one GPU: this box has %d (the driver's multi-GPU run covers N = 2, 4, 8)" % n)
+    world = 8 if n >= 8 else 4 if n >= 4 else 2
+    out = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "20", "--warmup", "3", "--regions", "1",
+                "--no-cpu-baseline", "--no-single-frame"])
+    d = _bench_line(out)
+    assert d["n_gpus"] == world and d["checked"] is True and d["config"]["rccl_ranks"] == world
+    assert d["config"]["collective"]["gathered_counts_ok"] is True
+
+
 def _multi_run(orbx, devices, n_frames, c4_oracle):
     """orbx_multi_* (the C ABI a C++ host uses) on `devices`: blocks resident per device, fused extract + match per block, counts
     all-gathered (RCCL when more than one device); everything against the oracle."""

@@ -827,8 +827,8 @@ def test_to_gray_and_colour_chain(orbx, ext640, oracle):
 
 @pytest.mark.parametrize("nosplit", [False, True])
 def test_banded_pyramid_large_batch(orbx, oracle, nosplit, monkeypatch):
-    """Batches of >= 32 frames per stream build the pyramid with k_pyramid_bands (one launch, row bands with halos; 16
-    bands for 32..63 frames, 8 bands from 64 frames): pyramid levels and extraction results equal the oracle, for an
+    """Batches of >= 32 frames per stream build the pyramid with k_pyramid_bands (one launch, row bands with halos; three
+    bands per 640x480 frame from 86 frames per stream, more and thinner ones below: ceil(256 / frames)): pyramid levels and extraction results equal the oracle, for an
     even-sized and an odd-height frame size."""
     import torch
     from orb_slam_tracking_amd import synth

@@ -194,3 +194,19 @@ def test_cpp_shim_compiles_and_links(orbx, tmp_path):
         p = subprocess.run([exe, "640", "480", str(raw), str(raw), "1000", "20", "7"], stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, text=True)
         assert p.returncode != 0 and "RESULT" not in p.stdout
+
+
+def test_bench_gpus_n_launches_its_ranks():
+    """`python bench.py --gpus 2` outside a launcher starts two ranks (torch.distributed.run children) instead of asking for one;
+    without a GPU each rank stops at bench.py's own "needs a GPU" exit -- which proves the ranks were started -- and the exit code
+    of the children comes back."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side check of the launcher path")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode != 0
+    assert "bench.py needs a GPU" in p.stdout and "launch with torch.distributed.run" not in p.stdout, p.stdout[-2000:]

@@ -3,7 +3,9 @@
 set -e
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_INSTS_VALU_IOPS SQ_WAVE_CYCLES --output-format csv -d $OUT/mb -- $R/tools/microbench/valu_rate > $OUT/mb.log 2>&1
+# the microbenchmark is always built from its source here (no binary is kept in the tree)
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $OUT/valu_rate $R/tools/microbench/valu_rate.hip
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_INSTS_VALU_IOPS SQ_WAVE_CYCLES --output-format csv -d $OUT/mb -- $OUT/valu_rate > $OUT/mb.log 2>&1
 python3 - <<PY
 import csv,glob,collections,re
 f=glob.glob("$OUT/mb/*/*_counter_collection.csv")[0]
