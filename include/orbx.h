@@ -308,7 +308,8 @@ int orbx_debug_candidates(orbx_ctx* ctx, int frame, int level, float* xyr, int c
 /* The quadtree selection alone, DistributeOctTree (cpp:698-1011), on the device (the kernels the pipeline uses).  Candidates must be given in row-major (y, x)
  * order with integer coordinates in [0, 4095] relative to (min_x, min_y) and integer responses in [0, 255].
  * variant 0 = LDS-resident kernel (redoing a unit that does not fit on global scratch), variant 1 = global-scratch kernel
- * only, variant 2 = the smaller LDS instance (<= 1024 candidates) that the pipeline picks when the previous batch allows. */
+ * only, variant 2 = the smaller LDS instance (<= 1024 candidates) and variant 3 = the smallest one (<= 512 candidates, quota
+ * <= 128) that the pipeline picks per pyramid level when the previous batch allows. */
 int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min_x, int max_x, int min_y, int max_y,
                                  int n_features, int variant, float* out_xyr, int cap);
 /* The device's literal replay of libstdc++ std::sort with the reference's compareNodes (cpp:684-696, 912) on n
@@ -321,7 +322,8 @@ int orbx_debug_sincos(orbx_ctx* ctx, const float* angle_deg, int n, float* cos_o
 /* How the context's last extraction batch was issued (the kernels behind one entry point depend on batch size, frame size,
  * alignment and the previous batch's statistics): info8 = { [0] pyramid: 1 = k_pyramid_bands (one launch), 0 = one resize launch
  * per level; [1] row bands per frame of k_pyramid_bands; [2] FAST: 1 = k_fast_wave, 0 = k_fast; [3] selection: candidate
- * capacity of the LDS instance the lowest level ran on (0 = every unit on global scratch); [4] 1 = the batch was cut into two
+ * capacity of the smallest LDS instance a pyramid level of the batch ran on (2048 / 1024 / 512; 0 = a level expected units beyond
+ * the LDS layout and went to the global-scratch kernel); [4] 1 = the batch was cut into two
  * halves on two streams; [5] frames per kernel launch; [6] 1 = the wide matcher kernels went with the batch; [7] lane the batch
  * went to (1-based; 0 = the context itself) }. */
 int orbx_debug_last_launch(const orbx_ctx* ctx, int32_t* info8);

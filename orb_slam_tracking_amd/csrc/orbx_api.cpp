@@ -36,7 +36,7 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
                         const uint8_t* desc, const int* nkp, int capacity, orbx_bounds b, int window, float nnratio, int checkOri,
                         int* matches12, int* nmatches, int* stats, int* scratch, int pair0, int wideMode, int* hostWide);
 hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, const int* cellCount, const OctLaunch& P,
-                         SelKp* selStage, int* nselLevel, uint8_t* scratch, int maxQuota, int* maxN, int nHint, int* usedInstance);
+                         SelKp* selStage, int* nselLevel, uint8_t* scratch, int* maxN, const int* hintL, int force, int* usedInstance);
 hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage, const int* nselLevel, const OctLaunch& P,
                               SelKp* sel, int* nsel, int* nselUser, int* hostNsel, int selCap, int* hostErr, int* maxN,
                               int* hostMaxN);
@@ -94,7 +94,7 @@ struct orbx_ctx {
   int* dMaxN = nullptr;        // [stream slot][level] largest candidate count of a unit (k_octree_lds), reset by k_sel_compact
   int* hMaxN = nullptr;        // pinned mirror, written by k_sel_compact
   int* hMaxNDev = nullptr;
-  int candHint = 0;            // largest candidate count of a unit in the previous batch of this geometry (0 = unknown)
+  int candHintL[ORBX_MAX_LEVELS]{};  // per level: largest candidate count of a unit in the previous batch of this geometry (0 = unknown)
   int maxSlotsUsed = 0;
   size_t cellCountEntries = 0;
   int* dOverflow = nullptr;
@@ -619,7 +619,7 @@ int allocAll(orbx_ctx* ctx) {
   if (hipHostGetDevicePointer((void**)&ctx->hWideDev, ctx->hWide, 0) != hipSuccess) return ORBX_E_HIP;
   ctx->hFlags[0] = ctx->hFlags[1] = 0;
   for (int i = 0; i < 2 * ORBX_MAX_LEVELS; i++) ctx->hMaxN[i] = 0;
-  ctx->candHint = 0;
+  for (int& v : ctx->candHintL) v = 0;
   ctx->maxSlotsUsed = 0;
 #undef ALLOC
 #undef ALLOCH
@@ -696,7 +696,7 @@ int ensureGeometry(orbx_ctx* ctx, int w, int h, int stride0) {
   ctx->curW = w;
   ctx->curH = h;
   ctx->curStride0 = stride0;
-  ctx->candHint = 0;  // candidate statistics of another frame size say nothing about this one
+  for (int& v : ctx->candHintL) v = 0;  // candidate statistics of another frame size say nothing about this one
   return ORBX_OK;
 }
 
@@ -843,8 +843,8 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
     StageTimer tm(ctx, ORBX_STAGE_SELECT, si, st);
     // per-level candidate maxima of this stream slot: device accumulators + their pinned host mirror (read after the sync)
     int* dMax = ctx->dMaxN + si * ORBX_MAX_LEVELS;
-    HIPCHK(launch_octree(st, n, ctx->dCand, ctx->dCellCount, oct, ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, ctx->maxQuota,
-                         dMax, ctx->candHint, &ctx->lastLaunch[3]));
+    HIPCHK(launch_octree(st, n, ctx->dCand, ctx->dCellCount, oct, ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, dMax,
+                         ctx->candHintL, 0, &ctx->lastLaunch[3]));
     HIPCHK(launch_sel_compact(st, n, ctx->dSelStage, ctx->dNselLevel, oct, ctx->dSel, ctx->dNsel, a.dNuser, ctx->hNselDev, g.selCap,
                               ctx->hFlagsDev + ctx->parity, dMax, ctx->hMaxNDev + si * ORBX_MAX_LEVELS));
     ctx->maxSlotsUsed |= 1 << si;
@@ -958,12 +958,13 @@ int waitOldest(orbx_ctx* ctx) {
     if (sm != ORBX_OK) return sm;
   }
   collectProfile(ctx, parity);
-  {  // largest candidate count of a unit in the batches seen so far: picks the selection kernel's instance for the next one
-    int m = 0;
-    for (int q = 0; q < 2; q++)
-      if (ctx->maxSlotsUsed & (1 << q))
-        for (int l = 0; l < ctx->p.nlevels; l++) m = std::max(m, ctx->hMaxN[q * ORBX_MAX_LEVELS + l]);
-    ctx->candHint = m;
+  {  // per level, the largest candidate count of a unit in the batch: picks the selection kernel's instances for the next one
+    for (int l = 0; l < ctx->p.nlevels; l++) {
+      int m = 0;
+      for (int q = 0; q < 2; q++)
+        if (ctx->maxSlotsUsed & (1 << q)) m = std::max(m, ctx->hMaxN[q * ORBX_MAX_LEVELS + l]);
+      ctx->candHintL[l] = m;
+    }
     if (ctx->pending == 0) ctx->maxSlotsUsed = 0;
   }
   if (ctx->hFlags[parity]) {  // raised by this batch's k_sel_compact through mapped host memory (one slot per parity: the
@@ -2004,7 +2005,8 @@ extern "C" {
 
 // DistributeOctTree on the device for caller-supplied candidates given in row-major (y, x) order, integer coordinates
 // relative to (min_x, min_y) in [0, 4095], integer responses in [0, 255].  variant 0 = LDS kernel (falls through to
-// the global-scratch kernel when it cannot take the unit), 1 = global-scratch kernel only.
+// the global-scratch kernel when it cannot take the unit), 1 = global-scratch kernel only, 2 / 3 = the 1024- / 512-candidate
+// LDS instances (a unit that does not fit is redone by the same workgroup on global scratch).
 int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min_x, int max_x, int min_y, int max_y,
                                  int n_features, int variant, float* out_xyr, int cap) {
   if (!ctx || n < 0 || (n > 0 && !xyr) || max_x <= min_x || max_y <= min_y || n_features < 0 || n > ORBX_OCT_MAX_CAND)
@@ -2047,7 +2049,8 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
     HIPCHK(hipMemcpyAsync(dC, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->st));
     int hi[2] = {n, -7};
     HIPCHK(hipMemcpyAsync(dI, hi, sizeof hi, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(launch_octree(ctx->st, 1, dC, dI, P, dS, dI + 1, dScr, variant == 0 ? n_features : (1 << 30), nullptr, variant == 2 ? 1 : 0, nullptr));
+    HIPCHK(launch_octree(ctx->st, 1, dC, dI, P, dS, dI + 1, dScr, nullptr, nullptr,
+                         variant == 1 ? -1 : variant == 2 ? 1024 : variant == 3 ? 512 : 0, nullptr));
     HIPCHK(hipMemcpyAsync(res, dI, sizeof res, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(sel.data(), dS, sel.size() * sizeof(SelKp), hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));

@@ -17,6 +17,7 @@
 // matters as the tie-breaker "first of the highest responses", so it is carried as an order key, never materialised.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 
@@ -85,12 +86,14 @@ template <int NMAX, int QMAX>
 __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict__ cand, const int* __restrict__ cellCount,
                                                      const OctLaunch P, SelKp* __restrict__ selStage,
                                                      int* __restrict__ nselLevel, uint8_t* __restrict__ scratch,
-                                                     int* __restrict__ maxN, int deferBig) {
+                                                     int* __restrict__ maxN, int deferBig, int level0) {
   constexpr int MCAP = 4 * QMAX, FCAP = 2 * QMAX;
   static_assert((NMAX & (NMAX - 1)) == 0 && (MCAP & (MCAP - 1)) == 0, "sort buffers must be powers of two");
   // LDS budget (QMAX 256): NMAX 2048: 16 + 8 + 4 + 6 + 2 + 3 KB = 39 KB -> FOUR workgroups per CU (it was 51 KB and three
   //                        until sorted positions became 16-bit here and alone[] a function of div[]);
-  //                        NMAX 1024:  8 + 8 + 3.4 + 6 + 1 + 3 KB = 29.4 KB -> five (launch_octree picks the instance).
+  //                        NMAX 1024:  8 + 8 + 3.4 + 6 + 1 + 3 KB = 29.4 KB -> five;
+  //            (QMAX 128)  NMAX  512:  4 + 4 + 3.4 + 3 + 0.5 + 1.5 KB = 16.5 KB -> eight (the wave slots of the CU), for the upper
+  //                        levels, whose quotas and candidate counts are small (launch_octree picks the instance per level).
   //   nodes[] is dead once the node records exist, so the partial pass's buffers (sized, pending, childCnt) live in it, and
   //   it is not yet written while step 1 reads the candidate position list, which therefore lives there too;
   //   hiOf[] (steps 3-4) shares its space with the parallel std::sort replay's scratch (partial pass).
@@ -113,9 +116,11 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   u64* sized = nodes;                                             // [2 * QMAX]
   int* pending = reinterpret_cast<int*>(nodes + 2 * QMAX);        // [2 * QMAX]
   int* childCnt = pending + 2 * QMAX;                             // [QMAX]
-  const int level = blockIdx.y, f = blockIdx.x + P.frame0;  // level-major dispatch, see launch_octree
+  const int level = blockIdx.y + level0, f = blockIdx.x + P.frame0;  // level-major dispatch, see launch_octree
   int* nOut = &nselLevel[f * P.nlevels + level];
-  static_assert(NMAX + MCAP >= OCT_SORT_LDS, "keys[] + nodes[] double as the sort exchange buffer of the global-scratch path");
+  // keys[] + nodes[] double as the sort exchange buffer of the global-scratch path: a workgroup's worth of padded keys, the radix
+  // sort's 256 x 4 digit counters (4 KB) and the parallel std::sort replay's scratch must fit
+  static_assert(NMAX + MCAP >= 1024 && (NMAX + MCAP) * 2 >= OCT_PAR_SCR_FOR(OCT_PAR_MAX), "exchange buffer of the global-scratch path");
   __shared__ int redo;
   __shared__ int gws[OCT_T / 64];
   const uint32_t* segBase = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   const int n = gatherCandidates(cellCnt, P.lev[level].nCells, P.lev[level].segCap, candL, NMAX, threadIdx.x, gws);
   if (threadIdx.x == 0 && maxN) atomicMax(&maxN[level], n);  // feedback for the next batch's choice of instance
   if (n <= NMAX && P.lev[level].quota <= QMAX) {
-    OctScratchT<uint16_t> S{keys, nodes, div, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, childCnt, candL, segBase, nullptr,
+    OctScratchT<uint16_t> S{keys, nodes, div, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, childCnt, candL, segBase, nullptr, 0,
                             hiPar /* hiOf's space: dead during the partial pass */, PARCAP};
     octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, MCAP, FCAP, QMAX);
     __syncthreads();
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
     return;
   }
   __syncthreads();
-  octreeGlobalUnit(cand, cellCount, P, selStage, nselLevel, scratch, level, f, keysNodes);
+  octreeGlobalUnit(cand, cellCount, P, selStage, nselLevel, scratch, level, f, keysNodes, NMAX + MCAP);
 }
 
 // global-scratch variant, 1024 threads, for the (frame, level) units the LDS variant left (nselLevel == -2), or for all
@@ -150,11 +155,11 @@ static_assert(OCT_SORT_LDS * 2 >= 256 * (1024 / 64), "... and as the 256 x nWave
 static_assert(OCT_SORT_LDS >= 1024, "the register sort of the 1024-thread instance exchanges 1024 padded keys through it");
 __global__ __launch_bounds__(1024) void k_octree_global(const uint32_t* __restrict__ cand, const int* __restrict__ cellCount,
                                                        const OctLaunch P, SelKp* __restrict__ selStage,
-                                                       int* __restrict__ nselLevel, uint8_t* __restrict__ scratch, int all) {
+                                                       int* __restrict__ nselLevel, uint8_t* __restrict__ scratch, int all, int level0) {
   __shared__ u64 xchg[OCT_SORT_LDS];
-  const int level = blockIdx.y, f = blockIdx.x + P.frame0;  // level-major dispatch, see launch_octree
+  const int level = blockIdx.y + level0, f = blockIdx.x + P.frame0;  // level-major dispatch, see launch_octree
   if (!all && nselLevel[f * P.nlevels + level] != -2) return;
-  t1024::octreeGlobalUnit(cand, cellCount, P, selStage, nselLevel, scratch, level, f, xchg);
+  t1024::octreeGlobalUnit(cand, cellCount, P, selStage, nselLevel, scratch, level, f, xchg, OCT_SORT_LDS);
 }
 
 size_t octScratchBytes(int nMax, int qMax) {
@@ -209,33 +214,92 @@ __global__ __launch_bounds__(256) void k_sel_compact(const SelKp* __restrict__ s
   }
 }
 
+// Instance of the LDS kernel for one level: the smallest one that holds the level's quota and, with 6 % headroom, the largest
+// candidate count a unit of that level had in the previous batch of this geometry (0 = unknown: the 2048-candidate instance).
+// 0 = the level expects units beyond the LDS layout (a quota above 256, more than 2048 candidates): those go to k_octree_global.
+static int octInstanceFor(int quota, int hint) {
+  if (quota > 256 || hint > 2048) return 0;
+  if (hint > 0 && hint <= 480 && quota <= 128) return 512;
+  if (hint > 0 && hint <= 960) return 1024;
+  return 2048;
+}
+
 hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, const int* cellCount, const OctLaunch& P,
-                         SelKp* selStage, int* nselLevel, uint8_t* scratch, int maxQuota, int* maxN, int nHint, int* usedInstance) {
+                         SelKp* selStage, int* nselLevel, uint8_t* scratch, int* maxN, const int* hintL, int force,
+                         int* usedInstance) {
   // workgroups are dispatched x-fastest: all frames of level 0 first, then level 1, ...  The units of the lowest levels
   // run longest (most candidates, largest quota), so this is longest-processing-time-first and keeps the tail short.
-  dim3 grid(nFrames, P.nlevels, 1), block(OCT_T, 1, 1);
   // Units the LDS variant cannot take (more than NMAX candidates, quota above 256, node-table overflow) run on global
-  // scratch: when the launch expects them (a quota above 256, or more than 2048 candidates in a unit of the previous
+  // scratch: when a level expects them (a quota above 256, or more than 2048 candidates in a unit of the previous
   // batch) they are deferred to k_octree_global, which gives each of them 1024 threads; otherwise the LDS kernel's own
   // workgroup handles the rare outlier and no second kernel is launched.
-  // nHint = largest candidate count of a unit in the previous batch (0 = unknown): with 6 % headroom below 1024 the
-  // smaller instance (30 KB of LDS) runs five workgroups per CU instead of four.
+  // force: 0 = choose per level from hintL (nullptr = unknown); 2048 / 1024 / 512 = that LDS instance for every level (test
+  // hook, diagnostics); -1 = every unit on global scratch (test hook).
   static const bool noSmall = getenv("ORBX_OCT_NO_SMALL") != nullptr;  // diagnostics: always the 2048-candidate instance
+  // ORBX_OCT_SPLIT_MIN (diagnostics) = batch size from which every group of consecutive levels with the same instance gets its
+  // own launch.  Off by default: measured on the bench workload (256 frames, four lanes) 2048 | 1024 x 2 | 512 x 5 gives 295.9 k
+  // frames/s, 2048 x 3 | 512 x 5 300.2 k, 2048 | 1024 x 7 302.3 k against 306.6 k with ONE launch on the largest instance --
+  // consecutive launches of a stream do not overlap (hipExtAnyOrderLaunch is ignored on gfx9: tools/microbench/any_order.hip),
+  // so every group adds its own tail, and that costs more than the smaller units' LDS gives back to the other lanes.
+  static const int splitMin = getenv("ORBX_OCT_SPLIT_MIN") ? atoi(getenv("ORBX_OCT_SPLIT_MIN")) : (1 << 30);
   if (usedInstance) *usedInstance = 0;
-  if (maxQuota >= (1 << 30)) {  // test hook (orbx_debug_distribute_device variant 1): every unit on global scratch
-    hipLaunchKernelGGL(k_octree_global, grid, dim3(1024), 0, st, cand, cellCount, P, selStage, nselLevel, scratch, 1);
+  if (force < 0) {
+    hipLaunchKernelGGL(k_octree_global, dim3(nFrames, P.nlevels, 1), dim3(1024), 0, st, cand, cellCount, P, selStage, nselLevel, scratch,
+                       1, 0);
     return hipGetLastError();
   }
-  const int deferBig = (maxQuota > 256 || nHint > 2048) ? 1 : 0;
-  if (usedInstance) *usedInstance = (nHint > 0 && nHint <= 960 && !noSmall && !deferBig) ? 1024 : 2048;
-  if (nHint > 0 && nHint <= 960 && !noSmall && !deferBig)
-    hipLaunchKernelGGL((k_octree_lds<1024, 256>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN, 0);
-  else
-    hipLaunchKernelGGL((k_octree_lds<2048, 256>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN,
-                       deferBig);
-  if (deferBig)
-    hipLaunchKernelGGL(k_octree_global, grid, dim3(1024), 0, st, cand, cellCount, P, selStage, nselLevel, scratch, 0);
-  return hipGetLastError();
+  int inst[ORBX_MAX_LEVELS];
+  int largest = 512;
+  bool anyBig = false;
+  for (int l = 0; l < P.nlevels; l++) {
+    inst[l] = force > 0 ? force : octInstanceFor(P.lev[l].quota, hintL ? hintL[l] : 0);
+    if (noSmall && inst[l] != 0 && force == 0) inst[l] = 2048;
+    if (inst[l] == 0) anyBig = true;
+    largest = std::max(largest, inst[l] == 0 ? 2048 : inst[l]);
+  }
+  // One launch on the largest instance any level needs (the levels of the reference's own 640x480 images stay below 960
+  // candidates -> 30 KB units; sparse scenes with small quotas -> 17 KB units).
+  if (nFrames < splitMin && force == 0)
+    for (int l = 0; l < P.nlevels; l++) inst[l] = anyBig ? 0 : largest;
+  static const char* instEnv = getenv("ORBX_OCT_INST");  // diagnostics: "2048,2048,1024,512,..." = the instance of every level
+  if (instEnv && force == 0 && !anyBig && hintL && hintL[0] > 0) {
+    const char* q = instEnv;
+    for (int l = 0; l < P.nlevels && *q; l++) {
+      const int v = atoi(q);
+      if (v == 512 || v == 1024 || v == 2048) inst[l] = std::max(inst[l] == largest ? octInstanceFor(P.lev[l].quota, hintL[l]) : inst[l], v);
+      while (*q && *q != ',') q++;
+      if (*q == ',') q++;
+    }
+  }
+  if (usedInstance) {  // the smallest instance any level runs on (0: some level goes to k_octree_global)
+    int m = 1 << 30;
+    for (int l = 0; l < P.nlevels; l++) m = std::min(m, inst[l]);
+    *usedInstance = m;
+  }
+  for (int l0 = 0; l0 < P.nlevels;) {
+    int l1 = l0 + 1;
+    while (l1 < P.nlevels && inst[l1] == inst[l0]) l1++;
+    const dim3 grid(nFrames, l1 - l0, 1), block(OCT_T, 1, 1);
+    switch (inst[l0]) {
+      case 512:
+        hipLaunchKernelGGL((k_octree_lds<512, 128>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN, 0, l0);
+        break;
+      case 1024:
+        hipLaunchKernelGGL((k_octree_lds<1024, 256>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN, 0, l0);
+        break;
+      case 2048:
+        hipLaunchKernelGGL((k_octree_lds<2048, 256>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN, 0, l0);
+        break;
+      default:  // the level expects large units: what fits the LDS layout is done there, the rest is deferred
+        hipLaunchKernelGGL((k_octree_lds<2048, 256>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN, 1, l0);
+        hipLaunchKernelGGL(k_octree_global, grid, dim3(1024), 0, st, cand, cellCount, P, selStage, nselLevel, scratch, 0, l0);
+        break;
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    l0 = l1;
+  }
+  return hipSuccess;
 }
 
 hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage, const int* nselLevel, const OctLaunch& P,

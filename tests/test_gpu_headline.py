@@ -96,6 +96,7 @@ def test_headline_shape_equals_oracle(orbx, headline, depth):
         else:
             assert info["split"] == 1 and info["frames_per_launch"] == B // 2 and info["lane"] == 0, info
         assert info["wide_with_batch"] == 0, info  # no bench pair leaves k_match_jacobi
+        assert info["octree_instance"] == 2048, info  # level 0 of these frames has more than 1024 candidates: 40 KB selection units
     e.wait()
     for k in range(NBATCH - nout, NBATCH):
         snap(k)
