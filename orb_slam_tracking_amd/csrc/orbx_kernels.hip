@@ -1055,11 +1055,12 @@ __host__ __device__ constexpr uint32_t descHTap(int t, int m) {
   }
   return k;
 }
-// The arithmetic of one keypoint on its staged raw window (IC_Angle, patch-local Gaussian, steered BRIEF), shared by the two
-// descriptor kernels.  raw: [43][RS] dwords (window column 0 at byte s of a row), overwritten with the blurred bytes; hz2: [22][40]
+// The arithmetic of one keypoint on its staged raw window (IC_Angle, patch-local Gaussian, steered BRIEF).  (A separate function
+// since round 3's k_describe_loop experiment -- a wave walking four keypoints with the next window prefetched by LDS-DMA, slower:
+// docs/history.md -- shared it with k_describe_patch.)  raw: [43][RS] dwords (window column 0 at byte s of a row), overwritten with the blurred bytes; hz2: [22][40]
 // dwords; msum: two ints, zeroed by the caller.  Every wave works on its own LDS slice: LDS operations of one wave execute in
 // order, the fences only pin the compiler's order.  Returns the angle; words[] = the 256 descriptor bits (wave-uniform).
-template <int GV, int RS /* dwords per staged window row: 13 (k_describe_patch) or 12 (k_describe_loop) */>
+template <int GV, int RS /* dwords per staged window row */>
 __device__ __forceinline__ float descCompute(uint32_t* raw, uint32_t* hz2, int* msum, const int s, const int lane, const uint4 w1a,
                                              const uint4 w1b, const uint4 wua, const uint4 wub, const float4 (&pat)[4],
                                              const uint32_t (&hitem)[3], unsigned long long (&words)[4]) {
@@ -1310,199 +1311,6 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
     kps[o] = kp;
   }
   DS_STAMP(5);
-}
-
-// -------------------------------------------------------------------------------------------------
-// k_describe_loop: the same arithmetic (descCompute), but a wave walks DL_KPW consecutive keypoints of its frame's list, and
-// the raw window of keypoint j + 1 is fetched by LDS-DMA (global_load_lds_dword: no VGPR destination, no ds_write) into the
-// wave's second raw buffer while keypoint j is computed.  In k_describe_patch 63 % of a wave's lifetime is the wait for its
-// window (tools/desc_stamps.py) with 27 waves per CU to cover it; here the wave covers it itself, and the tables (disc weights,
-// BRIEF pattern, blur items) are loaded once per wave instead of once per keypoint.
-//   * window staging layout = lane-linear, as LDS-DMA demands: rows of 48 bytes (12 dwords: the 43 columns start at byte s <= 3
-//     of the 4-aligned row start) = three 16-byte pieces, piece G of the window at raw + 16 G, so a wave-instruction of 64 pieces
-//     (global_load_lds_dwordx4) fills 1 KiB and three of them the window -- with single dwords (eleven instructions, the
-//     layout of k_describe_patch) issuing the DMAs took a wave 3.4 k cycles per keypoint;
-//   * ordering: the DMA of window j + 1 is issued at the top of iteration j, after the wave's last LDS reads of iteration
-//     j - 1 (same buffer) have returned; iteration j + 1 starts with s_waitcnt vmcnt(0).  The results of keypoint j are stored
-//     at the top of iteration j + 1, BEFORE the next DMA is issued, so that this wait never waits for a younger store;
-//   * the DMA is inline assembly (the compiler does not count it): no ordinary vector load is issued while one is in flight
-//     (the keypoint records come through scalar loads), so no compiler-generated vmcnt wait can stall on it;
-//   * dwords that cross the level's left / right edge (REFLECT_101 byte gathers; keypoints within ~20 px of the edge) and
-//     unaligned level-0 rows are not DMA-able: those lanes fill their dwords with byte loads at the top of the keypoint's own
-//     iteration.
-// -------------------------------------------------------------------------------------------------
-#ifndef DL_WAVES
-#define DL_WAVES 2
-#endif
-#ifndef DL_KPW
-#define DL_KPW 4
-#endif
-#ifndef DL_WPE
-#define DL_WPE 4   // waves per SIMD the register allocation aims at
-#endif
-#define DL_RS 12          // dwords per staged row: the window's 43 columns start at byte s <= 3 of a 4-aligned 48-byte row
-#define DL_RAW_WORDS 520  // 43 * 12 = 516, + the dword the horizontal pass reads behind the last row (padding columns), 16-byte multiple
-#define DL_GRANULES (PW_ROWS * 3)  // 16-byte pieces of a window: 129 = two full wave-instructions and one lane of a third
-// one 16-byte LDS-DMA per lane: LDS destination = ldsDst (wave-uniform, M0) + 16 * lane, source = base + voff
-__device__ __forceinline__ void descDmaX4(const uint8_t* base /* wave-uniform */, uint32_t voff, uint32_t ldsDst /* wave-uniform */) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(ldsDst), "s"(base)
-               : "memory");
-}
-template <int GV>
-__global__ __launch_bounds__(64 * DL_WAVES) __attribute__((amdgpu_waves_per_eu(DL_WPE, DL_WPE))) void k_describe_loop(const uint8_t* __restrict__ img0, long long img0FrameStride,
-                                                                int img0Aligned, const uint8_t* __restrict__ pyr, const Geom g,
-                                                                const SelKp* __restrict__ sel, const int* __restrict__ nsel,
-                                                                orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                                int capacity) {
-  // per wave: two raw windows (the blurred bytes of a keypoint overwrite its own raw window), one set of row-pair sums
-  __shared__ __attribute__((aligned(16))) uint32_t rawAll[DL_WAVES][2][DL_RAW_WORDS];
-  __shared__ __attribute__((aligned(16))) uint32_t hzAll[DL_WAVES][PW_PAIRS * PW_COLS + 4];
-  static_assert(BL_ROWS_PAD * (PW_COLS / 4) <= PW_ROWS * DL_RS && PW_ROWS * DL_RS + 1 <= DL_RAW_WORDS && DL_RAW_WORDS % 4 == 0, "raw window");
-  const int f = blockIdx.y + g.frame0, lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // XCD-aware order as in k_describe_patch: one XCD works on a contiguous eighth of the frame's keypoint list
-  const int grp = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int i0 = (grp * DL_WAVES + wave) * DL_KPW;
-  const int cnt = min(DL_KPW, nsel[f] - i0);  // wave-uniform
-  if (cnt <= 0) return;
-  const uint2* const recs = reinterpret_cast<const uint2*>(sel + (long long)f * g.selCap);
-  static_assert(sizeof(SelKp) == 8, "keypoint records are read as uint2");
-  const int icRow = min(lane, 30), icAv = icRow < 15 ? 15 - icRow : icRow - 15;
-  const uint4 w1a = reinterpret_cast<const uint4*>(d_ic.w1 + icAv * 8)[0], w1b = reinterpret_cast<const uint4*>(d_ic.w1 + icAv * 8)[1];
-  const uint4 wua = reinterpret_cast<const uint4*>(d_ic.wu + icAv * 8)[0], wub = reinterpret_cast<const uint4*>(d_ic.wu + icAv * 8)[1];
-  float4 pat[4];
-#pragma unroll
-  for (int wq = 0; wq < 4; wq++) pat[wq] = reinterpret_cast<const float4*>(d_patternf.v)[wq * 64 + lane];
-  uint32_t hitem[3];
-#pragma unroll
-  for (int it = 0; it < 3; it++) hitem[it] = d_descHItems.v[it * 64 + lane];
-  uint32_t* const hz2 = hzAll[wave];
-  int* const msum = reinterpret_cast<int*>(hz2 + PW_PAIRS * PW_COLS);
-  // this lane's 16-byte pieces of a window: piece G = 64 i + lane = (row G / 3, third G % 3), i = 0 .. 2
-  int gRow[3], gX[3];
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    const int G = 64 * i + lane;
-    gRow[i] = (int)(((uint32_t)G * 21846u) >> 16);  // G / 3 for G < 192
-    gX[i] = 16 * (G - 3 * gRow[i]);
-    if (G >= DL_GRANULES) gRow[i] = -1;
-  }
-
-  // record -> SGPRs (x | y << 16, level | response << 8)
-  auto recAt = [&](int j) -> uint2 {
-    const uint2 r = recs[min(i0 + j, g.selCap - 1)];
-    return make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)r.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)r.y));
-  };
-  struct Win {  // what a keypoint's staging and edge fix-up need (wave-uniform)
-    const uint8_t* img;
-    int w, h, stride, kx, ky, ax;
-    bool aligned;
-  };
-  auto winOf = [&](const uint2 r) -> Win {
-    Win q;
-    const int level = (int)(r.y & 0xffu);
-    const LevelGeom& L = g.L[level];
-    q.img = level == 0 ? img0 + (long long)f * img0FrameStride : pyr + L.imgOff + (long long)f * L.frameStride;
-    q.w = L.w; q.h = L.h; q.stride = L.stride;
-    q.kx = (int)(r.x & 0xffffu); q.ky = (int)(r.x >> 16);
-    q.ax = (q.kx - 21) & ~3;  // may be -4
-    q.aligned = level > 0 || img0Aligned != 0;
-    return q;
-  };
-  auto rowOf = [&](const Win& q, int row) {  // REFLECT_101 of window row `row` (cpp:1598-1606 blurs a clone of the level)
-    int yy = q.ky - 21 + row;
-    yy = yy < 0 ? -yy : yy;
-    yy = yy >= q.h ? 2 * q.h - 2 - yy : yy;
-    return min(max(yy, 0), q.h - 1);
-  };
-  // issues the LDS-DMA of a keypoint's window into `rawDst`: the 16-byte pieces that lie inside the level's rows
-  auto stage = [&](const Win& q, uint32_t* rawDst) {
-    const uint32_t ldsBase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)rawDst);
-    const bool inner = q.ky - 21 >= 0 && q.ky + 21 < q.h;  // (uniform) no reflected row
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const int xs = q.ax + gX[i];
-      const int yy = inner ? q.ky - 21 + gRow[i] : rowOf(q, gRow[i]);
-      if (gRow[i] >= 0 && q.aligned && xs >= 0 && xs + 16 <= q.w) descDmaX4(q.img, (uint32_t)(yy * q.stride + xs), ldsBase + (uint32_t)i * 1024u);
-    }
-  };
-  // the pieces the DMA could not fetch (they cross the level's left / right edge, or level 0 is not 4-byte aligned): byte
-  // gathers with REFLECT_101
-  auto fixEdges = [&](const Win& q, uint32_t* rawDst) {
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const int xs = q.ax + gX[i];
-      if (gRow[i] >= 0 && !(q.aligned && xs >= 0 && xs + 16 <= q.w)) {
-        const uint8_t* row = q.img + (long long)rowOf(q, gRow[i]) * q.stride;
-        uint32_t word[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int b = 0; b < 16; b++) {
-          int xx = xs + b;
-          xx = xx < 0 ? -xx : xx; xx = xx >= q.w ? 2 * q.w - 2 - xx : xx; xx = min(max(xx, 0), q.w - 1);
-          word[b >> 2] |= (uint32_t)row[xx] << (8 * (b & 3));
-        }
-        *reinterpret_cast<uint4*>(rawDst + 4 * (64 * i + lane)) = make_uint4(word[0], word[1], word[2], word[3]);
-      }
-    }
-  };
-  auto store = [&](int j, const uint2 r, float angle, const unsigned long long (&words)[4]) {
-    const long long o = (long long)f * capacity + (i0 + j);
-    if (lane < 4) reinterpret_cast<unsigned long long*>(desc + o * 32)[lane] = words[lane];
-    if (lane == 0) {
-      const int level = (int)(r.y & 0xffu), kx = (int)(r.x & 0xffffu), ky = (int)(r.x >> 16);
-      const LevelGeom& L = g.L[level];
-      orbx_keypoint kp;
-      kp.x = level ? (float)kx * L.scale : (float)kx;  // cpp:1631-1634 (scale[0] == 1 exactly)
-      kp.y = level ? (float)ky * L.scale : (float)ky;
-      kp.size = (float)L.patchSize;
-      kp.angle = angle;
-      kp.response = (float)((r.y >> 8) & 0xffu);
-      kp.octave = level;
-      kp.class_id = -1;
-      kps[o] = kp;
-    }
-  };
-
-#ifdef ORBX_DESC_STAMPS
-  const unsigned dsWave_ = (unsigned)((blockIdx.y * gridDim.x + blockIdx.x) * DL_WAVES + wave);
-#define DL_STAMP(k) do { if (j == 1) DS_STAMP(k); } while (0)
-  { const int j = 1; DL_STAMP(6); }
-#else
-#define DL_STAMP(k) do { } while (0)
-#endif
-  uint2 recCur = recAt(0), recNext = recAt(1);
-  stage(winOf(recCur), rawAll[wave][0]);
-  uint2 recPrev = recCur;
-  float anglePrev = 0.f;
-  unsigned long long wordsPrev[4] = {0ull, 0ull, 0ull, 0ull};
-#pragma unroll 1
-  for (int j = 0; j < cnt; j++) {
-    uint32_t* const raw = rawAll[wave][j & 1];
-    const Win q = winOf(recCur);
-    DL_STAMP(0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): window j has landed (and the stores of keypoint j - 2 are done)
-    DL_STAMP(1);
-    fixEdges(q, raw);
-    if (lane == 0) { msum[0] = 0; msum[1] = 0; }
-    if (j > 0) store(j - 1, recPrev, anglePrev, wordsPrev);       // older than the DMA below: the next vmcnt(0) does not wait for it
-    if (j + 1 < cnt) stage(winOf(recNext), rawAll[wave][(j + 1) & 1]);
-    const uint2 recNN = recAt(j + 2);                              // scalar load, used two iterations later
-    DL_STAMP(2);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    unsigned long long words[4];
-    const float angle = descCompute<GV, DL_RS>(raw, hz2, msum, (q.kx - 21) - q.ax, lane, w1a, w1b, wua, wub, pat, hitem, words);
-    DL_STAMP(3);
-    recPrev = recCur; anglePrev = angle;
-#pragma unroll
-    for (int wq = 0; wq < 4; wq++) wordsPrev[wq] = words[wq];
-    recCur = recNext; recNext = recNN;
-  }
-  store(cnt - 1, recPrev, anglePrev, wordsPrev);
-  { const int j = 1; DL_STAMP(5); (void)j; }
 }
 
 // =================================================================================================
@@ -2671,20 +2479,6 @@ hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const 
                                  int img0Aligned, const uint8_t* pyr, const Geom& g, const SelKp* sel, const int* nsel,
                                  orbx_keypoint* kps, uint8_t* desc, int capacity, int gaussVariant) {
   if (maxSel <= 0) return hipSuccess;
-  // k_describe_loop (LDS-DMA prefetch of the next keypoint's window) is opt-in: measured SLOWER than k_describe_patch, 417 us
-  // against 340 us per 256 frames alone on the chip and 285 k against 306 k frames/s on the lanes (docs/history.md, round 3)
-  static const bool loopKernel = getenv("ORBX_DESC_LOOP") != nullptr;
-  if (loopKernel && (long long)nFrames * maxSel >= 64 * 1024) {
-    const int perWg = DL_WAVES * DL_KPW;
-    dim3 block(64 * DL_WAVES, 1, 1), grid(((maxSel + perWg - 1) / perWg + 7) / 8 * 8, nFrames, 1);  // x: multiple of 8
-    if (gaussVariant)
-      hipLaunchKernelGGL(k_describe_loop<1>, grid, block, 0, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps, desc,
-                         capacity);
-    else
-      hipLaunchKernelGGL(k_describe_loop<0>, grid, block, 0, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps, desc,
-                         capacity);
-    return hipGetLastError();
-  }
   dim3 block(64 * DESC_WAVES, 1, 1), grid(((maxSel + DESC_WAVES - 1) / DESC_WAVES + 7) / 8 * 8, nFrames, 1);  // x: multiple of 8
   if (gaussVariant)
     hipLaunchKernelGGL(k_describe_patch<1>, grid, block, 0, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps, desc,

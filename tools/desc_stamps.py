@@ -23,19 +23,10 @@ for it in range(3):
     e.extract_batch_device(frames, B, W, H, W, W * H, k, d, n, cap)
 torch.cuda.synchronize()
 L.orbx_diag_desc_stamps(ctypes.c_void_p(buf.ctypes.data), nw)
-if os.environ.get("ORBX_DESC_LOOP"):  # k_describe_loop: stamps of the wave's second keypoint (steady state of the prefetch loop)
-    ok = (buf[:, 5] != 0) & (buf[:, 3] != 0)
-    t = buf[ok].astype(np.int64)
-    d = lambda a, b: (t[:, a] - t[:, b]) & 0xffffffff
-    print("waves %d (4 keypoints each); wave lifetime mean %.0f cycles" % (ok.sum(), d(5, 6).mean()))
-    for nm, v in (("prologue (tables, first window issue, keypoint 0)", d(0, 6)), ("wait for the window (vmcnt)", d(1, 0)),
-                  ("edge fix-up + stores + DMA issue of the next window", d(2, 1)), ("compute (IC, blur, BRIEF)", d(3, 2))):
-        print("  %-52s mean %8.0f median %8.0f cycles" % (nm, v.mean(), np.median(v)))
-    sys.exit(0)
 ok = buf[:, 5] != 0
-t = buf[ok, :6].astype(np.int64)
+t = buf[ok][:, [0, 1, 5]].astype(np.int64)
 dt = (t[:, 1:] - t[:, :-1]) & 0xffffffff
-names = ["window fetch (loads landed)", "IC_Angle + fastAtan2", "horizontal blur", "vertical blur", "BRIEF + output"]
+names = ["window fetch (loads landed)", "IC_Angle .. BRIEF + output (descCompute carries no stamps)"]
 tot = dt.sum(1)
 print("waves %d, cycles per wave: mean %.0f median %.0f" % (ok.sum(), tot.mean(), np.median(tot)))
 for i, nm in enumerate(names):
