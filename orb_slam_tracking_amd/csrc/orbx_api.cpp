@@ -1050,8 +1050,12 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
   ctx->late[ctx->parity].valid = false;
   if (nPairs > 0) armMatch(ctx, *match, dKps, dDesc, dN, capacity);
 
-  static const int splitMin = getenv("ORBX_NO_SPLIT") ? (1 << 30) : 16;
-  const bool split = ctx->st2 != nullptr && B >= splitMin && !ctx->noSplit;
+  // two half batches from 16 frames on -- or from 4 when the frames are large (4 x 4K): the selection of such frames is a handful
+  // of long latency-bound units (one 1024-thread workgroup per frame and level) under which the other half's pyramid, FAST and
+  // descriptors find the chip almost empty (8 frames 4K / 8000 features: 6.0 k -> 8 k frames/s)
+  static const bool noSplitEnv = getenv("ORBX_NO_SPLIT") != nullptr;
+  const bool enoughToSplit = B >= 16 || (B >= 4 && (long long)B * w * h >= (32ll << 20));
+  const bool split = ctx->st2 != nullptr && enoughToSplit && !noSplitEnv && !ctx->noSplit;
   const int n0 = split ? ((B / 2) & ~1) : B;
   // pairs whose frames both lie in one half can run right behind that half's extraction, on its stream; this needs
   // the pair list to be ordered [half 0][half 1][rest] (true for consecutive pairs (2k, 2k+1))

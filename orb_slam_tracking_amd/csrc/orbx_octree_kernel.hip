@@ -60,10 +60,12 @@ typedef unsigned long long u64;
 
 // sizes shared by both instances of the device code
 #define OCT_SORT_LDS 2048
+#define OCT_GLOBAL_XCHG 4096  // keys of k_octree_global's exchange buffer (32 KB: one such workgroup per CU anyway)
 #define SLESS(a, b) (((a) >> 20) < ((b) >> 20))
 #define OCT_PAR_MAX 512
-#define OCT_PAR_RANGES 64
-#define OCT_PAR_SCR_FOR(capN) (4 * (((capN) + 8) / 2) + 2 * OCT_PAR_RANGES + 2 * OCT_PAR_RANGES + OCT_PAR_RANGES + 4)
+#define OCT_PAR_BIG 2048  // k_octree_global: two positions per thread of its 1024
+#define OCT_PAR_RANGES_FOR(capN) ((capN) / 16 < 64 ? 64 : (capN) / 16)  // ranges of more than 16 keys alive at a time: < capN / 16
+#define OCT_PAR_SCR_FOR(capN) (4 * (((capN) + 8) / 2) + 5 * OCT_PAR_RANGES_FOR(capN) + 4)
 #define OCT_PAR_SCR OCT_PAR_SCR_FOR(OCT_PAR_MAX)
 
 #define OCT_T 256
@@ -129,7 +131,9 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   if (threadIdx.x == 0 && maxN) atomicMax(&maxN[level], n);  // feedback for the next batch's choice of instance
   if (n <= NMAX && P.lev[level].quota <= QMAX) {
     OctScratchT<uint16_t> S{keys, nodes, div, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, childCnt, candL, segBase, nullptr, 0,
-                            hiPar /* hiOf's space: dead during the partial pass */, PARCAP};
+                            hiPar /* hiOf's space: dead during the partial pass */, PARCAP, nullptr, nullptr,
+                            reinterpret_cast<uint32_t*>(nodes) /* step 6 only: nodes[] and what aliases it are dead by then */};
+    static_assert(MCAP * 8 >= NMAX * 4, "the sorted candidate copy of step 6 must fit into nodes[]");
     octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, MCAP, FCAP, QMAX);
     __syncthreads();
     if (threadIdx.x == 0) redo = (*nOut == -2);  // a node table overflowed the LDS layout
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
     return;
   }
   __syncthreads();
-  octreeGlobalUnit(cand, cellCount, P, selStage, nselLevel, scratch, level, f, keysNodes, NMAX + MCAP);
+  octreeGlobalUnit(cand, cellCount, P, selStage, nselLevel, scratch, level, f, keysNodes, NMAX + MCAP, nullptr, 0);
 }
 
 // global-scratch variant, 1024 threads, for the (frame, level) units the LDS variant left (nselLevel == -2), or for all
@@ -156,10 +160,14 @@ static_assert(OCT_SORT_LDS >= 1024, "the register sort of the 1024-thread instan
 __global__ __launch_bounds__(1024) void k_octree_global(const uint32_t* __restrict__ cand, const int* __restrict__ cellCount,
                                                        const OctLaunch P, SelKp* __restrict__ selStage,
                                                        int* __restrict__ nselLevel, uint8_t* __restrict__ scratch, int all, int level0) {
-  __shared__ u64 xchg[OCT_SORT_LDS];
+  // exchange buffer: 2048 keys for the register sorts, and 512 x 16 digit counters (9-bit digits) for the radix sort
+  __shared__ u64 xchg[OCT_GLOBAL_XCHG];
+  // scratch of the workgroup-parallel std::sort replay for up to 2048 pending nodes (the level-0 quota of 1080p / 4000 features is
+  // 869, of 4K / 8000 features 1737: the one-lane replay took 96 k cycles of such a unit)
+  __shared__ uint32_t parScr[OCT_PAR_SCR_FOR(OCT_PAR_BIG)];
   const int level = blockIdx.y + level0, f = blockIdx.x + P.frame0;  // level-major dispatch, see launch_octree
   if (!all && nselLevel[f * P.nlevels + level] != -2) return;
-  t1024::octreeGlobalUnit(cand, cellCount, P, selStage, nselLevel, scratch, level, f, xchg, OCT_SORT_LDS);
+  t1024::octreeGlobalUnit(cand, cellCount, P, selStage, nselLevel, scratch, level, f, xchg, OCT_GLOBAL_XCHG, parScr, OCT_PAR_BIG);
 }
 
 size_t octScratchBytes(int nMax, int qMax) {
