@@ -300,6 +300,25 @@ int orbx_multi_extract_match_batch_device(orbx_multi* m, int n_frames, const uin
                                           int check_orientation, int32_t* const* d_matches12, int32_t* const* d_nmatches,
                                           int32_t* counts_all);
 
+/* The throughput form (what bench.py does with one process per GPU, for a C / C++ host): one issuing host thread per device, the
+ * blocks of a batch issued stream-ordered on every device's context, several batches in flight.
+ *   orbx_multi_set_pipeline_depth: orbx_set_pipeline_depth(depth) on every device's context (whole blocks on `depth` lanes;
+ *     0 = two half blocks on two streams); at most max(depth, 2) batches are in flight;
+ *   orbx_multi_extract_match_batch_device_async: returns once every device has queued its block; a call that would exceed the
+ *     batches in flight first completes the oldest one (whose error, if any, it returns);
+ *   orbx_multi_wait_one: completes the oldest batch -- waits for its blocks, all-gathers its counts on the collective streams
+ *     (RCCL; the devices meanwhile run the batches issued after it) and fills ITS counts_all; orbx_multi_wait: all of them.
+ * Batches in flight together need different output arrays (and counts_all arrays); the contexts returned by orbx_multi_ctx must
+ * not be used directly while batches are in flight.  orbx_multi_extract_match_batch_device == the async call + orbx_multi_wait. */
+int orbx_multi_set_pipeline_depth(orbx_multi* m, int depth);
+int orbx_multi_extract_match_batch_device_async(orbx_multi* m, int n_frames, const uint8_t* const* d_imgs, int width, int height,
+                                                int stride, size_t frame_stride_bytes, orbx_keypoint* const* d_kps,
+                                                uint8_t* const* d_desc32, int capacity, int32_t* const* d_n_out,
+                                                const orbx_bounds* bounds, int window_size, float nnratio, int check_orientation,
+                                                int32_t* const* d_matches12, int32_t* const* d_nmatches, int32_t* counts_all);
+int orbx_multi_wait_one(orbx_multi* m);
+int orbx_multi_wait(orbx_multi* m);
+
 /* ---- test hooks (used by tests/ only; stable but not part of the reference surface) -------- */
 /* candidates of (frame, level) of the last extract call, as produced by the FAST kernel, sorted
  * into the reference's order (cell row, cell col, y, x): xyr = (x, y, response) triples relative to

@@ -121,6 +121,10 @@ def lib() -> ctypes.CDLL:
     L.orbx_multi_shard_range.argtypes = [i32, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.orbx_multi_extract_match_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, sz, vp, vp, i32, vp, ctypes.POINTER(_Bounds), i32,
                                                         f32, i32, vp, vp, vp]
+    L.orbx_multi_extract_match_batch_device_async.argtypes = L.orbx_multi_extract_match_batch_device.argtypes
+    L.orbx_multi_set_pipeline_depth.argtypes = [vp, i32]
+    L.orbx_multi_wait_one.argtypes = [vp]
+    L.orbx_multi_wait.argtypes = [vp]
     L.orbx_profile_enable.argtypes = [vp, i32]
     L.orbx_profile_reset.argtypes = [vp]
     L.orbx_profile_get.argtypes = [vp, vp, vp]

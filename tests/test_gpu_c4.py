@@ -212,6 +212,100 @@ def test_multi_c_abi_one_device(orbx, c4_oracle):
     assert L.orbx_multi_create(ctypes.byref(p), 2, (ctypes.c_int * 2)(0, 0), W, H, 32, ctypes.byref(h)) == orbx.E_BADARG
 
 
+def _multi_async_run(orbx, devices, c4_oracle, depth, nbatch=5, n_frames=64):
+    """orbx_multi_*_async: `nbatch` batches of `n_frames` frames (batch j = frames [j * n_frames, (j + 1) * n_frames) of config 4),
+    as many in flight as the lanes take, every batch's blocks, pairs and gathered counts against the oracle."""
+    import ctypes
+    import torch
+    from orb_slam_tracking_amd import synth
+    ext, pairs = c4_oracle
+    L = orbx.lib()
+    p = orbx._Params(*PARAMS)
+    h = ctypes.c_void_p(0)
+    nd = len(devices)
+    devs = (ctypes.c_int * nd)(*devices)
+    per = -(-(-(-n_frames // 2) // nd)) * 2
+    assert L.orbx_multi_create(ctypes.byref(p), nd, devs, W, H, per, ctypes.byref(h)) == 0
+    try:
+        assert L.orbx_multi_set_pipeline_depth(h, depth) == 0
+        nfl = max(depth, 2)  # batches in flight -> output sets
+        vp = ctypes.c_void_p
+        blocks = []
+        for i in range(nd):
+            lo, hi = ctypes.c_int(0), ctypes.c_int(0)
+            L.orbx_multi_shard_range(n_frames, nd, i, ctypes.byref(lo), ctypes.byref(hi))
+            blocks.append((lo.value, hi.value))
+        imgs = []  # [batch][device]
+        for j in range(nbatch):
+            imgs.append([torch.from_numpy(np.stack([synth.synth(W, H, 1000 + j * n_frames + g) for g in range(lo, hi)])).to(torch.device("cuda", dv))
+                         for dv, (lo, hi) in zip(devices, blocks)])
+        sets = []
+        for _ in range(nfl):
+            a = {k: [] for k in "kdnmq"}
+            for dv, (lo, hi) in zip(devices, blocks):
+                nb, dev = hi - lo, torch.device("cuda", dv)
+                a["k"].append(torch.zeros(nb * CAP * 28, dtype=torch.uint8, device=dev))
+                a["d"].append(torch.zeros(nb * CAP * 32, dtype=torch.uint8, device=dev))
+                a["n"].append(torch.zeros(nb, dtype=torch.int32, device=dev))
+                a["m"].append(torch.zeros(max(nb // 2, 1) * CAP, dtype=torch.int32, device=dev))
+                a["q"].append(torch.zeros(max(nb // 2, 1), dtype=torch.int32, device=dev))
+            a["counts"] = np.full(n_frames, -7, np.int32)
+            a["ptrs"] = {k: (vp * nd)(*[t.data_ptr() for t in a[k]]) for k in "kdnmq"}
+            sets.append(a)
+        torch.cuda.synchronize()
+        b = orbx._Bounds(0, W, 0, H)
+
+        def check(j, a):
+            g0 = j * n_frames
+            assert np.array_equal(a["counts"], np.array([len(ext[g0 + g][1]) for g in range(n_frames)], np.int32)), j
+            for i, (lo, hi) in enumerate(blocks):
+                nb = hi - lo
+                n = a["n"][i].cpu().numpy()
+                kk = a["k"][i].cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(nb, CAP)
+                dd = a["d"][i].cpu().numpy().reshape(nb, CAP, 32)
+                mm = a["m"][i].cpu().numpy().reshape(-1, CAP)
+                nm = a["q"][i].cpu().numpy()
+                for f in range(nb):
+                    _, ko, do = ext[g0 + lo + f]
+                    assert n[f] == len(ko) and kk[f, :n[f]].tobytes() == ko.tobytes() and np.array_equal(dd[f, :n[f]], do), (j, i, f)
+                for pp in range(nb // 2):
+                    onm, om12, _ = pairs[(g0 + lo) // 2 + pp]
+                    assert nm[pp] == onm and np.array_equal(mm[pp, :len(om12)], om12), (j, i, pp)
+        for j in range(nbatch):
+            a = sets[j % nfl]
+            if j >= nfl:  # the set is about to be reused: its batch is the oldest in flight
+                assert L.orbx_multi_wait_one(h) == 0, L.orbx_multi_last_error(h)
+                check(j - nfl, a)
+                a["counts"][:] = -7
+            ip = (vp * nd)(*[t.data_ptr() for t in imgs[j]])
+            r = L.orbx_multi_extract_match_batch_device_async(h, n_frames, ip, W, H, W, W * H, a["ptrs"]["k"], a["ptrs"]["d"], CAP, a["ptrs"]["n"],
+                                                              ctypes.byref(b), 100, 0.9, 1, a["ptrs"]["m"], a["ptrs"]["q"], a["counts"].ctypes.data)
+            assert r == 0, (r, L.orbx_multi_last_error(h))
+        assert L.orbx_multi_wait(h) == 0, L.orbx_multi_last_error(h)
+        for j in range(max(nbatch - nfl, 0), nbatch):
+            check(j, sets[j % nfl])
+    finally:
+        L.orbx_multi_destroy(h)
+
+
+@pytest.mark.parametrize("depth", [0, 3])
+def test_multi_c_abi_async_one_device(orbx, c4_oracle, depth):
+    """The throughput form of the C ABI's multi-device host (issuing thread per device, batches in flight, counts of batch k gathered
+    while batch k + 1 runs) on one device: every batch equals the oracle, in the two-half-batches mode and on three lanes."""
+    import torch
+    torch.cuda.init()
+    _multi_async_run(orbx, [0], c4_oracle, depth, nbatch=4, n_frames=64)
+
+
+def test_multi_c_abi_async_rccl(orbx, c4_oracle):
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("RCCL needs more than one GPU: this box has %d" % n)
+    world = 8 if n >= 8 else 4 if n >= 4 else 2
+    _multi_async_run(orbx, list(range(world)), c4_oracle, 3, nbatch=4, n_frames=64)
+
+
 def test_multi_c_abi_rccl(orbx, c4_oracle):
     """More than one GPU: ncclCommInitAll + ncclAllGather of the counts inside liborbx.so (librccl.so through dlopen)."""
     import torch
