@@ -793,13 +793,17 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
         const int nv = live ? min(iw - 4 * qc, 4) : 0;
         const uint32_t bits = (((fl[0] >> 15) & 1u) | ((fl[0] >> 30) & 2u) | ((fl[1] >> 13) & 4u) | ((fl[1] >> 28) & 8u)) & ((1u << nv) - 1u);
         const int offP = offA + sh;  // tile offset of the quad's first pixel
+        if (__ballot(bits != 0u) != 0ull) {  // (wave-uniform) a step without any survivor appends nothing
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const bool cj = (bits >> j) & 1u;
           const unsigned long long m = __ballot(cj);
-          ring[cj ? ((head + nList + fwMbcnt(m)) & (FW_RING - 1)) : FW_RING + lane] = (uint16_t)(offP + j);
-          nList += (int)__popcll(m);
-          if (nList >= 64) flush(64);
+          if (m != 0ull) {  // (wave-uniform) most steps of a flat region have no survivor at all: nothing to append
+            ring[cj ? ((head + nList + fwMbcnt(m)) & (FW_RING - 1)) : FW_RING + lane] = (uint16_t)(offP + j);
+            nList += (int)__popcll(m);
+            if (nList >= 64) flush(64);
+          }
+        }
         }
         qc += dqc;
         offA += dOffA;
