@@ -684,21 +684,25 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
   // ---- stage the cell image: lane = (row mod 4, dword), eight loads per lane in flight.  Rows and dwords beyond the cell
   //      are clamped to its last ones (in-bounds duplicates), so nothing is predicated ----
   {
-    const int rsub = lane >> 4, wcol = min(lane & 15, TS / 4 - 1);
+    // a load instruction covers RP whole tile rows: 5 rows of 12 dwords (60 lanes; the last four duplicate) or 4 rows of 16, and
+    // NB of them are in flight: 45 or 32 rows -- the cells of every frame size from VGA up (44 rows) in ONE batch
+    constexpr int DW = TS / 4, RP = 64 / DW, NB = TS == 48 ? 9 : 8;
+    const int lrow = TS == 48 ? (int)(((uint32_t)lane * 5462u) >> 16) : lane >> 4;  // lane / DW
+    const int rsub = min(lrow, RP - 1), wcol = lrow < RP ? lane - lrow * DW : DW - 1;
     const unsigned wsrc = 4u * (unsigned)min(wcol, nw - 1);
     const int stride = (int)c.stride;
     uint32_t* const tile32 = reinterpret_cast<uint32_t*>(tile);
-    for (int r0 = 0; r0 < ch; r0 += 32) {
-      uint32_t v[8];
+    for (int r0 = 0; r0 < ch; r0 += RP * NB) {
+      uint32_t v[NB];
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int r = min(r0 + 4 * j + rsub, ch - 1);
+      for (int j = 0; j < NB; j++) {
+        const int r = min(r0 + RP * j + rsub, ch - 1);
         v[j] = *reinterpret_cast<const uint32_t*>(base + ((unsigned)(r * stride) + wsrc));
       }
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int r = min(r0 + 4 * j + rsub, ch - 1);
-        tile32[r * (TS / 4) + wcol] = v[j];
+      for (int j = 0; j < NB; j++) {
+        const int r = min(r0 + RP * j + rsub, ch - 1);
+        tile32[r * DW + wcol] = v[j];
       }
     }
   }
