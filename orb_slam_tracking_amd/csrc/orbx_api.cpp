@@ -491,6 +491,11 @@ size_t buildOctLaunch(const orbx_ctx* c, const Geom& g, OctLaunch* out) {
     O.height = L.maxBY - ORBX_MIN_BORDER;
     O.nIni = (int)std::round((float)O.width / (float)O.height);  // cpp:706
     O.hX = (float)O.width / (float)O.nIni;                       // cpp:709
+    {  // a root is at most ceil(hX) + 1 wide; DivideNode gives the left / upper child ceil(extent / 2) (cpp:620-621)
+      int e = std::max((int)std::ceil(O.hX) + 1, O.height), d = 0;
+      while (e > 1) { e = (e + 1) >> 1; d++; }
+      O.depthBits = std::max(d, 1);
+    }
     O.wCell = L.wCell;
     O.hCell = L.hCell;
     O.nCols = L.nCols;
@@ -2010,7 +2015,8 @@ extern "C" {
 // DistributeOctTree on the device for caller-supplied candidates given in row-major (y, x) order, integer coordinates
 // relative to (min_x, min_y) in [0, 4095], integer responses in [0, 255].  variant 0 = LDS kernel (falls through to
 // the global-scratch kernel when it cannot take the unit), 1 = global-scratch kernel only, 2 / 3 = the 1024- / 512-candidate
-// LDS instances (a unit that does not fit is redone by the same workgroup on global scratch).
+// LDS instances (a unit that does not fit is redone by the same workgroup on global scratch), 4 = the 2048-candidate LDS instance
+// with 64-bit sort keys (the others take 32-bit keys whenever the rectangle's path codes fit 21 bits).
 int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min_x, int max_x, int min_y, int max_y,
                                  int n_features, int variant, float* out_xyr, int cap) {
   if (!ctx || n < 0 || (n > 0 && !xyr) || max_x <= min_x || max_y <= min_y || n_features < 0 || n > ORBX_OCT_MAX_CAND)
@@ -2025,6 +2031,11 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
   O.nIni = (int)std::round((float)O.width / (float)O.height);
   if (O.nIni < 1 || O.nIni > 255) return ORBX_E_TOOSMALL;
   O.hX = (float)O.width / (float)O.nIni;
+  {
+    int e = std::max((int)std::ceil(O.hX) + 1, O.height), d = 0;
+    while (e > 1) { e = (e + 1) >> 1; d++; }
+    O.depthBits = std::max(d, 1);
+  }
   O.wCell = O.hCell = 1 << 20;  // one "cell": candidate order = row-major
   O.nCols = 1;
   O.quota = n_features;
@@ -2054,7 +2065,7 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
     int hi[2] = {n, -7};
     HIPCHK(hipMemcpyAsync(dI, hi, sizeof hi, hipMemcpyHostToDevice, ctx->st));
     HIPCHK(launch_octree(ctx->st, 1, dC, dI, P, dS, dI + 1, dScr, nullptr, nullptr,
-                         variant == 1 ? -1 : variant == 2 ? 1024 : variant == 3 ? 512 : 0, nullptr));
+                         variant == 1 ? -1 : variant == 2 ? 1024 : variant == 3 ? 512 : variant == 4 ? (2048 | 0x10000) : 0, nullptr));
     HIPCHK(hipMemcpyAsync(res, dI, sizeof res, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(sel.data(), dS, sel.size() * sizeof(SelKp), hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));

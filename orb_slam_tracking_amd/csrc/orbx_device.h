@@ -80,7 +80,8 @@ struct OctLevel {
   int32_t wCell, hCell, nCols;  // FAST cell grid: defines the reference's candidate order
   int32_t quota;
   int32_t cellBase, nCells, segCap;  // the level's cells in the per-frame cell-count array; entries per cell segment
-  int32_t pad_;
+  int32_t depthBits;       // splits after which every cell of the level is one pixel (DivideNode halves with ceil): the quadrant
+                           // digits of a path code beyond this depth are all 0
 };
 
 struct OctLaunch {

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "../../include/orbx.h"
 #include "orbx_device.h"
@@ -83,8 +84,9 @@ using namespace t256;
 
 // ---- kernels ---------------------------------------------------------------------------------------------------------
 
-// LDS-resident variant: n <= NMAX candidates, quota <= QMAX
-template <int NMAX, int QMAX>
+// LDS-resident variant: n <= NMAX candidates, quota <= QMAX; K32: 32-bit sort keys (OctScratchT), for levels whose path codes
+// need at most 21 bits
+template <int NMAX, int QMAX, bool K32>
 __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict__ cand, const int* __restrict__ cellCount,
                                                      const OctLaunch P, SelKp* __restrict__ selStage,
                                                      int* __restrict__ nselLevel, uint8_t* __restrict__ scratch,
@@ -99,9 +101,12 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   //   nodes[] is dead once the node records exist, so the partial pass's buffers (sized, pending, childCnt) live in it, and
   //   it is not yet written while step 1 reads the candidate position list, which therefore lives there too;
   //   hiOf[] (steps 3-4) shares its space with the parallel std::sort replay's scratch (partial pass).
-  __shared__ u64 keysNodes[NMAX + MCAP];
-  u64* keys = keysNodes;
-  u64* nodes = keysNodes + NMAX;
+  using KEY = typename std::conditional<K32, uint32_t, u64>::type;
+  // LDS budget with 32-bit keys: NMAX 2048: 8 + 8 + 4 + 6 + 2 + 3 KB = 31.5 KB -> FIVE workgroups per CU
+  constexpr int KEYW = K32 ? (NMAX / 2 < 1024 - MCAP ? 1024 - MCAP : NMAX / 2) : NMAX;  // u64 words of the key array
+  __shared__ u64 keysNodes[KEYW + MCAP];
+  KEY* keys = reinterpret_cast<KEY*>(keysNodes);
+  u64* nodes = keysNodes + KEYW;
   static_assert(MCAP * 8 >= NMAX * 4, "the candidate position list must fit into nodes[]");
   uint32_t* candL = reinterpret_cast<uint32_t*>(nodes);
   // the sort replay never sees more than QMAX entries here (the partial pass's list is shorter than the quota): 256 keys
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   static_assert(NMAX <= 65535, "16-bit sorted positions");
   __shared__ uint16_t nodeLo[MCAP + FCAP], nodeHi[MCAP + FCAP];
   __shared__ uint8_t div[NMAX + 4];
-  __shared__ uint8_t nodeDepth[MCAP + FCAP], nodeAlive[MCAP + FCAP];
+  __shared__ uint8_t nodeDepth[MCAP + FCAP];
   static_assert(2 * QMAX * 8 + 2 * QMAX * 4 + QMAX * 4 <= MCAP * 8, "partial-pass buffers must fit in nodes[]");
   u64* sized = nodes;                                             // [2 * QMAX]
   int* pending = reinterpret_cast<int*>(nodes + 2 * QMAX);        // [2 * QMAX]
@@ -122,17 +127,25 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   int* nOut = &nselLevel[f * P.nlevels + level];
   // keys[] + nodes[] double as the sort exchange buffer of the global-scratch path: a workgroup's worth of padded keys, the radix
   // sort's 256 x 4 digit counters (4 KB) and the parallel std::sort replay's scratch must fit
-  static_assert(NMAX + MCAP >= 1024 && (NMAX + MCAP) * 2 >= OCT_PAR_SCR_FOR(OCT_PAR_MAX), "exchange buffer of the global-scratch path");
+  static_assert(KEYW + MCAP >= 1024 && (KEYW + MCAP) * 2 >= OCT_PAR_SCR_FOR(OCT_PAR_MAX), "exchange buffer of the global-scratch path");
+  static_assert(NMAX <= 2048, "11-bit candidate index of the 32-bit keys");
   __shared__ int redo;
   __shared__ int gws[OCT_T / 64];
   const uint32_t* segBase = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
   const int* cellCnt = cellCount + (int64_t)f * P.nCellsTotal + P.lev[level].cellBase;
   const int n = gatherCandidates(cellCnt, P.lev[level].nCells, P.lev[level].segCap, candL, NMAX, threadIdx.x, gws);
   if (threadIdx.x == 0 && maxN) atomicMax(&maxN[level], n);  // feedback for the next batch's choice of instance
-  if (n <= NMAX && P.lev[level].quota <= QMAX) {
-    OctScratchT<uint16_t> S{keys, nodes, div, hiOf, nodeLo, nodeHi, nodeDepth, nodeAlive, sized, pending, childCnt, candL, segBase, nullptr, 0,
-                            hiPar /* hiOf's space: dead during the partial pass */, PARCAP, nullptr, nullptr,
-                            reinterpret_cast<uint32_t*>(nodes) /* step 6 only: nodes[] and what aliases it are dead by then */};
+  // 32-bit keys: the level's path codes must fit 21 bits (the host picks this instance only then; checked again here)
+  const int depthBits = P.lev[level].depthBits;
+  const int rootBits = P.lev[level].nIni > 1 ? 32 - __builtin_clz((unsigned)(P.lev[level].nIni - 1)) : 0;
+  const bool keysFit = !K32 || (depthBits >= 1 && depthBits <= OCT_DEPTH && rootBits + 2 * depthBits <= 21);
+  if (n <= NMAX && P.lev[level].quota <= QMAX && keysFit) {
+    // the candidate words of the unit, in candidate-list order: head of the unit's global scratch area (octScratchBytes >= 8 KB)
+    uint32_t* candE = reinterpret_cast<uint32_t*>(scratch + P.scrOff[level] + (int64_t)f * P.scrStride[level]);
+    OctScratchT<uint16_t, KEY> S{keys, 2 * (OCT_DEPTH - depthBits), nodes, div, hiOf, nodeLo, nodeHi, nodeDepth, sized, pending,
+                                 childCnt, candL, segBase, nullptr, 0, hiPar /* hiOf's space: dead during the partial pass */, PARCAP,
+                                 nullptr, candE,
+                                 reinterpret_cast<uint32_t*>(nodes) /* step 6 only: nodes[] and what aliases it are dead by then */};
     static_assert(MCAP * 8 >= NMAX * 4, "the sorted candidate copy of step 6 must fit into nodes[]");
     octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, MCAP, FCAP, QMAX);
     __syncthreads();
@@ -148,7 +161,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
     return;
   }
   __syncthreads();
-  octreeGlobalUnit(cand, cellCount, P, selStage, nselLevel, scratch, level, f, keysNodes, NMAX + MCAP, nullptr, 0);
+  octreeGlobalUnit(cand, cellCount, P, selStage, nselLevel, scratch, level, f, keysNodes, KEYW + MCAP, nullptr, 0);
 }
 
 // global-scratch variant, 1024 threads, for the (frame, level) units the LDS variant left (nselLevel == -2), or for all
@@ -244,6 +257,9 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
   // force: 0 = choose per level from hintL (nullptr = unknown); 2048 / 1024 / 512 = that LDS instance for every level (test
   // hook, diagnostics); -1 = every unit on global scratch (test hook).
   static const bool noSmall = getenv("ORBX_OCT_NO_SMALL") != nullptr;  // diagnostics: always the 2048-candidate instance
+  static const bool key64Env = getenv("ORBX_OCT_KEY64") != nullptr;    // diagnostics: always 64-bit sort keys
+  const bool key64 = key64Env || (force & 0x10000) != 0;               // (test hook: force | 0x10000)
+  force = force < 0 ? force : (force & 0xffff);
   // ORBX_OCT_SPLIT_MIN (diagnostics) = batch size from which every group of consecutive levels with the same instance gets its
   // own launch.  Off by default: measured on the bench workload (256 frames, four lanes) 2048 | 1024 x 2 | 512 x 5 gives 295.9 k
   // frames/s, 2048 x 3 | 512 x 5 300.2 k, 2048 | 1024 x 7 302.3 k against 306.6 k with ONE launch on the largest instance --
@@ -288,21 +304,30 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
     int l1 = l0 + 1;
     while (l1 < P.nlevels && inst[l1] == inst[l0]) l1++;
     const dim3 grid(nFrames, l1 - l0, 1), block(OCT_T, 1, 1);
+    // 32-bit sort keys when the path codes of every level of the launch fit 21 bits (frames up to ~1024 px per root and
+    // side: VGA, 752x480, 1080p; not 4K)
+    bool k32 = !key64;
+    for (int l = l0; l < l1; l++) {
+      const int rootBits = P.lev[l].nIni > 1 ? 32 - __builtin_clz((unsigned)(P.lev[l].nIni - 1)) : 0;
+      k32 = k32 && P.lev[l].depthBits >= 1 && rootBits + 2 * P.lev[l].depthBits <= 21;
+    }
+#define ORBX_OCT_LAUNCH(N_, Q_, DEFER_)                                                                                             \
+  do {                                                                                                                              \
+    if (k32)                                                                                                                        \
+      hipLaunchKernelGGL((k_octree_lds<N_, Q_, true>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN, DEFER_, l0);  \
+    else                                                                                                                            \
+      hipLaunchKernelGGL((k_octree_lds<N_, Q_, false>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN, DEFER_, l0); \
+  } while (0)
     switch (inst[l0]) {
-      case 512:
-        hipLaunchKernelGGL((k_octree_lds<512, 128>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN, 0, l0);
-        break;
-      case 1024:
-        hipLaunchKernelGGL((k_octree_lds<1024, 256>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN, 0, l0);
-        break;
-      case 2048:
-        hipLaunchKernelGGL((k_octree_lds<2048, 256>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN, 0, l0);
-        break;
+      case 512: ORBX_OCT_LAUNCH(512, 128, 0); break;
+      case 1024: ORBX_OCT_LAUNCH(1024, 256, 0); break;
+      case 2048: ORBX_OCT_LAUNCH(2048, 256, 0); break;
       default:  // the level expects large units: what fits the LDS layout is done there, the rest is deferred
-        hipLaunchKernelGGL((k_octree_lds<2048, 256>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN, 1, l0);
+        ORBX_OCT_LAUNCH(2048, 256, 1);
         hipLaunchKernelGGL(k_octree_global, grid, dim3(1024), 0, st, cand, cellCount, P, selStage, nselLevel, scratch, 0, l0);
         break;
     }
+#undef ORBX_OCT_LAUNCH
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     l0 = l1;

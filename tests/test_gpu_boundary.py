@@ -233,7 +233,7 @@ def test_regression_r01_fault_tiny_units_on_global_scratch(orbx, oracle):
         xyr = np.stack([pos % W, pos // W, rng.integers(1, 200, n)], 1).astype(np.float32)
         for N in (1, 10, 217, 300, 434):
             exp = oracle.distribute(xyr, 16, 16 + W, 16, 16 + H, N)[:N]
-            for variant in (1, 0, 2, 3):
+            for variant in (1, 0, 2, 3, 4):
                 got = e.debug_distribute_device(xyr, 16, 16 + W, 16, 16 + H, N, variant)
                 assert got.shape == exp.shape and np.array_equal(got, exp), (n, N, variant)
     e.close()

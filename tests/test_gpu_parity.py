@@ -385,7 +385,7 @@ def test_device_octree_random(orbx, ext640, oracle):
         xyr = _rowmajor_cands(rng, W, H, n)
         N = int(rng.integers(0, max(2, 2 * n // 3 + 2)))
         exp = oracle.distribute(xyr, 16, 16 + W, 16, 16 + H, N)[:N]  # the pipeline truncates to the quota (cpp:1159-1161)
-        for variant in (0, 1, 2, 3):
+        for variant in (0, 1, 2, 3, 4):
             got = ext640.debug_distribute_device(xyr, 16, 16 + W, 16, 16 + H, N, variant)
             assert got.shape == exp.shape and np.array_equal(got, exp), (it, variant, W, H, n, N)
         done += 1
@@ -404,7 +404,7 @@ def test_device_octree_small_quotas(orbx, ext640, oracle):
         xyr = _rowmajor_cands(rng, W, H, n)
         for N in (1, 2, 3, 5, 11, int(rng.integers(4, 40))):
             exp = oracle.distribute(xyr, 16, 16 + W, 16, 16 + H, N)[:N]
-            for variant in (0, 1, 2, 3):
+            for variant in (0, 1, 2, 3, 4):
                 got = ext640.debug_distribute_device(xyr, 16, 16 + W, 16, 16 + H, N, variant)
                 assert got.shape == exp.shape and np.array_equal(got, exp), (it, variant, W, H, n, N)
     from orb_slam_tracking_amd import synth
@@ -434,7 +434,7 @@ def test_device_octree_level_geometries(orbx, ext640, oracle, shape):
         _, uniq = np.unique(key, return_index=True)
         xyr = xyr[uniq]  # unique, and sorted row-major by construction of np.unique
         exp = oracle.distribute(xyr, 16, 16 + W, 16, 16 + H, N)[:N]
-        for variant in (0, 1, 2, 3):
+        for variant in (0, 1, 2, 3, 4):
             got = ext640.debug_distribute_device(xyr, 16, 16 + W, 16, 16 + H, N, variant)
             assert np.array_equal(got, exp), (dens, variant)
 
