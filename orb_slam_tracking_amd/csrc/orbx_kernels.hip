@@ -1063,146 +1063,6 @@ __host__ __device__ constexpr uint32_t descHTap(int t, int m) {
   }
   return k;
 }
-// The arithmetic of one keypoint on its staged raw window (IC_Angle, patch-local Gaussian, steered BRIEF).  (A separate function
-// since round 3's k_describe_loop experiment -- a wave walking four keypoints with the next window prefetched by LDS-DMA, slower:
-// docs/history.md -- shared it with k_describe_patch.)  raw: [43][RS] dwords (window column 0 at byte s of a row), overwritten with the blurred bytes; hz2: [22][40]
-// dwords; msum: two ints, zeroed by the caller.  Every wave works on its own LDS slice: LDS operations of one wave execute in
-// order, the fences only pin the compiler's order.  Returns the angle; words[] = the 256 descriptor bits (wave-uniform).
-template <int GV, int RS /* dwords per staged window row */>
-__device__ __forceinline__ float descCompute(uint32_t* raw, uint32_t* hz2, int* msum, const int s, const int lane, const uint4 w1a,
-                                             const uint4 w1b, const uint4 wua, const uint4 wub, const float4 (&pat)[4],
-                                             const uint32_t (&hitem)[3], unsigned long long (&words)[4]) {
-  uint32_t* bl32 = raw;  // [38][10] dwords = blurred bytes, row stride 40 (raw is dead by then)
-  // ---- IC_Angle (cpp:103-159) on the un-blurred window: pixel (u, v) is row 21+v, byte s+21+u.  Lane = disc row v;
-  //      the row's bytes u = -15..16 are 8 dwords, each weighted with v_dot4_u32_u8 (tables d_ic) ----
-  if (lane < 31) {
-    const int v = lane - 15;
-    const uint32_t w1[8] = {w1a.x, w1a.y, w1a.z, w1a.w, w1b.x, w1b.y, w1b.z, w1b.w};
-    const uint32_t wu[8] = {wua.x, wua.y, wua.z, wua.w, wub.x, wub.y, wub.z, wub.w};
-    const uint32_t* rowp = raw + (6 + lane) * RS + ((s + 6) >> 2);  // row 21 + v, first dword holding u = -15
-    const uint32_t sh = (uint32_t)(s + 6) & 3u;
-    uint32_t src[9];
-#pragma unroll
-    for (int j = 0; j < 9; j++) src[j] = rowp[j];
-    uint32_t sumI = 0, sumU = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const uint32_t B = __builtin_amdgcn_alignbyte(src[j + 1], src[j], sh);
-      sumI = __builtin_amdgcn_udot4(B, w1[j], sumI, false);
-      sumU = __builtin_amdgcn_udot4(B, wu[j], sumU, false);
-    }
-    atomicAdd(&msum[0], (int)sumU - 15 * (int)sumI);  // m10 = sum u*I
-    atomicAdd(&msum[1], v * (int)sumI);                // m01 = sum v*I
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  const int m10 = msum[0], m01 = msum[1];
-  const float angle = fast_atan2_deg((float)m01, (float)m10);
-  // ---- horizontal pass: blurred column c (x = kx-18+c) uses window bytes s+c .. s+c+6 of the staged row.
-  //      Item = (row pair, group of 4 columns): 4 dwords per row cover the 10 bytes the 4 columns need; the 190 items of
-  //      the sampling disc (d_descHItems) in 3 steps.
-  //      The byte shift s of the window inside its dwords is the same for the whole wave, so instead of shifting the data
-  //      (9 v_alignbyte per row) the TAPS are shifted: for each s the weights of the four dwords are compile-time
-  //      constants (descHTap), zero ones are skipped, and every s costs exactly 10 v_dot4_u32_u8 per row ----
-  {
-    auto hpass = [&](auto sTag) {
-      constexpr int SH = decltype(sTag)::value;
-#pragma unroll
-      for (int it = 0; it < 3; it++) {
-        const int rp = (int)(hitem[it] >> 4), gq = (int)(hitem[it] & 15u);
-        if (hitem[it] != 0xffffu) {
-          uint32_t hs[2][4];
-#pragma unroll
-          for (int h2 = 0; h2 < 2; h2++) {
-            const int row = h2 ? min(2 * rp + 1, PW_ROWS - 1) : 2 * rp;
-            const uint32_t* p = raw + row * RS + gq;  // (p[3] of the last column group feeds padding columns only)
-            const uint32_t dd[4] = {p[0], p[1], p[2], p[3]};
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-              uint32_t acc = 0;
-#pragma unroll
-              for (int m = 0; m < 4; m++)
-                if (descHTap<GV>(SH + c, m) != 0u) acc = __builtin_amdgcn_udot4(dd[m], descHTap<GV>(SH + c, m), acc, false);
-              hs[h2][c] = acc;
-            }
-          }
-          uint4 o4;
-          o4.x = hs[0][0] | (hs[1][0] << 16); o4.y = hs[0][1] | (hs[1][1] << 16);
-          o4.z = hs[0][2] | (hs[1][2] << 16); o4.w = hs[0][3] | (hs[1][3] << 16);
-          *reinterpret_cast<uint4*>(&hz2[rp * PW_COLS + 4 * gq]) = o4;
-        }
-      }
-    };
-    switch (s) {  // wave-uniform
-      case 0: hpass(std::integral_constant<int, 0>{}); break;
-      case 1: hpass(std::integral_constant<int, 1>{}); break;
-      case 2: hpass(std::integral_constant<int, 2>{}); break;
-      default: hpass(std::integral_constant<int, 3>{}); break;
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  // ---- vertical pass + rounding with v_dot2_u32_u16 on row pairs: blurred rows 2q and 2q+1 both use pairs q..q+3,
-  //      even row taps (18,34)(48,56)(48,34)(18,0), odd row taps (0,18)(34,48)(56,48)(34,18).  Item = (q, group of 4
-  //      columns), 190 items over 3 steps; the blurred bytes overwrite the raw window (no longer needed) ----
-  {
-    constexpr uint32_t T0 = 18u, T1 = 34u, T2 = GV ? 49u : 48u, T3 = GV ? 55u : 56u;
-    constexpr uint32_t E0 = T0 | (T1 << 16), E1 = T2 | (T3 << 16), E2 = T2 | (T1 << 16), E3 = T0;
-    constexpr uint32_t O0 = T0 << 16, O1 = T1 | (T2 << 16), O2 = T3 | (T2 << 16), O3 = T1 | (T0 << 16);
-    int q = lane / 10, gq = lane - q * 10;
-#pragma unroll
-    for (int it = 0; it < 3; it++) {
-      if (q < BL_ROWS_PAD / 2) {
-        const uint4 P0 = *reinterpret_cast<const uint4*>(&hz2[(q + 0) * PW_COLS + 4 * gq]);
-        const uint4 P1 = *reinterpret_cast<const uint4*>(&hz2[(q + 1) * PW_COLS + 4 * gq]);
-        const uint4 P2 = *reinterpret_cast<const uint4*>(&hz2[(q + 2) * PW_COLS + 4 * gq]);
-        const uint4 P3 = *reinterpret_cast<const uint4*>(&hz2[(q + 3) * PW_COLS + 4 * gq]);
-#define ORBX_VE(c) dot2u16(P0.c, E0, dot2u16(P1.c, E1, dot2u16(P2.c, E2, dot2u16(P3.c, E3, 32768u))))
-#define ORBX_VO(c) dot2u16(P0.c, O0, dot2u16(P1.c, O1, dot2u16(P2.c, O2, dot2u16(P3.c, O3, 32768u))))
-        uint32_t e0 = ORBX_VE(x), e1 = ORBX_VE(y), e2 = ORBX_VE(z), e3 = ORBX_VE(w);
-        uint32_t o0 = ORBX_VO(x), o1 = ORBX_VO(y), o2 = ORBX_VO(z), o3 = ORBX_VO(w);
-        if (GV) {  // taps that sum to 257: saturate_cast<uchar>
-          e0 = min(e0, 0xffffffu); e1 = min(e1, 0xffffffu); e2 = min(e2, 0xffffffu); e3 = min(e3, 0xffffffu);
-          o0 = min(o0, 0xffffffu); o1 = min(o1, 0xffffffu); o2 = min(o2, 0xffffffu); o3 = min(o3, 0xffffffu);
-        }
-#undef ORBX_VE
-#undef ORBX_VO
-        // each sum is < 2^24: its blurred byte is bits 16..23; v_perm_b32 gathers byte 2 of four sums into one dword
-        bl32[(2 * q) * (PW_COLS / 4) + gq] =
-            __builtin_amdgcn_perm(e1, e0, 0x0c0c0602u) | __builtin_amdgcn_perm(e3, e2, 0x06020c0cu);
-        bl32[(2 * q + 1) * (PW_COLS / 4) + gq] =
-            __builtin_amdgcn_perm(o1, o0, 0x0c0c0602u) | __builtin_amdgcn_perm(o3, o2, 0x06020c0cu);
-      }
-      q += 6; gq += 4;  // item + 64
-      if (gq >= 10) { gq -= 10; q++; }
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  // ---- steered BRIEF (cpp:169-228).  cos/sin of the f32 argument are evaluated in f64 and rounded to f32 ----
-  const uint8_t* bl = reinterpret_cast<const uint8_t*>(bl32);
-  const float factorPI = (float)(3.14159265358979323846 / 180.f);
-  double sd, cd;
-  sincosSmall((double)(angle * factorPI), &sd, &cd);
-  const float cs = (float)cd, sn = (float)sd;
-#pragma unroll
-  for (int wq = 0; wq < 4; wq++) {
-    const float4 pt = pat[wq];
-    const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
-    // cvRound of the rotated coordinates (cpp:184-188) and the byte address (18 + r) * 40 + 18 + c in one go: v + 1.5 * 2^23
-    // rounds to nearest-even at integer granularity and leaves 0x4B400000 + rint(v) in the float's bits; the low 24 bits
-    // (0x400000 + r) go through v_mad_u32_u24, the constants are taken off at the end
-    constexpr float MAGIC = 12582912.f;
-    constexpr uint32_t OFF = 40u * 0x400000u + 0x4B400000u - (18u * PW_COLS + 18u);
-    const uint32_t ir0 = __float_as_uint((x0 * sn + y0 * cs) + MAGIC), ic0 = __float_as_uint((x0 * cs - y0 * sn) + MAGIC);
-    const uint32_t ir1 = __float_as_uint((x1 * sn + y1 * cs) + MAGIC), ic1 = __float_as_uint((x1 * cs - y1 * sn) + MAGIC);
-    const int t0 = bl[(ir0 & 0xffffffu) * (uint32_t)PW_COLS + ic0 - OFF];
-    const int t1 = bl[(ir1 & 0xffffffu) * (uint32_t)PW_COLS + ic1 - OFF];
-    words[wq] = __ballot(t0 < t1);
-  }
-  return angle;
-}
-
 template <int GV>
 __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_t* __restrict__ img0, long long img0FrameStride,
                                                        int img0Aligned, const uint8_t* __restrict__ pyr, const Geom g,
@@ -1240,6 +1100,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   for (int it = 0; it < 3; it++) hitem[it] = d_descHItems.v[it * 64 + lane];
   uint32_t* raw = lds;                               // [43][13] dwords
   uint32_t* hz2 = raw + PW_RAW_WORDS;                // [22][40] row-pair packed horizontal sums (16-byte aligned rows)
+  uint32_t* bl32 = raw;                              // [38][10] dwords = blurred bytes, row stride 40 (raw is dead by then)
   int* msum = reinterpret_cast<int*>(hz2 + PW_PAIRS * PW_COLS);  // [2] moment sums of IC_Angle
   static_assert(BL_ROWS_PAD * (PW_COLS / 4) <= PW_ROWS * PW_WORDS, "blurred bytes must fit in the raw window");
   static_assert(PW_ROWS * PW_WORDS <= PW_RAW_WORDS && PW_RAW_WORDS % 4 == 0, "raw window padding");
@@ -1302,8 +1163,138 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   DS_STAMP(1);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
+  // ---- IC_Angle (cpp:103-159) on the un-blurred window: pixel (u, v) is row 21+v, byte s+21+u.  Lane = disc row v;
+  //      the row's bytes u = -15..16 are 8 dwords, each weighted with v_dot4_u32_u8 (tables d_ic) ----
+  if (lane < 31) {
+    const int v = lane - 15;
+    const uint32_t w1[8] = {w1a.x, w1a.y, w1a.z, w1a.w, w1b.x, w1b.y, w1b.z, w1b.w};
+    const uint32_t wu[8] = {wua.x, wua.y, wua.z, wua.w, wub.x, wub.y, wub.z, wub.w};
+    const uint32_t* rowp = raw + (6 + lane) * PW_WORDS + ((s + 6) >> 2);  // row 21 + v, first dword holding u = -15
+    const uint32_t sh = (uint32_t)(s + 6) & 3u;
+    uint32_t src[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) src[j] = rowp[j];
+    uint32_t sumI = 0, sumU = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t B = __builtin_amdgcn_alignbyte(src[j + 1], src[j], sh);
+      sumI = __builtin_amdgcn_udot4(B, w1[j], sumI, false);
+      sumU = __builtin_amdgcn_udot4(B, wu[j], sumU, false);
+    }
+    atomicAdd(&msum[0], (int)sumU - 15 * (int)sumI);  // m10 = sum u*I
+    atomicAdd(&msum[1], v * (int)sumI);                // m01 = sum v*I
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  const int m10 = msum[0], m01 = msum[1];
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+  DS_STAMP(2);
+  // ---- horizontal pass: blurred column c (x = kx-18+c) uses window bytes s+c .. s+c+6 of the staged row.
+  //      Item = (row pair, group of 4 columns): 4 dwords per row cover the 10 bytes the 4 columns need; the 190 items of
+  //      the sampling disc (d_descHItems) in 3 steps.
+  //      The byte shift s of the window inside its dwords is the same for the whole wave, so instead of shifting the data
+  //      (9 v_alignbyte per row) the TAPS are shifted: for each s the weights of the four dwords are compile-time
+  //      constants (descHTap), zero ones are skipped, and every s costs exactly 10 v_dot4_u32_u8 per row ----
+  {
+    auto hpass = [&](auto sTag) {
+      constexpr int SH = decltype(sTag)::value;
+#pragma unroll
+      for (int it = 0; it < 3; it++) {
+        const int rp = (int)(hitem[it] >> 4), gq = (int)(hitem[it] & 15u);
+        if (hitem[it] != 0xffffu) {
+          uint32_t hs[2][4];
+#pragma unroll
+          for (int h2 = 0; h2 < 2; h2++) {
+            const int row = h2 ? min(2 * rp + 1, PW_ROWS - 1) : 2 * rp;
+            const uint32_t* p = raw + row * PW_WORDS + gq;
+            const uint32_t dd[4] = {p[0], p[1], p[2], p[3]};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+              uint32_t acc = 0;
+#pragma unroll
+              for (int m = 0; m < 4; m++)
+                if (descHTap<GV>(SH + c, m) != 0u) acc = __builtin_amdgcn_udot4(dd[m], descHTap<GV>(SH + c, m), acc, false);
+              hs[h2][c] = acc;
+            }
+          }
+          uint4 o4;
+          // (both sums are < 2^16: one v_perm_b32 packs the pair instead of a shift and an or)
+          o4.x = __builtin_amdgcn_perm(hs[1][0], hs[0][0], 0x05040100u); o4.y = __builtin_amdgcn_perm(hs[1][1], hs[0][1], 0x05040100u);
+          o4.z = __builtin_amdgcn_perm(hs[1][2], hs[0][2], 0x05040100u); o4.w = __builtin_amdgcn_perm(hs[1][3], hs[0][3], 0x05040100u);
+          *reinterpret_cast<uint4*>(&hz2[rp * PW_COLS + 4 * gq]) = o4;
+        }
+      }
+    };
+    switch (s) {  // wave-uniform
+      case 0: hpass(std::integral_constant<int, 0>{}); break;
+      case 1: hpass(std::integral_constant<int, 1>{}); break;
+      case 2: hpass(std::integral_constant<int, 2>{}); break;
+      default: hpass(std::integral_constant<int, 3>{}); break;
+    }
+  }
+  DS_STAMP(3);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // ---- vertical pass + rounding with v_dot2_u32_u16 on row pairs: blurred rows 2q and 2q+1 both use pairs q..q+3,
+  //      even row taps (18,34)(48,56)(48,34)(18,0), odd row taps (0,18)(34,48)(56,48)(34,18).  Item = (q, group of 4
+  //      columns), 190 items over 3 steps; the blurred bytes overwrite the raw window (no longer needed) ----
+  {
+    constexpr uint32_t T0 = 18u, T1 = 34u, T2 = GV ? 49u : 48u, T3 = GV ? 55u : 56u;
+    constexpr uint32_t E0 = T0 | (T1 << 16), E1 = T2 | (T3 << 16), E2 = T2 | (T1 << 16), E3 = T0;
+    constexpr uint32_t O0 = T0 << 16, O1 = T1 | (T2 << 16), O2 = T3 | (T2 << 16), O3 = T1 | (T0 << 16);
+    int q = lane / 10, gq = lane - q * 10;
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+      if (q < BL_ROWS_PAD / 2) {
+        const uint4 P0 = *reinterpret_cast<const uint4*>(&hz2[(q + 0) * PW_COLS + 4 * gq]);
+        const uint4 P1 = *reinterpret_cast<const uint4*>(&hz2[(q + 1) * PW_COLS + 4 * gq]);
+        const uint4 P2 = *reinterpret_cast<const uint4*>(&hz2[(q + 2) * PW_COLS + 4 * gq]);
+        const uint4 P3 = *reinterpret_cast<const uint4*>(&hz2[(q + 3) * PW_COLS + 4 * gq]);
+#define ORBX_VE(c) dot2u16(P0.c, E0, dot2u16(P1.c, E1, dot2u16(P2.c, E2, dot2u16(P3.c, E3, 32768u))))
+#define ORBX_VO(c) dot2u16(P0.c, O0, dot2u16(P1.c, O1, dot2u16(P2.c, O2, dot2u16(P3.c, O3, 32768u))))
+        uint32_t e0 = ORBX_VE(x), e1 = ORBX_VE(y), e2 = ORBX_VE(z), e3 = ORBX_VE(w);
+        uint32_t o0 = ORBX_VO(x), o1 = ORBX_VO(y), o2 = ORBX_VO(z), o3 = ORBX_VO(w);
+        if (GV) {  // taps that sum to 257: saturate_cast<uchar>
+          e0 = min(e0, 0xffffffu); e1 = min(e1, 0xffffffu); e2 = min(e2, 0xffffffu); e3 = min(e3, 0xffffffu);
+          o0 = min(o0, 0xffffffu); o1 = min(o1, 0xffffffu); o2 = min(o2, 0xffffffu); o3 = min(o3, 0xffffffu);
+        }
+#undef ORBX_VE
+#undef ORBX_VO
+        // each sum is < 2^24: its blurred byte is bits 16..23; v_perm_b32 gathers byte 2 of four sums into one dword
+        bl32[(2 * q) * (PW_COLS / 4) + gq] =
+            __builtin_amdgcn_perm(e1, e0, 0x0c0c0602u) | __builtin_amdgcn_perm(e3, e2, 0x06020c0cu);
+        bl32[(2 * q + 1) * (PW_COLS / 4) + gq] =
+            __builtin_amdgcn_perm(o1, o0, 0x0c0c0602u) | __builtin_amdgcn_perm(o3, o2, 0x06020c0cu);
+      }
+      q += 6; gq += 4;  // item + 64
+      if (gq >= 10) { gq -= 10; q++; }
+    }
+  }
+  DS_STAMP(4);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // ---- steered BRIEF (cpp:169-228).  cos/sin of the f32 argument are evaluated in f64 and rounded to f32 ----
+  const uint8_t* bl = reinterpret_cast<const uint8_t*>(bl32);
+  const float factorPI = (float)(3.14159265358979323846 / 180.f);
+  double sd, cd;
+  sincosSmall((double)(angle * factorPI), &sd, &cd);
+  const float cs = (float)cd, sn = (float)sd;
   unsigned long long words[4];
-  const float angle = descCompute<GV, PW_WORDS>(raw, hz2, msum, s, lane, w1a, w1b, wua, wub, pat, hitem, words);
+#pragma unroll
+  for (int wq = 0; wq < 4; wq++) {
+    const float4 pt = pat[wq];
+    const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
+    // cvRound of the rotated coordinates (cpp:184-188) and the byte address (18 + r) * 40 + 18 + c in one go: v + 1.5 * 2^23
+    // rounds to nearest-even at integer granularity and leaves 0x4B400000 + rint(v) in the float's bits; the low 24 bits
+    // (0x400000 + r) go through v_mad_u32_u24, the constants are taken off at the end
+    constexpr float MAGIC = 12582912.f;
+    constexpr uint32_t OFF = 40u * 0x400000u + 0x4B400000u - (18u * PW_COLS + 18u);
+    const uint32_t ir0 = __float_as_uint((x0 * sn + y0 * cs) + MAGIC), ic0 = __float_as_uint((x0 * cs - y0 * sn) + MAGIC);
+    const uint32_t ir1 = __float_as_uint((x1 * sn + y1 * cs) + MAGIC), ic1 = __float_as_uint((x1 * cs - y1 * sn) + MAGIC);
+    const int t0 = bl[(ir0 & 0xffffffu) * (uint32_t)PW_COLS + ic0 - OFF];
+    const int t1 = bl[(ir1 & 0xffffffu) * (uint32_t)PW_COLS + ic1 - OFF];
+    words[wq] = __ballot(t0 < t1);
+  }
   const long long o = (long long)f * capacity + i;
   if (lane < 4) reinterpret_cast<unsigned long long*>(desc + o * 32)[lane] = words[lane];
   if (lane == 0) {

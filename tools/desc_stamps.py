@@ -24,9 +24,9 @@ for it in range(3):
 torch.cuda.synchronize()
 L.orbx_diag_desc_stamps(ctypes.c_void_p(buf.ctypes.data), nw)
 ok = buf[:, 5] != 0
-t = buf[ok][:, [0, 1, 5]].astype(np.int64)
+t = buf[ok, :6].astype(np.int64)
 dt = (t[:, 1:] - t[:, :-1]) & 0xffffffff
-names = ["window fetch (loads landed)", "IC_Angle .. BRIEF + output (descCompute carries no stamps)"]
+names = ["window fetch (loads landed)", "IC_Angle + fastAtan2", "horizontal blur", "vertical blur", "BRIEF + output"]
 tot = dt.sum(1)
 print("waves %d, cycles per wave: mean %.0f median %.0f" % (ok.sum(), tot.mean(), np.median(tot)))
 for i, nm in enumerate(names):
