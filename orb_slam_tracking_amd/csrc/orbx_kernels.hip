@@ -739,6 +739,7 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
   const uint32_t selC0 = 0x0c000c00u + (uint32_t)sh * 0x00010001u + 0x00010000u, selC1 = selC0 + 0x00020002u;
   const uint32_t selL0 = selC0 + 0x00010001u, selL1 = selL0 + 0x00020002u;
   const bool rNear = sh <= 1;
+  const int rOff = rNear ? 0 : 1;
   const uint32_t selR0 = 0x0c000c00u + (uint32_t)(rNear ? sh + 3 : sh - 1) * 0x00010001u + 0x00010000u, selR1 = selR0 + 0x00020002u;
   const int off0 = 3 * TS + xoff + 3;  // a valid pixel offset for idle lanes
   uint32_t* const dstc = cand + L.candOff + (long long)f * L.candCap + c.segOff;
@@ -773,10 +774,12 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
         // allocation: they read the cell's first quad instead, their verdicts are masked below)
         const bool live = idx0 + lane < nItems;
         const int wA = (live ? offA : offIdle) >> 2;  // dword index of the quad's first pixel's dword
-        const uint32_t cM = t32[wA - 1], c0 = t32[wA], c1 = t32[wA + 1], c2 = t32[wA + 2];
+        const uint32_t cM = t32[wA - 1], c0 = t32[wA], c1 = t32[wA + 1];
         const uint32_t t0 = t32[wA - 3 * (TS / 4)], t1 = t32[wA - 3 * (TS / 4) + 1];
         const uint32_t b0 = t32[wA + 3 * (TS / 4)], b1 = t32[wA + 3 * (TS / 4) + 1];
-        const uint32_t rlo = rNear ? c0 : c1, rhi = rNear ? c1 : c2;
+        // the dword pair that holds the right compass pixels: read again at a wave-uniform offset (an LDS read instead of two
+        // v_cndmask on the vector port, which is the port this kernel is bound by)
+        const uint32_t rlo = t32[wA + rOff], rhi = t32[wA + rOff + 1];
         uint32_t fl[2];
 #pragma unroll
         for (int hp = 0; hp < 2; hp++) {  // pixels (0, 1) and (2, 3) of the quad as u16 pairs
@@ -795,7 +798,10 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
         }
         // the quad's four verdicts as bits 0..3, cleared for pixels beyond the row's end and for idle lanes
         const int nv = live ? min(iw - 4 * qc, 4) : 0;
-        const uint32_t bits = (((fl[0] >> 15) & 1u) | ((fl[0] >> 30) & 2u) | ((fl[1] >> 13) & 4u) | ((fl[1] >> 28) & 8u)) & ((1u << nv) - 1u);
+        // fl[hp] holds its two verdicts in bits 15 and 31: (fl0 >> 15) | (fl1 >> 13) has them in bits 0, 16 and 2, 18; folding the
+        // upper half down by 15 puts all four into bits 0 .. 3 (what lies above is masked off)
+        const uint32_t fx = (fl[0] >> 15) | (fl[1] >> 13);
+        const uint32_t bits = (fx | (fx >> 15)) & ((1u << nv) - 1u);
         const int offP = offA + sh;  // tile offset of the quad's first pixel
         if (__ballot(bits != 0u) != 0ull) {  // (wave-uniform) a step without any survivor appends nothing
 #pragma unroll
