@@ -477,6 +477,21 @@ Sizes sizesOf(const orbx_ctx* c, const Geom& g, size_t tabEntries) {
   return s;
 }
 
+// OctLevel::depthBits D: after D DivideNode splits (cpp:617-676: the left / upper child gets ceil(extent / 2), the right / lower
+// one floor) every cell of the level is one pixel, and from there on a key's quadrant digits are all 0 -- which is what lets the
+// LDS kernel sort 32-bit keys (the path code's top rootBits + 2 D bits).  One case needs care: with a non-integral hX the
+// reference's root = x / hX (cpp:747) against UL.x = hX * i (cpp:715-716) can put the column x = (int)(hX * i) into root i - 1,
+// one pixel to the RIGHT of that root's rectangle, where it is routed right for ever (digits 1, 1, 1 ...).  It parts from the
+// rectangle's last column one split after the rightmost cell has become one pixel wide, i.e. at depth floor(log2 w) + 1 =
+// ceil(log2(w + 1)) for a rectangle of width w <= ceil(hX) -- so D is taken from ceil(hX) + 1, and the difference lies within the
+// top D digits (tests: test_device_octree_root_boundary_columns).  A key can never lie left of its rectangle (x / hX >= i
+// implies x >= floor(hX * i)), and y always lies inside [0, height).
+int octDepthBits(int height, float hX) {
+  int e = std::max((int)std::ceil(hX) + 1, height), d = 0;
+  while (e > 1) { e = (e + 1) >> 1; d++; }
+  return std::max(d, 1);
+}
+
 // launch constants of the quadtree selection stage; returns the bytes of global scratch it needs
 size_t buildOctLaunch(const orbx_ctx* c, const Geom& g, OctLaunch* out) {
   OctLaunch P{};
@@ -491,11 +506,7 @@ size_t buildOctLaunch(const orbx_ctx* c, const Geom& g, OctLaunch* out) {
     O.height = L.maxBY - ORBX_MIN_BORDER;
     O.nIni = (int)std::round((float)O.width / (float)O.height);  // cpp:706
     O.hX = (float)O.width / (float)O.nIni;                       // cpp:709
-    {  // a root is at most ceil(hX) + 1 wide; DivideNode gives the left / upper child ceil(extent / 2) (cpp:620-621)
-      int e = std::max((int)std::ceil(O.hX) + 1, O.height), d = 0;
-      while (e > 1) { e = (e + 1) >> 1; d++; }
-      O.depthBits = std::max(d, 1);
-    }
+    O.depthBits = octDepthBits(O.height, O.hX);
     O.wCell = L.wCell;
     O.hCell = L.hCell;
     O.nCols = L.nCols;
@@ -2031,11 +2042,7 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
   O.nIni = (int)std::round((float)O.width / (float)O.height);
   if (O.nIni < 1 || O.nIni > 255) return ORBX_E_TOOSMALL;
   O.hX = (float)O.width / (float)O.nIni;
-  {
-    int e = std::max((int)std::ceil(O.hX) + 1, O.height), d = 0;
-    while (e > 1) { e = (e + 1) >> 1; d++; }
-    O.depthBits = std::max(d, 1);
-  }
+  O.depthBits = octDepthBits(O.height, O.hX);
   O.wCell = O.hCell = 1 << 20;  // one "cell": candidate order = row-major
   O.nCols = 1;
   O.quota = n_features;

@@ -419,6 +419,44 @@ def test_device_octree_small_quotas(orbx, ext640, oracle):
     e.close()
 
 
+@pytest.mark.parametrize("W,H", [(595, 368), (501, 150), (333, 100), (596, 368), (513, 256), (1025, 512), (769, 256), (767, 256), (1535, 512)])
+def test_device_octree_root_boundary_columns(orbx, ext640, oracle, W, H):
+    """Rectangles with two or three roots whose boundary is not integral (odd width: hX = 297.5; three roots: hX = 167.0 / 111.0
+    ...): the reference's root = x / hX (cpp:747) puts the column x = (int)hX into root 0, outside that root's rectangle
+    [0, (int)hX), where DivideNode routes it right for ever -- only the full 16-level path code tells it from the rectangle's
+    last column.  The LDS kernel's 32-bit sort keys drop the digits beyond the one-pixel depth D, so D must cover the split at
+    which that column parts from the rectangle's last one (octDepthBits: ceil(hX) + 1; rectangles of power-of-two width -- 513 / 2,
+    1025 / 2, 769 / 3 -- are the tight case); candidates are packed onto the boundary columns to make a wrong D visible."""
+    rng = np.random.default_rng(W)
+    nIni = round(float(np.float32(W) / np.float32(H)))
+    assert nIni >= 2
+    hX = np.float32(W) / np.float32(nIni)
+    cols = sorted({int(c) for i in range(1, nIni) for c in (int(hX * i) - 1, int(hX * i), int(hX * i) + 1) if 0 <= c < W})
+    pts = {(x, y) for x in cols for y in range(0, H, 1 + int(rng.integers(0, 2)))}
+    while len(pts) < 1500:
+        pts.add((int(rng.integers(0, W)), int(rng.integers(0, H))))
+    xyr = np.array(sorted([(x, y, int(rng.integers(6, 40))) for x, y in pts], key=lambda t: (t[1], t[0])), np.float32)
+    for N in (60, 217, 250, 400):
+        exp = oracle.distribute(xyr, 16, 16 + W, 16, 16 + H, N)[:N]
+        for variant in (0, 1, 2, 3, 4):
+            got = ext640.debug_distribute_device(xyr, 16, 16 + W, 16, 16 + H, N, variant)
+            assert got.shape == exp.shape and np.array_equal(got, exp), (N, variant)
+    # the deep case: a quota that forces the tree down to single pixels right at a boundary -- the column pair ((int)hX - 1,
+    # (int)hX) over 140 rows, and hardly anything else
+    for i in range(1, nIni):
+        c = int(hX * i)
+        h0 = min(140, H - 2)
+        pts2 = {(x, y) for x in (c - 1, c) for y in range(1, 1 + h0)}
+        while len(pts2) < 2 * h0 + 40:
+            pts2.add((int(rng.integers(0, W)), int(rng.integers(0, H))))
+        xyr2 = np.array(sorted([(x, y, int(rng.integers(6, 40))) for x, y in pts2], key=lambda t: (t[1], t[0])), np.float32)
+        for N in (200, 250, 256):
+            exp = oracle.distribute(xyr2, 16, 16 + W, 16, 16 + H, N)[:N]
+            for variant in (0, 1, 2, 3, 4):
+                got = ext640.debug_distribute_device(xyr2, 16, 16 + W, 16, 16 + H, N, variant)
+                assert got.shape == exp.shape and np.array_equal(got, exp), ("deep", i, N, variant)
+
+
 @pytest.mark.parametrize("shape", [(608, 448, 217), (720, 448, 434), (1888, 1048, 869), (3808, 2128, 1737), (147, 102, 60)])
 def test_device_octree_level_geometries(orbx, ext640, oracle, shape):
     W, H, N = shape
