@@ -170,7 +170,7 @@ struct CamD {
 // list, the per-query candidate counts and MW_CP list entries per query, all for min(capacity, MW_CAP) queries / trains.
 constexpr int MW_CAP = 4096;  // octave-0 queries / eligible trains per pair the wide path takes
 constexpr int MW_CP = 128;    // candidates listed per query (a fuller window hands the pair to k_match)
-constexpr int MW_HDR = 16;    // [0] nQ, [1] nT, [2] 1 = too large for the wide path, [3] != 0 = a list overflowed
+constexpr int MW_HDR = 16;    // [0] nQ, [1] nT, [2] 1 = too large for the wide path, [3] != 0 = a list overflowed, [4..7] bounding box of the eligible trains (float bits: min x, max x, min y, max y)
 inline int matchWideCap(int capacity) { return capacity < MW_CAP ? capacity : MW_CAP; }
 inline long long matchScratchStride(int capacity) {
   const long long capl = matchWideCap(capacity);

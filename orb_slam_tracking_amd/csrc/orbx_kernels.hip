@@ -1381,6 +1381,9 @@ __device__ void matchWidePrep(const int pair, const int* __restrict__ pairFirst,
   if (t == 0) { sBaseQ = 0; sBaseT = 0; }
   __syncthreads();
   const int n = max(n1, n2);
+  // bounding box of the eligible trains (header [4..7]): lets k_match_wide_lists recognise the brute-force case -- a window that
+  // covers every train for every query of a workgroup -- and skip the per-pair window tests there
+  float bbx0 = 3.0e38f, bbx1 = -3.0e38f, bby0 = 3.0e38f, bby1 = -3.0e38f;
   for (int i0 = 0; i0 < n; i0 += T) {
     const int i = i0 + t;
     bool okQ = false, okT = false;
@@ -1397,6 +1400,7 @@ __device__ void matchWidePrep(const int pair, const int* __restrict__ pairFirst,
       py = (int)roundf((kp.y - fminY) * hInv);
       okT = kp.octave == 0 && px >= 0 && px < ORBX_GRID_COLS && py >= 0 && py < ORBX_GRID_ROWS;
       tx = kp.x; ty = kp.y;
+      if (okT) { bbx0 = fminf(bbx0, tx); bbx1 = fmaxf(bbx1, tx); bby0 = fminf(bby0, ty); bby1 = fmaxf(bby1, ty); }
     }
     const unsigned long long bq = __ballot(okQ), bt = __ballot(okT);
     if (lane == 0) { wq[wave] = __popcll(bq); wt[wave] = __popcll(bt); }
@@ -1416,6 +1420,22 @@ __device__ void matchWidePrep(const int pair, const int* __restrict__ pairFirst,
       sBaseQ = tq; sBaseT = tt;
     }
     __syncthreads();
+  }
+  {  // workgroup reduction of the bounding box (wq / wt are free again: reused as float slots through LDS arrays of their own)
+    __shared__ float bbW[4][T / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      bbx0 = fminf(bbx0, __shfl_xor(bbx0, o)); bbx1 = fmaxf(bbx1, __shfl_xor(bbx1, o));
+      bby0 = fminf(bby0, __shfl_xor(bby0, o)); bby1 = fmaxf(bby1, __shfl_xor(bby1, o));
+    }
+    if (lane == 0) { bbW[0][wave] = bbx0; bbW[1][wave] = bbx1; bbW[2][wave] = bby0; bbW[3][wave] = bby1; }
+    __syncthreads();
+    if (t == 0) {
+      for (int w2 = 1; w2 < T / 64; w2++) {
+        bbx0 = fminf(bbx0, bbW[0][w2]); bbx1 = fmaxf(bbx1, bbW[1][w2]); bby0 = fminf(bby0, bbW[2][w2]); bby1 = fmaxf(bby1, bbW[3][w2]);
+      }
+      S[4] = (int)__float_as_uint(bbx0); S[5] = (int)__float_as_uint(bbx1); S[6] = (int)__float_as_uint(bby0); S[7] = (int)__float_as_uint(bby1);
+    }
   }
   if (t == 0) {
     S[0] = sBaseQ; S[1] = sBaseT;
@@ -1984,31 +2004,48 @@ __global__ __launch_bounds__(256) void k_match_wide_lists(const int* __restrict_
   const int chunk = (nT + 3) >> 2;
   const int e0 = part * chunk, e1 = min(nT, e0 + chunk);
   bool any = false;
-  for (int eb = e0; eb < e1; eb += 4) {  // four wave-uniform train records in flight
-    uint4 rec[4];
+  // Brute force (BASELINE config 5's 2000 x 2000 match: the window covers the frame): when, for every query of this wave, the
+  // cell range is the whole grid and both ends of the trains' bounding box lie within r -- float subtraction is monotonic, so
+  // then fabsf(tx - qx) < r for EVERY train -- the six comparisons per (query, train) are dropped and the loop is the 16
+  // xor / bcnt operations of the Hamming distance plus one compare (k_match_wide_lists 410 -> see profiles us per 64 x 2000^2)
+  const float bbx0 = __uint_as_float((uint32_t)S[4]), bbx1 = __uint_as_float((uint32_t)S[5]);
+  const float bby0 = __uint_as_float((uint32_t)S[6]), bby1 = __uint_as_float((uint32_t)S[7]);
+  const bool lanePass = !valid || (minCX == 0 && maxCX == ORBX_GRID_COLS - 1 && minCY == 0 && maxCY == ORBX_GRID_ROWS - 1 &&
+                                   fabsf(bbx0 - qx) < r && fabsf(bbx1 - qx) < r && fabsf(bby0 - qy) < r && fabsf(bby1 - qy) < r);
+  const bool allPass = __ballot(!lanePass) == 0ull;  // wave-uniform
+  auto scan = [&](auto tag) {
+    constexpr bool ALL = decltype(tag)::value;
+    for (int eb = e0; eb < e1; eb += 4) {  // four wave-uniform train records in flight
+      uint4 rec[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) rec[j] = trec[min(eb + j, e1 - 1)];
+      for (int j = 0; j < 4; j++) rec[j] = trec[min(eb + j, e1 - 1)];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int e = eb + j;
-      if (e >= e1) break;
-      const int cx = (int)(rec[j].z & 0xff), cy = (int)(rec[j].z >> 8);
-      const float dx = __uint_as_float(rec[j].x) - qx, dy = __uint_as_float(rec[j].y) - qy;
-      const bool in = valid && cx >= minCX && cx <= maxCX && cy >= minCY && cy <= maxCY && fabsf(dx) < r && fabsf(dy) < r;
-      if (__ballot(in) == 0ull) continue;  // wave-uniform
-      const uint32_t* b = d2 + (long long)(rec[j].w & 0xfffff) * 8;  // wave-uniform address: scalar loads
-      const uint4 b0 = reinterpret_cast<const uint4*>(b)[0], b1 = reinterpret_cast<const uint4*>(b)[1];
-      if (in) {
-        const int dist = __popc(qd[0] ^ b0.x) + __popc(qd[1] ^ b0.y) + __popc(qd[2] ^ b0.z) + __popc(qd[3] ^ b0.w) +
-                         __popc(qd[4] ^ b1.x) + __popc(qd[5] ^ b1.y) + __popc(qd[6] ^ b1.z) + __popc(qd[7] ^ b1.w);
-        any = true;
-        if (dist < mp.dmax) {  // a farther train can neither be accepted nor fail the ratio test of a nearer one
-          const int slot = atomicAdd(&cnt[lane], 1);
-          if (slot < MW_CP) lists[(size_t)slot * capl + q] = ((uint32_t)dist << 16) | (uint32_t)e;
+      for (int j = 0; j < 4; j++) {
+        const int e = eb + j;
+        if (e >= e1) break;
+        bool in = valid;
+        if (!ALL) {
+          const int cx = (int)(rec[j].z & 0xff), cy = (int)(rec[j].z >> 8);
+          const float dx = __uint_as_float(rec[j].x) - qx, dy = __uint_as_float(rec[j].y) - qy;
+          in = valid && cx >= minCX && cx <= maxCX && cy >= minCY && cy <= maxCY && fabsf(dx) < r && fabsf(dy) < r;
+          if (__ballot(in) == 0ull) continue;  // wave-uniform
+        }
+        const uint32_t* b = d2 + (long long)(rec[j].w & 0xfffff) * 8;  // wave-uniform address: scalar loads
+        const uint4 b0 = reinterpret_cast<const uint4*>(b)[0], b1 = reinterpret_cast<const uint4*>(b)[1];
+        if (in) {
+          const int dist = __popc(qd[0] ^ b0.x) + __popc(qd[1] ^ b0.y) + __popc(qd[2] ^ b0.z) + __popc(qd[3] ^ b0.w) +
+                           __popc(qd[4] ^ b1.x) + __popc(qd[5] ^ b1.y) + __popc(qd[6] ^ b1.z) + __popc(qd[7] ^ b1.w);
+          any = true;
+          if (dist < mp.dmax) {  // a farther train can neither be accepted nor fail the ratio test of a nearer one
+            const int slot = atomicAdd(&cnt[lane], 1);
+            if (slot < MW_CP) lists[(size_t)slot * capl + q] = ((uint32_t)dist << 16) | (uint32_t)e;
+          }
         }
       }
     }
-  }
+  };
+  if (allPass) scan(std::true_type{});
+  else scan(std::false_type{});
   if (any) anyIn[lane] = 1;  // vIndices2 of the query is not empty (the four parts may all store the same 1)
   __syncthreads();
   if (t < 64 && valid) {
