@@ -419,8 +419,8 @@ def main():
         # second figure: the call the reference actually makes -- one frame per call through the host API
         # (Frame.cpp:58-60: host image in, keypoints + descriptors back on the host), and one SearchForInitialization per call
         try:
-            if args.no_single_frame:
-                raise RuntimeError("skipped (--no-single-frame)")
+            if args.no_single_frame or world > 1:
+                raise RuntimeError("skipped (--no-single-frame)" if args.no_single_frame else "skipped (N > 1: an N = 1 figure)")
             e1 = orbx.ORBextractor(*PARAMS, max_width=W, max_height=H, max_batch=1, device=local_rank)
             fa, fb = orbx.Frame(frames[0], 0.0, e1), orbx.Frame(frames[1], 1.0, e1)
             mt = orbx.ORBmatcher(0.9, True)
@@ -440,7 +440,7 @@ def main():
             e1.close()
         except Exception as ex:  # never let the second figure break the line
             out["single_frame"] = {"error": str(ex)[:200]}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # (the CPU baseline is an N = 1 figure: rank 0's host cores, one GPU beside it)
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O
             cores = cpu_share()
