@@ -142,7 +142,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   if (n <= NMAX && P.lev[level].quota <= QMAX && keysFit) {
     // the candidate words of the unit, in candidate-list order: head of the unit's global scratch area (octScratchBytes >= 8 KB)
     uint32_t* candE = reinterpret_cast<uint32_t*>(scratch + P.scrOff[level] + (int64_t)f * P.scrStride[level]);
-    OctScratchT<uint16_t, KEY> S{keys, 2 * (OCT_DEPTH - depthBits), nodes, div, hiOf, nodeLo, nodeHi, nodeDepth, sized, pending,
+    OctScratchT<uint16_t, KEY, (NMAX / OCT_T + 3) / 4 * 4> S{keys, 2 * (OCT_DEPTH - depthBits), nodes, div, hiOf, nodeLo, nodeHi, nodeDepth, sized, pending,
                                  childCnt, candL, segBase, nullptr, 0, hiPar /* hiOf's space: dead during the partial pass */, PARCAP,
                                  nullptr, candE,
                                  reinterpret_cast<uint32_t*>(nodes) /* step 6 only: nodes[] and what aliases it are dead by then */};
