@@ -2084,11 +2084,17 @@ __global__ __launch_bounds__(MW_T) void k_match_wide_resolve(const int* __restri
   const int* qIdx = S + MW_HDR + 4 * capl;
   const int* cntIn = S + MW_HDR + 5 * capl;
   const uint32_t* lists = reinterpret_cast<const uint32_t*>(S + MW_HDR + 6 * capl);
+  // behind the MW_CP list rows: MW_TOPK rows with every query's best candidates by (distance, candidate order), ascending --
+  // written by the query's first full scan.  A later sweep only needs the first two of them that no earlier query hides
+  // (best, and the distance of the second); only a query that finds fewer than two among its top ones re-reads its whole list.
+  // (A sweep used to re-read all lists: a dozen dependent L2 round trips per sweep, 170 us for eight 1080p pairs.)
+  uint32_t* top = reinterpret_cast<uint32_t*>(scratch + (long long)pair * scratchStride + MW_HDR + 6 * capl) + (size_t)MW_CP * capl;
   const int fa = pairFirst[pair], fb = pairSecond[pair];
   const int cap = mp.capacity;
   const orbx_keypoint* k1 = kps + (long long)fa * cap;
   const orbx_keypoint* k2 = kps + (long long)fb * cap;
   int* m12 = matches12 + (long long)pair * cap;
+  unsigned topReady = 0;  // bit rr: the top rows of query t + rr * MW_T are written
 
   if (t == 0) { sNm = 0; sBadDist = 0; sBadRatio = 0; sBadOri = 0; }
   if (t < HISTO_LENGTH) hist[t] = 0;
@@ -2116,33 +2122,83 @@ __global__ __launch_bounds__(MW_T) void k_match_wide_resolve(const int* __restri
       const uint32_t* myList = lists + q;
       unsigned long long best = MATCH_NONE;  // dist << 32 | cell << 20 | train index
       int second = INF_DIST, bt = 0;
-      for (int k = 0; k < nc; k += 4) {
-        uint32_t ce[4], ord[4];
-        int hd[4];
+      // vMatchedDistance[e] as query q sees it: smallest distance of an earlier accepted query that chose e
+      auto hiddenBelow = [&](int hd) {
+        int md = INF_DIST;
+        for (int c = hd; c >= 0;) {
+          if (c < q) md = min(md, (int)outD[c]);
+          const int nx = nextQ[c];
+          c = nx == MW_END ? -1 : nx;
+        }
+        return md;
+      };
+      bool fromTop = false;
+      if (topReady & (1u << rr)) {
+        uint32_t tc[MW_TOPK], ord[MW_TOPK];
+        int hd[MW_TOPK];
+        const int tn = min(nc, MW_TOPK);
 #pragma unroll
-        for (int j = 0; j < 4; j++) ce[j] = myList[(size_t)min(k + j, nc - 1) * capl];
+        for (int j = 0; j < MW_TOPK; j++) tc[j] = top[(size_t)min(j, tn - 1) * capl + q];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { hd[j] = head[ce[j] & 0xffff]; ord[j] = tOrd[ce[j] & 0xffff]; }
+        for (int j = 0; j < MW_TOPK; j++) { hd[j] = head[tc[j] & 0xffff]; ord[j] = tOrd[tc[j] & 0xffff]; }
+        int found = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          if (k + j >= nc) break;
-          const int e = ce[j] & 0xffff, dist = (int)(ce[j] >> 16);
-          // vMatchedDistance[e] as query q sees it: smallest distance of an earlier accepted query that chose e
-          int md = INF_DIST;
-          for (int c = hd[j]; c >= 0;) {
-            if (c < q) md = min(md, (int)outD[c]);
-            const int nx = nextQ[c];
-            c = nx == MW_END ? -1 : nx;
+        for (int j = 0; j < MW_TOPK; j++) {
+          if (j >= tn || found == 2) break;
+          const int e = tc[j] & 0xffff, dist = (int)(tc[j] >> 16);
+          if (hiddenBelow(hd[j]) <= dist) continue;  // ORBmatcher.cpp:67
+          if (found == 0) { best = ((unsigned long long)dist << 32) | ord[j]; bt = e; }
+          else second = dist;  // sorted by (distance, order): the second visible one carries the second-smallest distance
+          found++;
+        }
+        fromTop = found == 2 || nc <= MW_TOPK;  // (all of a short list is in the top rows)
+        if (!fromTop) { best = MATCH_NONE; second = INF_DIST; bt = 0; }
+      }
+      if (!fromTop) {
+        const bool record = !(topReady & (1u << rr));
+        unsigned long long tk[MW_TOPK];  // the MW_TOPK smallest keys seen, ascending, and their list entries
+        uint32_t tce[MW_TOPK];
+#pragma unroll
+        for (int j = 0; j < MW_TOPK; j++) { tk[j] = MATCH_NONE; tce[j] = 0u; }
+        for (int k = 0; k < nc; k += 4) {
+          uint32_t ce[4], ord[4];
+          int hd[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) ce[j] = myList[(size_t)min(k + j, nc - 1) * capl];
+#pragma unroll
+          for (int j = 0; j < 4; j++) { hd[j] = head[ce[j] & 0xffff]; ord[j] = tOrd[ce[j] & 0xffff]; }
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (k + j >= nc) break;
+            const int e = ce[j] & 0xffff, dist = (int)(ce[j] >> 16);
+            const unsigned long long key = ((unsigned long long)dist << 32) | ord[j];
+            if (record && key < tk[MW_TOPK - 1]) {  // insertion into the sorted top entries (keys are unique: the order holds the index)
+              unsigned long long ck = key;
+              uint32_t cc = ce[j];
+#pragma unroll
+              for (int u = 0; u < MW_TOPK; u++) {
+                const bool sw = ck < tk[u];
+                const unsigned long long ok = tk[u];
+                const uint32_t oc = tce[u];
+                tk[u] = sw ? ck : ok; tce[u] = sw ? cc : oc;
+                ck = sw ? ok : ck; cc = sw ? oc : cc;
+              }
+            }
+            if (hiddenBelow(hd[j]) <= dist) continue;  // ORBmatcher.cpp:67
+            if (key < best) {
+              second = min(second, (int)(best >> 32));
+              best = key;
+              bt = e;
+            } else {
+              second = min(second, dist);
+            }
           }
-          if (md <= dist) continue;  // ORBmatcher.cpp:67
-          const unsigned long long key = ((unsigned long long)dist << 32) | ord[j];
-          if (key < best) {
-            second = min(second, (int)(best >> 32));
-            best = key;
-            bt = e;
-          } else {
-            second = min(second, dist);
-          }
+        }
+        if (record) {
+#pragma unroll
+          for (int j = 0; j < MW_TOPK; j++)
+            if (j < nc) top[(size_t)j * capl + q] = tce[j];
+          topReady |= 1u << rr;
         }
       }
       int nOutcome, nBestT = -1, nBestD = 0;
