@@ -91,7 +91,7 @@ struct orbx_ctx {
   size_t candEntries = 0;
   int* dCandCount = nullptr;   // only its tail is used: the two error flags (dOverflow)
   int* dCellCount = nullptr;   // [frame][cell of all levels]: candidates in the cell's segment
-  int* dMaxN = nullptr;        // [stream slot][level] largest candidate count of a unit (k_octree_lds), reset by k_sel_compact
+  int* dMaxN = nullptr;        // [frame][level] candidate count of the unit (k_octree_lds); reduced and reset by k_sel_compact
   int* hMaxN = nullptr;        // pinned mirror, written by k_sel_compact
   int* hMaxNDev = nullptr;
   int candHintL[ORBX_MAX_LEVELS]{};  // per level: largest candidate count of a unit in the previous batch of this geometry (0 = unknown)
@@ -113,6 +113,9 @@ struct orbx_ctx {
   SelKp* dSelStage = nullptr;
   int* dNselLevel = nullptr;
   uint8_t* dOctScratch = nullptr;
+  uint32_t* dOctTab = nullptr;     // path-code tables of the current geometry's levels (OctLaunch::codeTab)
+  size_t octTabEntries = 0;
+  std::vector<uint32_t> hOctTab;
   size_t octScratchBytes = 0;
   int* hFlags = nullptr;  // pinned [2], written by k_sel_compact through hFlagsDev: selection error of the batch in flight with that parity
   int* hFlagsDev = nullptr;
@@ -492,6 +495,57 @@ int octDepthBits(int height, float hX) {
   return std::max(d, 1);
 }
 
+// Path-code tables of one level (OctLevel::tabOff): DivideNode routes x and y independently (cpp:656-668: pt.x < n1.UR.x, then
+// pt.y < n1.BR.y), so the 16 quadrant digits of a candidate are the OR of an x word and a y word, each a function of one
+// coordinate: root = x / hX (cpp:747), the root's rectangle (cpp:715-716), then mid = UL + ceil(extent / 2) (cpp:620-621) 16 times.
+// The selection units look the two words up instead of walking the 16 splits per candidate.  out: 2 tabW + tabH dwords.
+void octCodeTable(const OctLevel& O, uint32_t* out) {
+  for (int xi = 0; xi < O.tabW; xi++) {
+    const float x = (float)xi;
+    int root = (int)(x / O.hX);
+    root = std::min(std::max(root, 0), O.nIni - 1);
+    int ul = (int)(O.hX * (float)root), br = (int)(O.hX * (float)(root + 1));
+    uint32_t s = 0;
+    for (int d = 0; d < 16; d++) {
+      const int mid = ul + ((br - ul + 1) >> 1);
+      const uint32_t q = !(x < (float)mid);
+      if (q) ul = mid; else br = mid;
+      s = (s << 2) | q;
+    }
+    out[2 * xi] = s;
+    out[2 * xi + 1] = (uint32_t)root;
+  }
+  uint32_t* ty = out + 2 * (size_t)O.tabW;
+  for (int yi = 0; yi < O.tabH; yi++) {
+    const float y = (float)yi;
+    int ul = 0, br = O.height;
+    uint32_t s = 0;
+    for (int d = 0; d < 16; d++) {
+      const int mid = ul + ((br - ul + 1) >> 1);
+      const uint32_t q = !(y < (float)mid);
+      if (q) ul = mid; else br = mid;
+      s = (s << 2) | (q << 1);
+    }
+    ty[yi] = s;
+  }
+}
+// places the levels' tables one behind the other (tabW / tabH set by the caller); returns the dwords they take
+size_t octTabLayout(OctLaunch* P) {
+  size_t off = 0;
+  for (int l = 0; l < P->nlevels; l++) {
+    OctLevel& O = P->lev[l];
+    O.tabOff = (int32_t)off;
+    off += (2 * (size_t)O.tabW + (size_t)O.tabH + 1) & ~(size_t)1;  // (the x pairs are read as 8-byte words)
+  }
+  return off;
+}
+void octCodeTables(const OctLaunch& P, std::vector<uint32_t>* out) {
+  size_t total = 0;
+  for (int l = 0; l < P.nlevels; l++) total = std::max(total, (size_t)P.lev[l].tabOff + 2 * (size_t)P.lev[l].tabW + (size_t)P.lev[l].tabH + 1);
+  out->assign(total, 0u);
+  for (int l = 0; l < P.nlevels; l++) octCodeTable(P.lev[l], out->data() + P.lev[l].tabOff);
+}
+
 // launch constants of the quadtree selection stage; returns the bytes of global scratch it needs
 size_t buildOctLaunch(const orbx_ctx* c, const Geom& g, OctLaunch* out) {
   OctLaunch P{};
@@ -507,6 +561,8 @@ size_t buildOctLaunch(const orbx_ctx* c, const Geom& g, OctLaunch* out) {
     O.nIni = (int)std::round((float)O.width / (float)O.height);  // cpp:706
     O.hX = (float)O.width / (float)O.nIni;                       // cpp:709
     O.depthBits = octDepthBits(O.height, O.hX);
+    O.tabW = O.width;    // candidates lie inside the level's region (relative to minBorder)
+    O.tabH = O.height;
     O.wCell = L.wCell;
     O.hCell = L.hCell;
     O.nCols = L.nCols;
@@ -528,6 +584,8 @@ size_t buildOctLaunch(const orbx_ctx* c, const Geom& g, OctLaunch* out) {
     scr += P.scrStride[l] * c->maxB;
   }
   P.nCellsTotal = g.nCellsTotal;
+  octTabLayout(&P);
+  P.codeTab = c->dOctTab;
   *out = P;
   return (size_t)scr;
 }
@@ -537,7 +595,7 @@ size_t buildOctLaunch(const orbx_ctx* c, const Geom& g, OctLaunch* out) {
 // matcher / staging buffers are not touched.
 void freeAll(orbx_ctx* ctx) {
   void* dev[] = {ctx->dPyr, ctx->dCand, ctx->dCandCount, ctx->dCellCount, ctx->dMaxN, ctx->dTab, ctx->dCells, ctx->dSel, ctx->dNsel,
-                 ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, ctx->dIn, ctx->dKps, ctx->dDesc};
+                 ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, ctx->dOctTab, ctx->dIn, ctx->dKps, ctx->dDesc};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   void* host[] = {ctx->hNsel, ctx->hFlags, ctx->hMaxN, ctx->hWide, ctx->hKpsPin, ctx->hDescPin};
@@ -545,7 +603,7 @@ void freeAll(orbx_ctx* ctx) {
     if (p) (void)hipHostFree(p);
   ctx->dPyr = nullptr; ctx->dCand = nullptr; ctx->dCandCount = nullptr; ctx->dCellCount = nullptr; ctx->dMaxN = nullptr;
   ctx->dTab = nullptr; ctx->dCells = nullptr; ctx->dSel = nullptr; ctx->dNsel = nullptr; ctx->dSelStage = nullptr; ctx->dNselLevel = nullptr;
-  ctx->dOctScratch = nullptr; ctx->dIn = nullptr; ctx->dKps = nullptr; ctx->dDesc = nullptr;
+  ctx->dOctScratch = nullptr; ctx->dOctTab = nullptr; ctx->dIn = nullptr; ctx->dKps = nullptr; ctx->dDesc = nullptr;
   ctx->hNsel = nullptr; ctx->hFlags = nullptr; ctx->hMaxN = nullptr; ctx->hWide = nullptr;
   ctx->hKpsPin = nullptr; ctx->hDescPin = nullptr; ctx->hKpsPinDev = nullptr; ctx->hDescPinDev = nullptr; ctx->pinFrames = 0;
   ctx->hNselDev = nullptr; ctx->hFlagsDev = nullptr; ctx->hMaxNDev = nullptr; ctx->hWideDev = nullptr;
@@ -610,17 +668,19 @@ int allocAll(orbx_ctx* ctx) {
   {
     OctLaunch oct;
     ctx->octScratchBytes = buildOctLaunch(ctx, g, &oct) + 4096;
+    ctx->octTabEntries = octTabLayout(&oct) + 64;  // (no level of a smaller frame is larger than the same level of the largest one)
     ctx->maxQuota = 0;
     for (int q : ctx->quota) ctx->maxQuota = std::max(ctx->maxQuota, q);
   }
   ALLOC(ctx->dOctScratch, ctx->octScratchBytes);
+  ALLOC(ctx->dOctTab, ctx->octTabEntries * 4);
   ALLOC(ctx->dIn, ctx->inBytes);
   ALLOC(ctx->dKps, B * cap * sizeof(orbx_keypoint));
   ALLOC(ctx->dDesc, B * cap * 32);
   ALLOCH(ctx->hNsel, B * sizeof(int))
   ALLOCH(ctx->hFlags, 2 * sizeof(int))
-  ALLOC(ctx->dMaxN, 2 * ORBX_MAX_LEVELS * sizeof(int));
-  if (hipMemset(ctx->dMaxN, 0, 2 * ORBX_MAX_LEVELS * sizeof(int)) != hipSuccess) return ORBX_E_HIP;
+  ALLOC(ctx->dMaxN, (B * nl + 2) * sizeof(int));
+  if (hipMemset(ctx->dMaxN, 0, (B * nl + 2) * sizeof(int)) != hipSuccess) return ORBX_E_HIP;
   ALLOCH(ctx->hMaxN, 2 * ORBX_MAX_LEVELS * sizeof(int))
   if (hipHostGetDevicePointer((void**)&ctx->hMaxNDev, ctx->hMaxN, 0) != hipSuccess) return ORBX_E_HIP;
   if (hipHostGetDevicePointer((void**)&ctx->hNselDev, ctx->hNsel, 0) != hipSuccess) return ORBX_E_HIP;
@@ -700,8 +760,15 @@ int ensureGeometry(orbx_ctx* ctx, int w, int h, int stride0) {
     ctx->err = "internal: geometry exceeds the buffers sized at orbx_create";
     return ORBX_E_BADARG;
   }
+  oct.codeTab = ctx->dOctTab;  // (growTo may have replaced the buffer since buildOctLaunch read the pointer: it did not, but keep one source)
+  octCodeTables(oct, &ctx->hOctTab);
+  if (ctx->hOctTab.size() > ctx->octTabEntries) {
+    ctx->err = "internal: geometry exceeds the buffers sized at orbx_create";
+    return ORBX_E_BADARG;
+  }
   ctx->g = g;
   ctx->oct = oct;
+  HIPCHK(hipMemcpyAsync(ctx->dOctTab, ctx->hOctTab.data(), ctx->hOctTab.size() * 4, hipMemcpyHostToDevice, ctx->st));
   ctx->hTab = tab;
   ctx->pyrInfo = pyrInfo;
   ctx->fastWaveOk = buildFastCells(g, &ctx->hCells);
@@ -858,7 +925,7 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   {  // selection stage: quadtree per (frame, level), then level-major compaction
     StageTimer tm(ctx, ORBX_STAGE_SELECT, si, st);
     // per-level candidate maxima of this stream slot: device accumulators + their pinned host mirror (read after the sync)
-    int* dMax = ctx->dMaxN + si * ORBX_MAX_LEVELS;
+    int* dMax = ctx->dMaxN;  // (indexed by frame: the two half batches do not meet)
     HIPCHK(launch_octree(st, n, ctx->dCand, ctx->dCellCount, oct, ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, dMax,
                          ctx->candHintL, 0, &ctx->lastLaunch[3]));
     HIPCHK(launch_sel_compact(st, n, ctx->dSelStage, ctx->dNselLevel, oct, ctx->dSel, ctx->dNsel, a.dNuser, ctx->hNselDev, g.selCap,
@@ -2043,6 +2110,7 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
   if (O.nIni < 1 || O.nIni > 255) return ORBX_E_TOOSMALL;
   O.hX = (float)O.width / (float)O.nIni;
   O.depthBits = octDepthBits(O.height, O.hX);
+  O.tabW = O.tabH = 4096;       // any coordinate the hook accepts
   O.wCell = O.hCell = 1 << 20;  // one "cell": candidate order = row-major
   O.nCols = 1;
   O.quota = n_features;
@@ -2057,7 +2125,11 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
     if (x < 0 || x > 4095 || y < 0 || y > 4095 || r < 0 || r > 255) return ORBX_E_BADARG;
     packed[i] = packCand(x, y, r);
   }
+  octTabLayout(&P);
+  std::vector<uint32_t> codeTab;
+  octCodeTables(P, &codeTab);
   uint32_t* dC = nullptr;
+  uint32_t* dT = nullptr;
   int* dI = nullptr;
   SelKp* dS = nullptr;
   uint8_t* dScr = nullptr;
@@ -2068,6 +2140,9 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
     HIPCHK(hipMalloc((void**)&dI, 2 * sizeof(int)));
     HIPCHK(hipMalloc((void**)&dS, sel.size() * sizeof(SelKp)));
     HIPCHK(hipMalloc((void**)&dScr, (size_t)P.scrStride[0]));
+    HIPCHK(hipMalloc((void**)&dT, codeTab.size() * 4));
+    P.codeTab = dT;
+    HIPCHK(hipMemcpyAsync(dT, codeTab.data(), codeTab.size() * 4, hipMemcpyHostToDevice, ctx->st));
     HIPCHK(hipMemcpyAsync(dC, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->st));
     int hi[2] = {n, -7};
     HIPCHK(hipMemcpyAsync(dI, hi, sizeof hi, hipMemcpyHostToDevice, ctx->st));
@@ -2083,6 +2158,7 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
   if (dI) (void)hipFree(dI);
   if (dS) (void)hipFree(dS);
   if (dScr) (void)hipFree(dScr);
+  if (dT) (void)hipFree(dT);
   if (rc != ORBX_OK) return rc;
   if (res[1] < 0) return ORBX_E_CAPACITY;
   for (int i = 0; i < res[1] && i < cap; i++) {

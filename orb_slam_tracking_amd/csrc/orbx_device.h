@@ -82,6 +82,9 @@ struct OctLevel {
   int32_t cellBase, nCells, segCap;  // the level's cells in the per-frame cell-count array; entries per cell segment
   int32_t depthBits;       // splits after which every cell of the level is one pixel (DivideNode halves with ceil): the quadrant
                            // digits of a path code beyond this depth are all 0
+  int32_t tabOff, tabW, tabH;  // the level's path-code tables inside OctLaunch::codeTab (dword offset, even): tabW pairs
+                           // {x digits of the 16 DivideNode splits at bit 2 (15 - d), root} by x, then tabH words of y digits
+                           // (bit 2 (15 - d) + 1) by y (octCodeTable on the host); tabW >= width, tabH >= height
 };
 
 struct OctLaunch {
@@ -94,6 +97,7 @@ struct OctLaunch {
   int32_t scrNMax[ORBX_MAX_LEVELS];
   int32_t nlevels, selStride;          // SelKp staging entries per frame
   int32_t frame0, nCellsTotal;         // first frame of this launch; cells of one frame over all levels
+  const uint32_t* codeTab;             // path-code tables of the levels (device memory), see OctLevel::tabOff
 };
 
 #define ORBX_OCT_MAX_CAND ((1 << 19) - 1)  // candidates per (frame, level) the selection stage can index

@@ -2546,7 +2546,8 @@ hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long lo
     const int ts = waveOk == 2 ? 48 : 64;  // tile / strength-map row stride: 48 when every cell image is <= 12 dwords wide
     // (+ 16: the quick reject's dword reads reach a few bytes beyond the last tile row)
     const int tileBytes = ch * ts + 16, smapBytes = (ch - 6 + 2) * ts;
-    const size_t lds = (size_t)(tileBytes + smapBytes + (FW_RING + 64) * 2 + (FW_CORN + 64) * 2);
+    static const int fastPad = getenv("ORBX_FAST_LDS_PAD") ? atoi(getenv("ORBX_FAST_LDS_PAD")) : 0;  // diagnostics: fewer waves per CU
+    const size_t lds = (size_t)(tileBytes + smapBytes + (FW_RING + 64) * 2 + (FW_CORN + 64) * 2) + fastPad;
     static const bool dbg = getenv("ORBX_FAST_DEBUG") != nullptr;
     if (dbg) {
       int nb48 = -1, nb64 = -1;
@@ -2578,11 +2579,12 @@ hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const 
                                  orbx_keypoint* kps, uint8_t* desc, int capacity, int gaussVariant) {
   if (maxSel <= 0) return hipSuccess;
   dim3 block(64 * DESC_WAVES, 1, 1), grid(((maxSel + DESC_WAVES - 1) / DESC_WAVES + 7) / 8 * 8, nFrames, 1);  // x: multiple of 8
+  static const int descPad = getenv("ORBX_DESC_LDS_PAD") ? atoi(getenv("ORBX_DESC_LDS_PAD")) : 0;  // diagnostics: fewer waves per CU
   if (gaussVariant)
-    hipLaunchKernelGGL(k_describe_patch<1>, grid, block, 0, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps, desc,
+    hipLaunchKernelGGL(k_describe_patch<1>, grid, block, descPad, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps, desc,
                        capacity);
   else
-    hipLaunchKernelGGL(k_describe_patch<0>, grid, block, 0, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps, desc,
+    hipLaunchKernelGGL(k_describe_patch<0>, grid, block, descPad, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps, desc,
                        capacity);
   return hipGetLastError();
 }

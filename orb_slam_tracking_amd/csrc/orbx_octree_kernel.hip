@@ -134,7 +134,9 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   const uint32_t* segBase = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
   const int* cellCnt = cellCount + (int64_t)f * P.nCellsTotal + P.lev[level].cellBase;
   const int n = gatherCandidates(cellCnt, P.lev[level].nCells, P.lev[level].segCap, candL, NMAX, threadIdx.x, gws);
-  if (threadIdx.x == 0 && maxN) atomicMax(&maxN[level], n);  // feedback for the next batch's choice of instance
+  // feedback for the next batch's choice of instance: one plain store per unit, reduced by k_sel_compact (an atomicMax on the
+  // level's counter serialised the 256 units of a level behind each other at the memory side: 9 us before the first barrier)
+  if (threadIdx.x == 0 && maxN) maxN[f * P.nlevels + level] = n;
   // 32-bit keys: the level's path codes must fit 21 bits (the host picks this instance only then; checked again here)
   const int depthBits = P.lev[level].depthBits;
   const int rootBits = P.lev[level].nIni > 1 ? 32 - __builtin_clz((unsigned)(P.lev[level].nIni - 1)) : 0;
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
                                  nullptr, candE,
                                  reinterpret_cast<uint32_t*>(nodes) /* step 6 only: nodes[] and what aliases it are dead by then */};
     static_assert(MCAP * 8 >= NMAX * 4, "the sorted candidate copy of step 6 must fit into nodes[]");
-    octreeSelect(S, n, P.lev[level], level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, MCAP, FCAP, QMAX);
+    octreeSelect(S, n, P.lev[level], P.codeTab, level, selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, MCAP, FCAP, QMAX);
     __syncthreads();
     if (threadIdx.x == 0) redo = (*nOut == -2);  // a node table overflowed the LDS layout
     __syncthreads();
@@ -205,10 +207,27 @@ __global__ __launch_bounds__(256) void k_sel_compact(const SelKp* __restrict__ s
                                                      int* __restrict__ hostErr, int* __restrict__ maxN,
                                                      int* __restrict__ hostMaxN) {
   const int f = blockIdx.x + P.frame0;
-  // per-level candidate maxima of this launch go to pinned host memory and are reset for the next one
-  if (blockIdx.x == 0 && maxN && threadIdx.x < P.nlevels) {
-    hostMaxN[threadIdx.x] = maxN[threadIdx.x];
-    maxN[threadIdx.x] = 0;
+  // per-level maxima of the units' candidate counts (k_octree_lds: maxN[frame * nlevels + level]) of this launch go to pinned
+  // host memory; the counts are reset for the next launch (levels no LDS unit ran on report 0)
+  // (workgroup b takes the levels b, b + frames, ...: one count per thread and level at 256 frames)
+  if (maxN && (int)blockIdx.x < P.nlevels) {
+    __shared__ int red[ORBX_MAX_LEVELS];
+    if (threadIdx.x < P.nlevels) red[threadIdx.x] = 0;
+    __syncthreads();
+    for (int l = blockIdx.x; l < P.nlevels; l += gridDim.x) {
+      int m = 0;
+      for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
+        const int idx = (P.frame0 + i) * P.nlevels + l;
+        m = max(m, maxN[idx]);
+        maxN[idx] = 0;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+      if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&red[l], m);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int l = blockIdx.x; l < P.nlevels; l += gridDim.x) hostMaxN[l] = red[l];
   }
   __shared__ int off[ORBX_MAX_LEVELS + 1];
   if (threadIdx.x == 0) {
@@ -311,12 +330,13 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
       const int rootBits = P.lev[l].nIni > 1 ? 32 - __builtin_clz((unsigned)(P.lev[l].nIni - 1)) : 0;
       k32 = k32 && P.lev[l].depthBits >= 1 && rootBits + 2 * P.lev[l].depthBits <= 21;
     }
+    static const int ldsPad = getenv("ORBX_OCT_LDS_PAD") ? atoi(getenv("ORBX_OCT_LDS_PAD")) : 0;  // diagnostics: fewer units per CU
 #define ORBX_OCT_LAUNCH(N_, Q_, DEFER_)                                                                                             \
   do {                                                                                                                              \
     if (k32)                                                                                                                        \
-      hipLaunchKernelGGL((k_octree_lds<N_, Q_, true>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN, DEFER_, l0);  \
+      hipLaunchKernelGGL((k_octree_lds<N_, Q_, true>), grid, block, ldsPad, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN, DEFER_, l0);  \
     else                                                                                                                            \
-      hipLaunchKernelGGL((k_octree_lds<N_, Q_, false>), grid, block, 0, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN, DEFER_, l0); \
+      hipLaunchKernelGGL((k_octree_lds<N_, Q_, false>), grid, block, ldsPad, st, cand, cellCount, P, selStage, nselLevel, scratch, maxN, DEFER_, l0); \
   } while (0)
     switch (inst[l0]) {
       case 512: ORBX_OCT_LAUNCH(512, 128, 0); break;

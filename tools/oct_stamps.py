@@ -30,3 +30,14 @@ for lvl in range(8):
          s[:, 8], s[:, 9], s[:, 10], s[:, 11], s[:, 12], s[:, 13], s[:, 15] - s[:, 14]]
     tot = s[:, 15] - s[:, 0]
     print("level %d total %.0f cyc:" % (lvl, tot.mean()), " ".join("%s=%.0f" % (n, x.mean()) for n, x in zip(names, d)))
+if os.environ.get("OCT_TIMELINE"):  # when the units' first phase starts and ends and when the units end, from the launch's first stamp
+    # (s_memtime counts per XCD: workgroup b runs on XCD b % 8, and each XCD's stamps are taken relative to its own first one)
+    rel = st[:nb].copy()
+    for x in range(8):
+        rows = np.arange(nb) % 8 == x
+        t0 = rel[rows, 0][rel[rows, 0] > 0].min()
+        rel[rows] -= t0
+    for lvl in range(8):
+        s = rel[lvl * B:(lvl + 1) * B]
+        print("level %d: step 1 starts at %6.0f .. %6.0f (mean %6.0f), ends at %6.0f .. %6.0f (mean %6.0f); unit ends at %6.0f .. %6.0f (mean %6.0f)" % (
+            lvl, s[:, 0].min(), s[:, 0].max(), s[:, 0].mean(), s[:, 1].min(), s[:, 1].max(), s[:, 1].mean(), s[:, 15].min(), s[:, 15].max(), s[:, 15].mean()))
