@@ -340,8 +340,8 @@ int orbx_debug_std_sort(orbx_ctx* ctx, int32_t* triples, int n);
 int orbx_debug_sincos(orbx_ctx* ctx, const float* angle_deg, int n, float* cos_out, float* sin_out);
 
 /* How the context's last extraction batch was issued (the kernels behind one entry point depend on batch size, frame size,
- * alignment and the previous batch's statistics): info8 = { [0] pyramid: 1 = k_pyramid_bands (one launch), 0 = one resize launch
- * per level; [1] row bands per frame of k_pyramid_bands; [2] FAST: 1 = k_fast_wave, 0 = k_fast; [3] selection: candidate
+ * alignment and the previous batch's statistics): info8 = { [0] pyramid: 1 = k_pyramid_bands (one launch, large batches), 2 = k_pyramid_tiles
+ * (one launch, small batches), 0 = one resize launch per level; [1] row bands (tiles) per frame of that kernel; [2] FAST: 1 = k_fast_wave, 0 = k_fast; [3] selection: candidate
  * capacity of the smallest LDS instance a pyramid level of the batch ran on (2048 / 1024 / 512; 0 = a level expected units beyond
  * the LDS layout and went to the global-scratch kernel); [4] 1 = the batch was cut into two
  * halves on two streams; [5] frames per kernel launch; [6] 1 = the wide matcher kernels went with the batch; [7] lane the batch

@@ -27,6 +27,9 @@ hipError_t launch_resize(hipStream_t st, int nFrames, const uint8_t* src, long l
 hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, int img0Aligned,
                        const uint8_t* pyr, const Geom& g, uint32_t* cand, int* cellCount, const FastCell* cells, int waveOk,
                        int* usedWave);
+hipError_t launch_pyramid_tiles(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, uint8_t* pyr,
+                                const Geom& g, const PyrTileRect* rects, const PyrTileTap* taps, int nTiles, int buf0Bytes,
+                                int bufBytes);
 hipError_t launch_pyramid_bands(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, uint8_t* pyr,
                                 const Geom& g, const ResizeTab* tab, const PyrBands& pb);
 hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const uint8_t* img0, long long img0FrameStride,
@@ -113,6 +116,12 @@ struct orbx_ctx {
   SelKp* dSelStage = nullptr;
   int* dNselLevel = nullptr;
   uint8_t* dOctScratch = nullptr;
+  PyrTileRect* dPyrTiles = nullptr;  // k_pyramid_tiles' rectangles of the current geometry (buildPyrTiles); nPyrTiles == 0: not usable
+  PyrTileTap* dPyrTaps = nullptr;    // ... and the tiles' tap blobs (ORBX_PYR_TILE_TAPS entries per tile)
+  size_t pyrTileCap = 0;             // tiles the two buffers hold
+  std::vector<PyrTileRect> hPyrTiles;
+  std::vector<PyrTileTap> hPyrTaps;
+  int nPyrTiles = 0, pyrTileBuf0 = 0, pyrTileBuf = 0;
   uint32_t* dOctTab = nullptr;     // path-code tables of the current geometry's levels (OctLaunch::codeTab)
   size_t octTabEntries = 0;
   std::vector<uint32_t> hOctTab;
@@ -495,6 +504,82 @@ int octDepthBits(int height, float hX) {
   return std::max(d, 1);
 }
 
+// Tiles of k_pyramid_tiles: TX x TY tiles per frame; tile (i, j) owns the pixels [i w / TX, (i + 1) w / TX) x [j h / TY, (j + 1) h / TY)
+// of every level and needs, per level, the bounding rectangle of what it owns and of what its rectangle of the next level reads
+// (k_resize's taps: columns ofs .. ofs + 1 and rows ofs .. ofs + 1, clamped as there); level 0's rectangle is what level 1 reads of
+// the caller's image.  The taps of a tile go into one blob, positions relative to the source rectangle.  Returns false when a tile
+// would not fit the kernel's budgets (then the levels are launched one by one).
+void pyrTileGrid(const Geom& g, int* TX, int* TY) {
+  *TX = std::max(1, (g.L[1].w + 35) / 36);
+  *TY = std::max(1, (g.L[1].h + 27) / 28);
+}
+bool buildPyrTiles(const Geom& g, const std::vector<ResizeTab>& tab, std::vector<PyrTileRect>* out, std::vector<PyrTileTap>* taps,
+                   int* nTiles, int* buf0Bytes, int* bufBytes) {
+  const int nl = g.nlevels;
+  *nTiles = 0;
+  *buf0Bytes = *bufBytes = 0;
+  out->clear();
+  taps->clear();
+  if (nl < 2 || g.L[0].w > 32000 || g.L[0].h > 32000) return false;
+  int TX, TY;
+  pyrTileGrid(g, &TX, &TY);
+  out->assign((size_t)TX * TY * nl, PyrTileRect{});
+  taps->assign((size_t)TX * TY * ORBX_PYR_TILE_TAPS, PyrTileTap{0, 0});
+  int maxPix = 0, maxPix0 = 0;
+  for (int tj = 0; tj < TY; tj++)
+    for (int ti = 0; ti < TX; ti++) {
+      PyrTileRect* R = out->data() + (size_t)(tj * TX + ti) * nl;
+      for (int l = 1; l < nl; l++) {
+        R[l].ox0 = (int16_t)((long long)ti * g.L[l].w / TX); R[l].ox1 = (int16_t)((long long)(ti + 1) * g.L[l].w / TX);
+        R[l].oy0 = (int16_t)((long long)tj * g.L[l].h / TY); R[l].oy1 = (int16_t)((long long)(tj + 1) * g.L[l].h / TY);
+      }
+      for (int l = nl - 1; l >= 0; l--) {
+        int x0 = R[l].ox0, x1 = R[l].ox1, y0 = R[l].oy0, y1 = R[l].oy1;
+        const bool ownEmpty = x1 <= x0 || y1 <= y0;
+        if (l + 1 < nl && R[l + 1].nx1 > R[l + 1].nx0 && R[l + 1].ny1 > R[l + 1].ny0) {
+          const ResizeTab* xt = tab.data() + g.L[l + 1].xtabOff;
+          const ResizeTab* yt = tab.data() + g.L[l + 1].ytabOff;
+          const int w = g.L[l].w, h = g.L[l].h;
+          const int fx0 = std::min(std::max(xt[R[l + 1].nx0].ofs, 0), w - 1), fx1 = std::min(xt[R[l + 1].nx1 - 1].ofs + 1, w - 1) + 1;
+          const int fy0 = std::min(std::max(yt[R[l + 1].ny0].ofs, 0), h - 1);
+          const int fy1 = std::min(std::max(yt[R[l + 1].ny1 - 1].ofs + 1, 0), h - 1) + 1;
+          if (ownEmpty) { x0 = fx0; x1 = fx1; y0 = fy0; y1 = fy1; }
+          else { x0 = std::min(x0, fx0); x1 = std::max(x1, fx1); y0 = std::min(y0, fy0); y1 = std::max(y1, fy1); }
+        } else if (ownEmpty) {
+          x0 = x1 = y0 = y1 = 0;
+        }
+        R[l].nx0 = (int16_t)x0; R[l].nx1 = (int16_t)x1; R[l].ny0 = (int16_t)y0; R[l].ny1 = (int16_t)y1;
+        (l == 0 ? maxPix0 : maxPix) = std::max(l == 0 ? maxPix0 : maxPix, (x1 - x0) * (y1 - y0));
+        // (the kernel splits a pixel index into row and column with a 20-bit reciprocal of the width: exact while index * width < 2^20)
+        if ((long long)(x1 - x0) * (y1 - y0) * (x1 - x0) >= (1ll << 20)) { out->clear(); taps->clear(); return false; }
+      }
+      // the tile's taps: per level the needed columns, then the needed rows, relative to the source rectangle (k_resize's clamps)
+      PyrTileTap* T = taps->data() + (size_t)(tj * TX + ti) * ORBX_PYR_TILE_TAPS;
+      int nT = 0;
+      for (int l = 1; l < nl; l++) {
+        const ResizeTab* xt = tab.data() + g.L[l].xtabOff;
+        const ResizeTab* yt = tab.data() + g.L[l].ytabOff;
+        const int sw = g.L[l - 1].w, sh = g.L[l - 1].h;
+        const int nw = R[l].nx1 - R[l].nx0, nh = R[l].ny1 - R[l].ny0;
+        if (nT + nw + nh > ORBX_PYR_TILE_TAPS) { out->clear(); taps->clear(); return false; }
+        for (int x = R[l].nx0; x < R[l].nx1; x++) {
+          const int sx = xt[x].ofs, sx1 = std::min(sx + 1, sw - 1);
+          T[nT++] = PyrTileTap{(uint32_t)(sx - R[l - 1].nx0) | ((uint32_t)(sx1 - sx) << 16), (uint32_t)xt[x].coef};
+        }
+        for (int y = R[l].ny0; y < R[l].ny1; y++) {
+          const int sy0 = std::min(std::max(yt[y].ofs, 0), sh - 1), sy1 = std::min(std::max(yt[y].ofs + 1, 0), sh - 1);
+          T[nT++] = PyrTileTap{(uint32_t)(sy0 - R[l - 1].ny0) | ((uint32_t)(sy1 - sy0) << 16), (uint32_t)yt[y].coef};
+        }
+      }
+    }
+  const int buf0 = (maxPix0 + 63) & ~63, buf = (maxPix + 63) & ~63;
+  if (buf0 <= 0 || buf <= 0 || ORBX_PYR_TILE_TAPS * (int)sizeof(PyrTileTap) + buf0 + 2 * buf > 60 * 1024) { out->clear(); taps->clear(); return false; }
+  *nTiles = TX * TY;
+  *buf0Bytes = buf0;
+  *bufBytes = buf;
+  return true;
+}
+
 // Path-code tables of one level (OctLevel::tabOff): DivideNode routes x and y independently (cpp:656-668: pt.x < n1.UR.x, then
 // pt.y < n1.BR.y), so the 16 quadrant digits of a candidate are the OR of an x word and a y word, each a function of one
 // coordinate: root = x / hX (cpp:747), the root's rectangle (cpp:715-716), then mid = UL + ceil(extent / 2) (cpp:620-621) 16 times.
@@ -595,7 +680,7 @@ size_t buildOctLaunch(const orbx_ctx* c, const Geom& g, OctLaunch* out) {
 // matcher / staging buffers are not touched.
 void freeAll(orbx_ctx* ctx) {
   void* dev[] = {ctx->dPyr, ctx->dCand, ctx->dCandCount, ctx->dCellCount, ctx->dMaxN, ctx->dTab, ctx->dCells, ctx->dSel, ctx->dNsel,
-                 ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, ctx->dOctTab, ctx->dIn, ctx->dKps, ctx->dDesc};
+                 ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, ctx->dOctTab, ctx->dPyrTiles, ctx->dPyrTaps, ctx->dIn, ctx->dKps, ctx->dDesc};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   void* host[] = {ctx->hNsel, ctx->hFlags, ctx->hMaxN, ctx->hWide, ctx->hKpsPin, ctx->hDescPin};
@@ -603,7 +688,7 @@ void freeAll(orbx_ctx* ctx) {
     if (p) (void)hipHostFree(p);
   ctx->dPyr = nullptr; ctx->dCand = nullptr; ctx->dCandCount = nullptr; ctx->dCellCount = nullptr; ctx->dMaxN = nullptr;
   ctx->dTab = nullptr; ctx->dCells = nullptr; ctx->dSel = nullptr; ctx->dNsel = nullptr; ctx->dSelStage = nullptr; ctx->dNselLevel = nullptr;
-  ctx->dOctScratch = nullptr; ctx->dOctTab = nullptr; ctx->dIn = nullptr; ctx->dKps = nullptr; ctx->dDesc = nullptr;
+  ctx->dOctScratch = nullptr; ctx->dOctTab = nullptr; ctx->dPyrTiles = nullptr; ctx->dPyrTaps = nullptr; ctx->nPyrTiles = 0; ctx->dIn = nullptr; ctx->dKps = nullptr; ctx->dDesc = nullptr;
   ctx->hNsel = nullptr; ctx->hFlags = nullptr; ctx->hMaxN = nullptr; ctx->hWide = nullptr;
   ctx->hKpsPin = nullptr; ctx->hDescPin = nullptr; ctx->hKpsPinDev = nullptr; ctx->hDescPinDev = nullptr; ctx->pinFrames = 0;
   ctx->hNselDev = nullptr; ctx->hFlagsDev = nullptr; ctx->hMaxNDev = nullptr; ctx->hWideDev = nullptr;
@@ -674,6 +759,13 @@ int allocAll(orbx_ctx* ctx) {
   }
   ALLOC(ctx->dOctScratch, ctx->octScratchBytes);
   ALLOC(ctx->dOctTab, ctx->octTabEntries * 4);
+  {  // tiles of the largest geometry (no smaller frame has more)
+    int TX = 1, TY = 1;
+    if (g.nlevels > 1) pyrTileGrid(g, &TX, &TY);
+    ctx->pyrTileCap = (size_t)TX * TY;
+  }
+  ALLOC(ctx->dPyrTiles, ctx->pyrTileCap * g.nlevels * sizeof(PyrTileRect));
+  ALLOC(ctx->dPyrTaps, ctx->pyrTileCap * ORBX_PYR_TILE_TAPS * sizeof(PyrTileTap));
   ALLOC(ctx->dIn, ctx->inBytes);
   ALLOC(ctx->dKps, B * cap * sizeof(orbx_keypoint));
   ALLOC(ctx->dDesc, B * cap * 32);
@@ -769,6 +861,13 @@ int ensureGeometry(orbx_ctx* ctx, int w, int h, int stride0) {
   ctx->g = g;
   ctx->oct = oct;
   HIPCHK(hipMemcpyAsync(ctx->dOctTab, ctx->hOctTab.data(), ctx->hOctTab.size() * 4, hipMemcpyHostToDevice, ctx->st));
+  if (!buildPyrTiles(g, tab, &ctx->hPyrTiles, &ctx->hPyrTaps, &ctx->nPyrTiles, &ctx->pyrTileBuf0, &ctx->pyrTileBuf) ||
+      (size_t)ctx->nPyrTiles > ctx->pyrTileCap) {
+    ctx->nPyrTiles = 0;
+  } else {
+    HIPCHK(hipMemcpyAsync(ctx->dPyrTiles, ctx->hPyrTiles.data(), ctx->hPyrTiles.size() * sizeof(PyrTileRect), hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemcpyAsync(ctx->dPyrTaps, ctx->hPyrTaps.data(), ctx->hPyrTaps.size() * sizeof(PyrTileTap), hipMemcpyHostToDevice, ctx->st));
+  }
   ctx->hTab = tab;
   ctx->pyrInfo = pyrInfo;
   ctx->fastWaveOk = buildFastCells(g, &ctx->hCells);
@@ -872,6 +971,10 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   // whole pyramid in one launch (k_pyramid_bands) when every level meets the dword path's preconditions and the batch
   // is large enough to fill the device with (bands x frames) workgroups; otherwise one launch per level
   static const bool noBands = getenv("ORBX_NO_BANDS") != nullptr;  // diagnostics
+  static const bool noTiles = getenv("ORBX_NO_TILES") != nullptr;  // diagnostics: small batches launch the levels one by one
+  // k_pyramid_tiles up to this many frames per launch: measured at 640x480 (tools/batch_sweep.py), one frame 0.108 against 0.117 ms
+  // per synchronous call and 22.1 k against 18.3 k frames/s on four lanes, 8 frames level, 16 frames 133 k against 147 k on lanes
+  static const int tilesMax = getenv("ORBX_TILES_MAX_FRAMES") ? atoi(getenv("ORBX_TILES_MAX_FRAMES")) : 8;
   static const int bandsEnv = getenv("ORBX_PYR_BANDS") ? atoi(getenv("ORBX_PYR_BANDS")) : 0;  // diagnostics
   static const int bandsMin = getenv("ORBX_BANDS_MIN_FRAMES") ? atoi(getenv("ORBX_BANDS_MIN_FRAMES")) : 0;  // diagnostics
   // from 32 frames per stream, or from 8 when the frames are large (16 frames 1080p: 0.43 -> 0.30 ms; 16 frames 640x480 are
@@ -898,6 +1001,14 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
     tm.stop(1);
     ctx->lastLaunch[0] = 1;
     ctx->lastLaunch[1] = pb.nBands;
+  } else if (nl > 1 && ctx->nPyrTiles > 0 && !noTiles && n <= tilesMax) {
+    // small batches: one launch, a workgroup per tile of a frame, the level chain through LDS
+    StageTimer tm(ctx, ORBX_STAGE_PYRAMID, si, st);
+    HIPCHK(launch_pyramid_tiles(st, n, a.dImg0, a.frameStride0, ctx->dPyr, g, ctx->dPyrTiles, ctx->dPyrTaps, ctx->nPyrTiles,
+                                ctx->pyrTileBuf0, ctx->pyrTileBuf));
+    tm.stop(1);
+    ctx->lastLaunch[0] = 2;
+    ctx->lastLaunch[1] = ctx->nPyrTiles;
   } else {
     StageTimer tm(ctx, ORBX_STAGE_PYRAMID, si, st);
     for (int l = 1; l < nl; l++) {

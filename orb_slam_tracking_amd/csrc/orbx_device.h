@@ -107,6 +107,20 @@ struct ResizeTab {
   int32_t coef;   // c0 | c1 << 16 (Q11)
 };
 
+// k_pyramid_tiles: what tile t of a frame produces of level l -- the rectangle it owns (written to the pyramid) and the rectangle it
+// needs (owned pixels plus what its rectangles of the higher levels read), both in level-l pixel coordinates; level 0: the part of
+// the caller's image the tile stages (host: buildPyrTiles).  The tile's resize taps follow in one blob per tile (PyrTileTap):
+// per level 1 .. nlevels - 1 the x taps of the needed columns, then the y taps of the needed rows.
+struct PyrTileRect {
+  int16_t nx0, nx1, ny0, ny1;  // needed: computed into LDS
+  int16_t ox0, ox1, oy0, oy1;  // owned: also stored to the pyramid
+};
+struct PyrTileTap {
+  uint32_t pos;   // first source column (row) relative to the previous level's needed rectangle | (second - first) << 16
+  uint32_t coef;  // c0 | c1 << 16 (Q11), as ResizeTab
+};
+#define ORBX_PYR_TILE_TAPS 768  // taps of one tile over all levels (capacity of the blob and of its LDS copy)
+
 // k_pyramid_bands: rows [r0, r1) of level l that band b of a frame produces (host: computePyrBands)
 #define ORBX_PYR_BANDS_MAX 32
 struct PyrBands {

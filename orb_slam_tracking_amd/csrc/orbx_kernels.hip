@@ -110,6 +110,106 @@ __global__ __launch_bounds__(256) void k_resize_dw(const uint8_t* __restrict__ s
   *reinterpret_cast<uint32_t*>(dst + (long long)f * dstFrameStride + (long long)dy * dstride + dx0) = packed;
 }
 
+// The whole pyramid of a frame in one launch for SMALL batches (one frame per call is what the reference's Frame constructor
+// hands over, SlamTypes/Frame.cpp:58-60): seven per-level launches are a 26 us chain of 3.7 us kernels there.  A workgroup owns
+// one tile of the frame on every level; the chain level l <- level l - 1 (cpp:1660-1713) runs inside the workgroup through LDS:
+// it stages the part of the caller's image its level-1 rectangle reads and its resize taps (one blob per tile, positions already
+// relative to the source rectangle: buildPyrTiles), then computes, level by level, the rectangle its higher levels need (a halo of
+// a few pixels around what it owns), keeps it in LDS as the source of the next level, and stores the owned part to the pyramid.
+// Global memory is read once, at the start.  Same Q11 arithmetic as k_resize; neighbouring tiles compute their shared halo pixels
+// twice and get the same bytes.  LDS: taps | level-0 rectangle | two level buffers.
+__global__ __launch_bounds__(256) void k_pyramid_tiles(const uint8_t* __restrict__ img0, long long img0FrameStride,
+                                                       uint8_t* __restrict__ pyr, const Geom g, const PyrTileRect* __restrict__ rects,
+                                                       const PyrTileTap* __restrict__ taps, int buf0Bytes, int bufBytes) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t tileLds[];
+  PyrTileTap* T = reinterpret_cast<PyrTileTap*>(tileLds);
+  uint8_t* buf0 = tileLds + ORBX_PYR_TILE_TAPS * sizeof(PyrTileTap);
+  uint8_t* bufA = buf0 + buf0Bytes;
+  uint8_t* bufB = bufA + bufBytes;
+  const int f = blockIdx.y + g.frame0, t = blockIdx.x;
+  const PyrTileRect* __restrict__ R = rects + (size_t)t * g.nlevels;
+  {  // taps and the level-0 rectangle: the only reads from global memory, all in flight together
+    int nT = 0;
+    for (int l = 1; l < g.nlevels; l++) nT += (R[l].nx1 - R[l].nx0) + (R[l].ny1 - R[l].ny0);
+    const uint2* __restrict__ src = reinterpret_cast<const uint2*>(taps + (size_t)t * ORBX_PYR_TILE_TAPS);
+    uint2* dst = reinterpret_cast<uint2*>(T);
+    uint2 tv[ORBX_PYR_TILE_TAPS / 256];
+#pragma unroll
+    for (int q = 0; q < ORBX_PYR_TILE_TAPS / 256; q++) tv[q] = (int)threadIdx.x + q * 256 < nT ? src[threadIdx.x + q * 256] : make_uint2(0, 0);
+    const PyrTileRect R0 = R[0];
+    const int w0 = R0.nx1 - R0.nx0, n0 = w0 * (R0.ny1 - R0.ny0);
+    const uint32_t inv0 = ((1u << 20) + (uint32_t)w0 - 1) / (uint32_t)max(w0, 1);
+    const uint8_t* G0 = img0 + (long long)f * img0FrameStride + (long long)R0.ny0 * g.L[0].stride + R0.nx0;
+    for (int base = 0; base < n0; base += 8 * 256) {
+      uint8_t pv[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int idx = min(base + q * 256 + (int)threadIdx.x, n0 - 1);
+        const int y = (int)(((uint32_t)idx * inv0) >> 20), x = idx - y * w0;  // (exact: idx < 2^11 * 8, w0 < 512)
+        pv[q] = G0[(long long)y * g.L[0].stride + x];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        if (base + q * 256 + (int)threadIdx.x < n0) buf0[base + q * 256 + threadIdx.x] = pv[q];
+    }
+#pragma unroll
+    for (int q = 0; q < ORBX_PYR_TILE_TAPS / 256; q++)
+      if ((int)threadIdx.x + q * 256 < nT) dst[threadIdx.x + q * 256] = tv[q];
+  }
+  __syncthreads();
+  const uint8_t* srcL = buf0;
+  int ppitch = R[0].nx1 - R[0].nx0;
+  uint8_t* dstL = bufA;
+  int tapOff = 0;
+  for (int l = 1; l < g.nlevels; l++) {
+    const LevelGeom& D = g.L[l];
+    const PyrTileRect Rl = R[l];
+    const int nw = Rl.nx1 - Rl.nx0, nh = Rl.ny1 - Rl.ny0, npx = nw * nh;
+    const uint32_t inv = ((1u << 20) + (uint32_t)nw - 1) / (uint32_t)max(nw, 1);
+    const PyrTileTap* TX = T + tapOff;
+    const PyrTileTap* TY = TX + nw;
+    uint8_t* out = pyr + D.imgOff + (long long)f * D.frameStride;
+    for (int base = 0; base < npx; base += 4 * 256) {  // four pixels per thread in flight: each is a chain tap -> source pixels
+      int pi[4], pj[4];
+      PyrTileTap ex[4], ey[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int idx = min(base + q * 256 + (int)threadIdx.x, npx - 1);
+        pj[q] = (int)(((uint32_t)idx * inv) >> 20);
+        pi[q] = idx - pj[q] * nw;
+        ex[q] = TX[pi[q]];
+        ey[q] = TY[pj[q]];
+      }
+      int p00[4], p01[4], p10[4], p11[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint8_t* S0 = srcL + (int)(ey[q].pos & 0xffff) * ppitch + (int)(ex[q].pos & 0xffff);
+        const uint8_t* S1 = S0 + (int)(ey[q].pos >> 16) * ppitch;
+        const int d = (int)(ex[q].pos >> 16);
+        p00[q] = S0[0]; p01[q] = S0[d]; p10[q] = S1[0]; p11[q] = S1[d];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int a0 = ex[q].coef & 0xffff, a1 = ex[q].coef >> 16, b0 = ey[q].coef & 0xffff, b1 = ey[q].coef >> 16;
+        const int t0 = p00[q] * a0 + p01[q] * a1;
+        const int t1 = p10[q] * a0 + p11[q] * a1;
+        int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+        v = min(max(v, 0), 255);
+        if (base + q * 256 + (int)threadIdx.x < npx) {
+          dstL[pj[q] * nw + pi[q]] = (uint8_t)v;
+          const int x = Rl.nx0 + pi[q], y = Rl.ny0 + pj[q];
+          if (y >= Rl.oy0 && y < Rl.oy1 && x >= Rl.ox0 && x < Rl.ox1) out[(long long)y * D.stride + x] = (uint8_t)v;
+        }
+      }
+    }
+    __syncthreads();
+    tapOff += nw + nh;
+    ppitch = nw;
+    srcL = dstL;
+    dstL = (dstL == bufA) ? bufB : bufA;
+  }
+}
+
 typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t dot2u16(uint32_t a, uint32_t b, uint32_t c) {  // v_dot2_u32_u16
   return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, b), c, false);
@@ -2500,6 +2600,15 @@ hipError_t launch_undistort(hipStream_t st, int nFrames, const orbx_keypoint* in
   if (nFrames <= 0 || capacity <= 0) return hipSuccess;
   dim3 block(256, 1, 1), grid((capacity + 255) / 256, nFrames, 1);
   hipLaunchKernelGGL(k_undistort, grid, block, 0, st, in, nkp, capacity, c, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_pyramid_tiles(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, uint8_t* pyr,
+                                const Geom& g, const PyrTileRect* rects, const PyrTileTap* taps, int nTiles, int buf0Bytes,
+                                int bufBytes) {
+  const size_t lds = ORBX_PYR_TILE_TAPS * sizeof(PyrTileTap) + (size_t)buf0Bytes + 2 * (size_t)bufBytes;
+  hipLaunchKernelGGL(k_pyramid_tiles, dim3(nTiles, nFrames, 1), dim3(256, 1, 1), lds, st, img0, img0FrameStride, pyr, g, rects, taps,
+                     buf0Bytes, bufBytes);
   return hipGetLastError();
 }
 

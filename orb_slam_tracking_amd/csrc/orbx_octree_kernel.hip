@@ -104,7 +104,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   using KEY = typename std::conditional<K32, uint32_t, u64>::type;
   // LDS budget with 32-bit keys: NMAX 2048: 8 + 8 + 4 + 6 + 2 + 3 KB = 31.5 KB -> FIVE workgroups per CU
   constexpr int KEYW = K32 ? (NMAX / 2 < 1024 - MCAP ? 1024 - MCAP : NMAX / 2) : NMAX;  // u64 words of the key array
-  __shared__ u64 keysNodes[KEYW + MCAP];
+  __shared__ __attribute__((aligned(16))) u64 keysNodes[KEYW + MCAP];
   KEY* keys = reinterpret_cast<KEY*>(keysNodes);
   u64* nodes = keysNodes + KEYW;
   static_assert(MCAP * 8 >= NMAX * 4, "the candidate position list must fit into nodes[]");
@@ -209,12 +209,23 @@ __global__ __launch_bounds__(256) void k_sel_compact(const SelKp* __restrict__ s
   const int f = blockIdx.x + P.frame0;
   // per-level maxima of the units' candidate counts (k_octree_lds: maxN[frame * nlevels + level]) of this launch go to pinned
   // host memory; the counts are reset for the next launch (levels no LDS unit ran on report 0)
-  // (workgroup b takes the levels b, b + frames, ...: one count per thread and level at 256 frames)
-  if (maxN && (int)blockIdx.x < P.nlevels) {
+  // (small launches: the first workgroup, one count per thread; else workgroup l takes level l, one count per thread at 256 frames)
+  const int nUnits = (int)gridDim.x * P.nlevels;
+  if (maxN && (nUnits <= 256 ? blockIdx.x == 0 : (int)blockIdx.x < P.nlevels)) {
     __shared__ int red[ORBX_MAX_LEVELS];
     if (threadIdx.x < P.nlevels) red[threadIdx.x] = 0;
     __syncthreads();
-    for (int l = blockIdx.x; l < P.nlevels; l += gridDim.x) {
+    if (nUnits <= 256) {
+      if ((int)threadIdx.x < nUnits) {
+        const int idx = P.frame0 * P.nlevels + threadIdx.x;
+        const int v = maxN[idx];
+        maxN[idx] = 0;
+        if (v > 0) atomicMax(&red[threadIdx.x % P.nlevels], v);
+      }
+      __syncthreads();
+      if (threadIdx.x < P.nlevels) hostMaxN[threadIdx.x] = red[threadIdx.x];
+    } else {
+      const int l = blockIdx.x;
       int m = 0;
       for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
         const int idx = (P.frame0 + i) * P.nlevels + l;
@@ -224,10 +235,9 @@ __global__ __launch_bounds__(256) void k_sel_compact(const SelKp* __restrict__ s
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
       if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&red[l], m);
+      __syncthreads();
+      if (threadIdx.x == 0) hostMaxN[l] = red[l];
     }
-    __syncthreads();
-    if (threadIdx.x == 0)
-      for (int l = blockIdx.x; l < P.nlevels; l += gridDim.x) hostMaxN[l] = red[l];
   }
   __shared__ int off[ORBX_MAX_LEVELS + 1];
   if (threadIdx.x == 0) {

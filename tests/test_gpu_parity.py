@@ -352,13 +352,13 @@ def test_device_std_sort_replay(orbx, ext640, oracle):
     cases.append(np.stack([killer, np.zeros(n, int), np.arange(n)], 1))
     # n <= 512 runs the workgroup-parallel replay (closed-form partitions, breadth first): sizes around its limits, sorted /
     # reversed / constant inputs, few distinct keys, and the median-of-3 killer (depth budget -> per-range heapsort)
-    for n in (19, 31, 64, 200, 300, 400, 449, 511, 512):
+    for n in (19, 20, 31, 34, 64, 66, 128, 130, 200, 254, 255, 256, 300, 400, 449, 511, 512):
         for hi in (1, 2, 3, 9, 1000):
             cases.append(np.stack([rng.integers(2, 2 + hi, n), rng.integers(0, 6, n) * 16, np.arange(n)], 1))
         cases.append(np.stack([np.arange(n), np.zeros(n, int), np.arange(n)], 1))
         cases.append(np.stack([np.arange(n)[::-1], np.zeros(n, int), np.arange(n)], 1))
         cases.append(np.stack([np.full(n, 7), np.full(n, 3), np.arange(n)], 1))
-    for n in (256, 512):
+    for n in (64, 254, 256, 512):
         k = n // 2
         killer = np.zeros(n, int)
         for i in range(1, k + 1):
@@ -1119,4 +1119,41 @@ def test_opencv_variant_constants(orbx, oracle):
             e.set_opencv_variant(2, 0)
     finally:
         oracle.set_opencv_variant(0, 0)
+        e.close()
+
+
+@pytest.mark.parametrize("params", [(500, 1.2, 8, 20, 7), (300, 2.0, 4, 20, 7), (300, 1.05, 6, 20, 7), (400, 1.37, 5, 20, 7)])
+def test_tiled_pyramid_small_batches(orbx, oracle, params):
+    """Batches of up to 8 frames build the pyramid with k_pyramid_tiles (one launch, a workgroup per tile of a frame, the level chain
+    through LDS, every tile with a halo of the pixels its higher levels read): every level image equals the oracle's cv::resize chain
+    (Features/ORBextractor.cpp:1660-1713) for frame sizes with ragged tile grids, a scale of 2 and scales close to 1, a strided
+    caller image; 9 frames take one launch per level."""
+    import torch
+    from orb_slam_tracking_amd import synth
+    nlev, cap = params[2], params[0]
+    for (w, h, B, pad) in ((640, 480, 1, 0), (641, 479, 3, 0), (322, 243, 8, 0), (173, 131, 2, 0), (752, 480, 5, 16), (1280, 720, 1, 0), (640, 480, 9, 0)):
+        if min(w, h) / params[1] ** (nlev - 1) < 70:  # the smallest level must hold a FAST cell grid (ORBX_E_TOOSMALL otherwise)
+            continue
+        frames = synth.synth_frames(B, w, h, 6100 + w)
+        stride = w + pad
+        buf = np.zeros((B, h, stride), np.uint8)
+        buf[:, :, :w] = frames
+        oe = oracle.Extractor(*params)
+        e = orbx.ORBextractor(*params, max_width=w, max_height=h, max_batch=B)
+        d_img = torch.from_numpy(buf).cuda()
+        d_k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+        d_d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+        d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+        e.extract_batch_device(d_img, B, w, h, stride, stride * h, d_k, d_d, d_n, cap)
+        info = e.debug_last_launch()
+        assert info["pyramid_banded"] == (2 if B <= 8 else 0), (w, h, B, info)
+        n = d_n.cpu().numpy()
+        kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, cap)
+        dd = d_d.cpu().numpy().reshape(B, cap, 32)
+        for f in sorted({0, B // 2, B - 1}):
+            _, ko, do = oe(frames[f], cap=cap)
+            assert n[f] == len(ko), (w, h, f)
+            _same(kk[f, :n[f]], dd[f, :n[f]], ko, do)
+            for l in range(1, nlev):
+                assert np.array_equal(e.image_pyramid(l, f), oe.level_image(l)), (params, w, h, f, l)
         e.close()
