@@ -272,7 +272,7 @@ class ORBextractor:
         r = self._L.orbx_extract(self._h, _ptr(image), w, h, image.strides[0], int(vLappingArea[0]), int(vLappingArea[1]),
                                  _ptr(kps), _ptr(desc), self.capacity, ctypes.byref(n))
         self._check(r, "orbx_extract")
-        return r, kps[:n.value].copy(), desc[:n.value].copy()
+        return r, kps[:n.value], desc[:n.value]  # (views of this call's own arrays)
 
     def extract_batch(self, images: np.ndarray, vLappingArea: Sequence[int] = (0, 0)):
         """images: [B, H, W] uint8 (host).  Returns a list of (monoIndex, keypoints, descriptors) per frame."""

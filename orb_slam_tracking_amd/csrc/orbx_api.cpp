@@ -974,7 +974,9 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   static const bool noTiles = getenv("ORBX_NO_TILES") != nullptr;  // diagnostics: small batches launch the levels one by one
   // k_pyramid_tiles up to this many frames per launch: measured at 640x480 (tools/batch_sweep.py), one frame 0.108 against 0.117 ms
   // per synchronous call and 22.1 k against 18.3 k frames/s on four lanes, 8 frames level, 16 frames 133 k against 147 k on lanes
+  // (and up to eight VGA frames' worth of pixels: 8 frames of 3840x2160 take 0.81 ms in tiles, 0.41 ms level by level)
   static const int tilesMax = getenv("ORBX_TILES_MAX_FRAMES") ? atoi(getenv("ORBX_TILES_MAX_FRAMES")) : 8;
+  static const long long tilesMaxPx = getenv("ORBX_TILES_MAX_PIXELS") ? atoll(getenv("ORBX_TILES_MAX_PIXELS")) : 2500000ll;
   static const int bandsEnv = getenv("ORBX_PYR_BANDS") ? atoi(getenv("ORBX_PYR_BANDS")) : 0;  // diagnostics
   static const int bandsMin = getenv("ORBX_BANDS_MIN_FRAMES") ? atoi(getenv("ORBX_BANDS_MIN_FRAMES")) : 0;  // diagnostics
   // from 32 frames per stream, or from 8 when the frames are large (16 frames 1080p: 0.43 -> 0.30 ms; 16 frames 640x480 are
@@ -1001,7 +1003,7 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
     tm.stop(1);
     ctx->lastLaunch[0] = 1;
     ctx->lastLaunch[1] = pb.nBands;
-  } else if (nl > 1 && ctx->nPyrTiles > 0 && !noTiles && n <= tilesMax) {
+  } else if (nl > 1 && ctx->nPyrTiles > 0 && !noTiles && n <= tilesMax && (long long)n * g.L[0].w * g.L[0].h <= tilesMaxPx) {
     // small batches: one launch, a workgroup per tile of a frame, the level chain through LDS
     StageTimer tm(ctx, ORBX_STAGE_PYRAMID, si, st);
     HIPCHK(launch_pyramid_tiles(st, n, a.dImg0, a.frameStride0, ctx->dPyr, g, ctx->dPyrTiles, ctx->dPyrTaps, ctx->nPyrTiles,
