@@ -2648,8 +2648,14 @@ hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long lo
     ch = std::max(ch, std::min(g.L[l].hCell + 6, ORBX_CELL_MAX));
   }
   static const bool forceOld = getenv("ORBX_FAST_WG") != nullptr;  // diagnostics: the workgroup-per-cell kernel
-  if (usedWave) *usedWave = (waveOk && img0Aligned && cells && !forceOld) ? 1 : 0;
-  if (waveOk && img0Aligned && cells && !forceOld) {
+  // a lone wave needs 17 us for its cell; the four waves of k_fast's workgroup 8.8 us: the latter for the one-frame call, whose
+  // cells cannot fill the chip either way (measured up to eight 640x480 frames = 4616 cells per launch: tools/exp_fast_small.sh)
+  // (read per launch, not once: the parity tests run their small batches through both kernels)
+  const char* wgEnv = getenv("ORBX_FAST_WG_MAX_CELLS");
+  const int wgMaxCells = wgEnv ? atoi(wgEnv) : 5000;
+  const bool small = (long long)nFrames * g.nCellsTotal <= wgMaxCells;
+  if (usedWave) *usedWave = (waveOk && img0Aligned && cells && !forceOld && !small) ? 1 : 0;
+  if (waveOk && img0Aligned && cells && !forceOld && !small) {
     // one wave per workgroup, FW_CPW cells per wave; x size padded to whole rounds of 8 runs (XCD-aware order)
     const int groups = ((g.nCellsTotal + FW_CPW - 1) / FW_CPW + 8 * FW_XK - 1) / (8 * FW_XK) * (8 * FW_XK);
     const int ts = waveOk == 2 ? 48 : 64;  // tile / strength-map row stride: 48 when every cell image is <= 12 dwords wide

@@ -10,6 +10,16 @@ CANON = (1000, 1.2, 8, 20, 7)
 SHIPPED = (2000, 1.2, 8, 0, 0)
 
 
+@pytest.fixture(autouse=True, params=["fast_default", "fast_wave_per_cell"])
+def fast_kernel_choice(request, monkeypatch):
+    """Launches of up to 5000 FAST cells (eight 640x480 frames) take k_fast, a workgroup per cell; ORBX_FAST_WG_MAX_CELLS=0 (read per
+    launch) sends them through k_fast_wave, one wave per cell, like the large batches.  Every test of this module runs both ways."""
+    if request.param == "fast_wave_per_cell":
+        monkeypatch.setenv("ORBX_FAST_WG_MAX_CELLS", "0")
+    else:
+        monkeypatch.delenv("ORBX_FAST_WG_MAX_CELLS", raising=False)
+
+
 @pytest.fixture(scope="module")
 def ext640(orbx):
     e = orbx.ORBextractor(*CANON, max_width=752, max_height=480, max_batch=8)
