@@ -286,7 +286,7 @@ void appendPyrTables(const Geom& g, std::vector<ResizeTab>* tab, PyrTabInfo* inf
     const LevelGeom& S = g.L[l - 1];
     const LevelGeom& D = g.L[l];
     const int sw = S.w, sh = S.h, ng = (D.w + 3) / 4;
-    if (sw < 8 || D.h >= 32768 || D.w > 2048) info->ok = 0;
+    if (sw < 8 || D.h >= 32768 || D.w > 4096) info->ok = 0;  // (512 thread-columns of two 4-pixel groups: k_pyramid_bands' loadCols)
     if (tab->size() & 1) tab->push_back(ResizeTab{0, 0});
     info->xoff[l] = (int32_t)(tab->size() / 2);
     const int lim = (sw - 1) & ~3;  // last dword that holds a pixel of the row: never read beyond it
@@ -982,6 +982,7 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   // from 32 frames per stream, or from 8 when the frames are large (16 frames 1080p: 0.43 -> 0.30 ms; 16 frames 640x480 are
   // better off with the per-level launches: 0.252 vs 0.263 ms per 32-frame call)
   const bool enough = bandsMin > 0 ? n >= bandsMin : (n >= 32 || (n >= 8 && (long long)n * g.L[0].w * g.L[0].h >= (16ll << 20)));
+  // (four 3840x2160 frames in 32 thin bands: 0.46 ms against 0.39 ms level by level; eight on a lane: level with the resize launches)
   bool banded = nl > 1 && ctx->pyrInfo.ok && a.aligned0 && enough && !noBands;  // (dword loads: level 0 rows 4-byte aligned)
   PyrBands pb{};
   if (banded) {  // a band's rows of one level are staged by one pass of the workgroup: at most 256

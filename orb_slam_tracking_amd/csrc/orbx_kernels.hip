@@ -294,8 +294,8 @@ __global__ __launch_bounds__(PYR_T) void k_pyramid_bands(const uint8_t* __restri
     // A thread keeps its column(s): it owns G adjacent groups (8 or 4 output pixels) of one thread-column and walks down the
     // band's rows, so the column constants of its pixels are loaded ONCE per level and stay in registers.  rpp rows are
     // covered per pass; G (1 or 2) = whichever fills more of the 256 lanes with whole rows (134 groups: 67 thread-columns
-    // x 3 rows = 201 of 256 lanes).  (The host takes this kernel only when every level is at most 2048 pixels wide, i.e.
-    // at most 256 thread-columns of two groups.)
+    // x 3 rows = 201 of 256 lanes).  (The host takes this kernel only when every level >= 1 is at most 4096 pixels wide,
+    // i.e. at most PYR_T = 512 thread-columns of two groups: 3840x2160 frames qualify.)
     const int ngt2 = (ng + 1) >> 1;
     const int use1 = ng <= PYR_T ? ng * (PYR_T / ng) : 0, use2 = ngt2 * (PYR_T / ngt2);
     c.G = use2 > use1 ? 2 : 1;

@@ -1167,3 +1167,36 @@ def test_tiled_pyramid_small_batches(orbx, oracle, params):
             for l in range(1, nlev):
                 assert np.array_equal(e.image_pyramid(l, f), oe.level_image(l)), (params, w, h, f, l)
         e.close()
+
+
+def test_banded_pyramid_wide_levels(orbx, oracle):
+    """k_pyramid_bands on 3840x2160 frames (BASELINE config 5's size; levels 1 .. 7 up to 3200 pixels wide: 400 thread-columns of two
+    4-pixel groups, one row per pass): eight frames on a lane take it (the halves of a synchronous call, four frames, go level by
+    level); the extraction results (keypoints of all eight levels, descriptors) equal the oracle."""
+    import torch
+    from orb_slam_tracking_amd import synth
+    w, h, B, cap = 3840, 2160, 8, 8000
+    params = (8000, 1.2, 8, 20, 7)
+    frames = synth.synth_frames(B, w, h, 7300)
+    oe = oracle.Extractor(*params)
+    e = orbx.ORBextractor(*params, max_width=w, max_height=h, max_batch=B)
+    e.set_pipeline_depth(1)  # whole batches on one lane: a single launch of eight frames
+    d_img = torch.from_numpy(frames).cuda()
+    d_k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+    d_d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    d_m = torch.zeros((B // 2) * cap, dtype=torch.int32, device="cuda")
+    d_nm = torch.zeros(B // 2, dtype=torch.int32, device="cuda")
+    first = np.arange(0, B, 2, dtype=np.int32)
+    e.extract_match_batch_device_async(d_img, B, w, h, w, w * h, d_k, d_d, d_n, first, first + 1, (0, w, 0, h), d_m, d_nm, None, 100, 0.9, True, cap)
+    info = e.debug_last_launch()
+    e.wait()
+    assert info["pyramid_banded"] == 1 and info["frames_per_launch"] == B, info
+    n = d_n.cpu().numpy()
+    kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, cap)
+    dd = d_d.cpu().numpy().reshape(B, cap, 32)
+    for f in (0, B - 1):
+        _, ko, do = oe(frames[f], cap=cap)
+        assert n[f] == len(ko)
+        _same(kk[f, :n[f]], dd[f, :n[f]], ko, do)
+    e.close()
