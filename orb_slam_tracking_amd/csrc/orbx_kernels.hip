@@ -1545,6 +1545,22 @@ __device__ void matchWidePrep(const int pair, const int* __restrict__ pairFirst,
 }
 
 
+// Diagnostic build only (-DORBX_MJ_STAMPS): per workgroup of k_match_jacobi, s_memtime behind each phase (a barrier first);
+// tools/mj_stamps.py prints the shares.
+#ifdef ORBX_MJ_STAMPS
+__device__ unsigned long long g_mjStamps[1024 * 16];
+#define MJ_STAMP(k)                                                                                      \
+  do {                                                                                                   \
+    __syncthreads();                                                                                     \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_mjStamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+extern "C" int orbx_diag_mj_stamps(unsigned long long* out, int nWgs) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mjStamps), sizeof(unsigned long long) * 16 * (size_t)nWgs);
+}
+#else
+#define MJ_STAMP(k) do { } while (0)
+#endif
+
 // -------------------------------------------------------------------------------------------------
 // k_match_jacobi: one workgroup per frame pair, ONE THREAD PER QUERY.
 // The reference's query loop is sequential only through vMatchedDistance: query q sees, for every train t, the smallest
@@ -1604,6 +1620,7 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
   const float wInv = (float)ORBX_GRID_COLS / (float)(mp.b.max_x - mp.b.min_x);  // Frame.cpp:46-47
   const float hInv = (float)ORBX_GRID_ROWS / (float)(mp.b.max_y - mp.b.min_y);
   const float fminX = (float)mp.b.min_x, fminY = (float)mp.b.min_y;
+  MJ_STAMP(0);
   if (t == 0) { sNT = 0; sBase = 0; sOverflow = n2 > 65535 ? 1 : 0; sNm = 0; sBadDist = 0; sBadRatio = 0; sBadOri = 0; }
   if (t < HISTO_LENGTH) hist[t] = 0;
   __syncthreads();
@@ -1626,6 +1643,7 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
     }
   }
   __syncthreads();
+  MJ_STAMP(1);
   // ---- the q-th octave-0 keypoint of F1 in index order is query q ----
   float qx = 0, qy = 0, qang = 0;
   int qi = -1;
@@ -1652,6 +1670,7 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
     }
     __syncthreads();
   }
+  MJ_STAMP(2);
   const int nQ = sBase, nT = sNT;
   if (nQ > MJ_CAP || nT > MJ_CAP || sOverflow) {  // block-uniform: the pair goes to the wide path
     if (t == 0) { nmatchesOut[pair] = MATCH_PENDING; *hostWide = 1; }  // (mapped host memory: the batch needs the wide path)
@@ -1668,6 +1687,7 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
   __syncthreads();
   if (t < MJ_CAP) clCount[t] = 0;
   __syncthreads();
+  MJ_STAMP(3);
   // cell window of my query, Frame.cpp:167-177
   const float r = (float)mp.window;
   const int minCX = max(0, (int)floorf((qx - fminX - r) * wInv));
@@ -1677,12 +1697,17 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
   const bool hasWindow = q < nQ && !(minCX >= ORBX_GRID_COLS || maxCX < 0 || minCY >= ORBX_GRID_ROWS || maxCY < 0);
 
   // ---- candidate list of (my query, my part of the trains), built once: every train inside the window, with its
-  //      Hamming distance.  The order inside a list is irrelevant: the comparison key is a total order. ----
+  //      Hamming distance.  The order inside a list is irrelevant: the comparison key is a total order.
+  //      Two steps: the window test of every train of the part (all threads of a wave walk the same trains: LDS broadcasts)
+  //      leaves a 64-bit mask per thread; the distances are then computed for the set bits only.  (Testing and measuring
+  //      in one loop made every wave pay the 256-bit distance for every train some lane had in its window -- nearly all,
+  //      at 13 % useful lanes: 56 k of the kernel's 86 k cycles.) ----
+  static_assert(MJ_CAP / MJ_P <= 64, "one mask bit per train of a part");
   uint32_t* const myList = candList + (size_t)part * MJ_CP * MJ_CAP + q;
   int nCand = 0;
-  bool anyIn = false;
+  unsigned long long win = 0ull;  // bit i: train part + MJ_P * i lies in my query's window
   if (hasWindow) {
-    for (int e0 = part; e0 < nT; e0 += 4 * MJ_P) {  // four trains per step: 16 independent LDS broadcasts in flight
+    for (int e0 = part, s4 = 0; e0 < nT; e0 += 4 * MJ_P, s4 += 4) {  // four trains per step: 16 independent LDS broadcasts in flight
       int cx[4], cy[4];
       float tx[4], ty[4];
 #pragma unroll
@@ -1690,24 +1715,28 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
         const int ee = min(e0 + j * MJ_P, MJ_CAP - 1);
         cx[j] = tCx[ee]; cy[j] = tCy[ee]; tx[j] = tX[ee]; ty[j] = tY[ee];
       }
+      uint32_t nib = 0;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const int e = e0 + j * MJ_P;
-        if (e >= nT) break;
-        if (cx[j] < minCX || cx[j] > maxCX || cy[j] < minCY || cy[j] > maxCY) continue;
-        const float dx = tx[j] - qx, dy = ty[j] - qy;
-        if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
-        int dist = 0;
-#pragma unroll
-        for (int w = 0; w < 8; w++) dist += __popc(qd[w] ^ tDesc[w][e]);
-        anyIn = true;
-        if (dist >= mp.dmax) continue;  // can neither be accepted nor fail the ratio test of a nearer train (launch_match)
-        if (nCand < MJ_CP) myList[nCand * MJ_CAP] = ((uint32_t)dist << 16) | (uint32_t)e;
-        nCand++;
+        const bool in = (e0 + j * MJ_P) < nT && !(cx[j] < minCX || cx[j] > maxCX || cy[j] < minCY || cy[j] > maxCY) &&
+                        (fabsf(tx[j] - qx) < r && fabsf(ty[j] - qy) < r);
+        nib |= (uint32_t)in << j;
       }
+      win |= (unsigned long long)nib << s4;
     }
-    if (nCand > MJ_CP) sOverflow = 1;
   }
+  const bool anyIn = win != 0ull;
+  while (win) {
+    const int e = part + MJ_P * __builtin_ctzll(win);
+    win &= win - 1ull;
+    int dist = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) dist += __popc(qd[w] ^ tDesc[w][e]);
+    if (dist >= mp.dmax) continue;  // can neither be accepted nor fail the ratio test of a nearer train (launch_match)
+    if (nCand < MJ_CP) myList[nCand * MJ_CAP] = ((uint32_t)dist << 16) | (uint32_t)e;
+    nCand++;
+  }
+  if (nCand > MJ_CP) sOverflow = 1;
   pCnt[part][q] = (uint8_t)(min(nCand, 127) | (anyIn ? 0x80 : 0));  // bit 7: the part saw a train in the window
   if (t < nT) tOrd[t] = ((uint32_t)(tCx[t] * ORBX_GRID_ROWS + tCy[t]) << 20) | (uint32_t)tIdx[t];
   __syncthreads();
@@ -1716,6 +1745,7 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
     matchWidePrep<MJ_T>(pair, pairFirst, pairSecond, kps, nkp, mp, matches12, scratch, scratchStride, capl);
     return;
   }
+  MJ_STAMP(4);
   // a query has a candidate in its window iff some part listed one (vIndices2.empty() -> continue, ORBmatcher.cpp:46-47)
   bool hasCand = false;
 #pragma unroll
@@ -1724,7 +1754,13 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
   // (kept by the part-0 thread of the query)
   int outcome = 0, bestT = -1, bestD = 0;
   bool converged = false;
+#ifdef ORBX_MJ_STAMPS
+  int sweepsDone_ = 0;
+#endif
   for (int sweep = 0; sweep < MJ_SWEEPS; sweep++) {
+#ifdef ORBX_MJ_STAMPS
+    sweepsDone_ = sweep + 1;
+#endif
     // ---- every part scans its share of the query's candidates ----
     unsigned long long best = MATCH_NONE;  // dist << 32 | cell << 20 | train index
     int second = INF_DIST, bt = 0;
@@ -1808,6 +1844,10 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
     matchWidePrep<MJ_T>(pair, pairFirst, pairSecond, kps, nkp, mp, matches12, scratch, scratchStride, capl);
     return;
   }
+  MJ_STAMP(5);
+#ifdef ORBX_MJ_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 1024) g_mjStamps[blockIdx.x * 16 + 8] = (unsigned long long)sweepsDone_;
+#endif
   // ---- final bookkeeping from the converged outcomes (part-0 threads hold them; the others have outcome 0) ----
   if (t < MJ_CAP) lastQ[t] = -1;
   __syncthreads();
@@ -1853,6 +1893,7 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
     nmatchesOut[pair] = sNm;
     if (statsOut) { statsOut[pair * 3] = sBadDist; statsOut[pair * 3 + 1] = sBadRatio; statsOut[pair * 3 + 2] = sBadOri; }
   }
+  MJ_STAMP(6);
 }
 
 // -------------------------------------------------------------------------------------------------
