@@ -1590,8 +1590,9 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
                                                                int* __restrict__ scratch, long long scratchStride, int capl,
                                                                int* __restrict__ hostWide) {
   constexpr int MJ_T = MJ_CAP * MJ_P;
-  __shared__ float tX[MJ_CAP], tY[MJ_CAP], tAng[MJ_CAP];
-  __shared__ uint32_t tDesc[8][MJ_CAP];
+  __shared__ float2 tXY[MJ_CAP];
+  __shared__ float tAng[MJ_CAP];
+  __shared__ uint4 tDesc[MJ_CAP][2];  // a train's 256 bits: two 16-byte reads per distance
   __shared__ uint16_t tIdx[MJ_CAP];
   __shared__ uint8_t tCx[MJ_CAP], tCy[MJ_CAP];
   __shared__ int clCount[MJ_CAP], lastQ[MJ_CAP];
@@ -1602,7 +1603,8 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
   __shared__ uint32_t pAux[MJ_P][MJ_CAP];                // per part: second-best distance (0xffff = none) | best train slot << 16
   __shared__ uint8_t pCnt[MJ_P][MJ_CAP];                 // per part: candidates listed for the query
   __shared__ int hist[HISTO_LENGTH];
-  __shared__ int sNT, sBase, sChanged, sOverflow, sNm, sBadDist, sBadRatio, sBadOri, sKeep[3];
+  __shared__ int sChangedSw[MJ_SWEEPS];
+  __shared__ int sNT, sBase, sOverflow, sNm, sBadDist, sBadRatio, sBadOri, sKeep[3], sKeepV[3];
   __shared__ int wcnt[MJ_T / 64];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1622,22 +1624,36 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
   const float fminX = (float)mp.b.min_x, fminY = (float)mp.b.min_y;
   MJ_STAMP(0);
   if (t == 0) { sNT = 0; sBase = 0; sOverflow = n2 > 65535 ? 1 : 0; sNm = 0; sBadDist = 0; sBadRatio = 0; sBadOri = 0; }
+  if (t < 3) { sKeep[t] = -1; sKeepV[t] = 0; }
+  if (t < MJ_SWEEPS) sChangedSw[t] = 0;
   if (t < HISTO_LENGTH) hist[t] = 0;
   __syncthreads();
-  // ---- stage the grid-eligible octave-0 trains of F2 (slot order is irrelevant: ties are broken by cell and index) ----
+  // F1's keypoint t and its descriptor are requested now: their latency runs under the staging of F2's trains
+  orbx_keypoint pk1{};
+  uint32_t pd1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (t < n1) {
+    pk1 = k1[t];
+#pragma unroll
+    for (int w = 0; w < 8; w++) pd1[w] = d1[(long long)t * 8 + w];
+  }
+  // ---- stage the grid-eligible octave-0 trains of F2 (slot order is irrelevant: ties are broken by cell and index);
+  //      keypoint and descriptor are loaded together (one round trip, not two) ----
   for (int j0 = 0; j0 < n2; j0 += MJ_T) {
     const int j = j0 + t;
     if (j < n2) {
       const orbx_keypoint kp = k2[j];
+      uint32_t dw[8];
+#pragma unroll
+      for (int w = 0; w < 8; w++) dw[w] = d2[(long long)j * 8 + w];
       // Frame::PosInGrid (Frame.cpp:89-99) + the octave filter of GetFeaturesInArea (Frame.cpp:179,191)
       const int px = (int)roundf((kp.x - fminX) * wInv), py = (int)roundf((kp.y - fminY) * hInv);
       if (kp.octave == 0 && px >= 0 && px < ORBX_GRID_COLS && py >= 0 && py < ORBX_GRID_ROWS) {
         const int slot = atomicAdd(&sNT, 1);
         if (slot < MJ_CAP) {
-          tX[slot] = kp.x; tY[slot] = kp.y; tAng[slot] = kp.angle;
+          tXY[slot] = make_float2(kp.x, kp.y); tAng[slot] = kp.angle;
           tIdx[slot] = (uint16_t)j; tCx[slot] = (uint8_t)px; tCy[slot] = (uint8_t)py;
-#pragma unroll
-          for (int w = 0; w < 8; w++) tDesc[w][slot] = d2[(long long)j * 8 + w];
+          tDesc[slot][0] = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+          tDesc[slot][1] = make_uint4(dw[4], dw[5], dw[6], dw[7]);
         }
       }
     }
@@ -1648,11 +1664,26 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
   float qx = 0, qy = 0, qang = 0;
   int qi = -1;
   uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // the queries' data reach their threads through LDS (candList's space, free until the lists are built)
+  float* const sQx = reinterpret_cast<float*>(candList);
+  float* const sQy = sQx + MJ_CAP;
+  float* const sQa = sQy + MJ_CAP;
+  uint32_t* const sQd = reinterpret_cast<uint32_t*>(sQa + MJ_CAP);  // [8][MJ_CAP]
+  static_assert(MJ_P * MJ_CP >= 11, "the query staging area must fit into candList");
   for (int i0 = 0; i0 < n1; i0 += MJ_T) {
     const int i = i0 + t;
     bool ok = false;
+    orbx_keypoint kq = pk1;
+    uint32_t dq[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) dq[w] = pd1[w];
+    if (i0 > 0 && i < n1) {  // (more than MJ_T keypoints in F1: the later ones are loaded here)
+      kq = k1[i];
+#pragma unroll
+      for (int w = 0; w < 8; w++) dq[w] = d1[(long long)i * 8 + w];
+    }
     if (i < n1) {
-      ok = !(k1[i].octave > 0);  // ORBmatcher.cpp:38-39
+      ok = !(kq.octave > 0);  // ORBmatcher.cpp:38-39
       m12[i] = -1;
     }
     const unsigned long long bm = __ballot(ok);
@@ -1661,7 +1692,12 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
     int before = sBase;
     for (int w2 = 0; w2 < wave; w2++) before += wcnt[w2];
     const int pos = before + __popcll(bm & ((1ull << lane) - 1ull));
-    if (ok && pos < MJ_CAP) clCount[pos] = i;  // clCount is free until the sweeps start: F1 index of query `pos`
+    if (ok && pos < MJ_CAP) {
+      clCount[pos] = i;  // clCount is free until the sweeps start: F1 index of query `pos`
+      sQx[pos] = kq.x; sQy[pos] = kq.y; sQa[pos] = kq.angle;
+#pragma unroll
+      for (int w = 0; w < 8; w++) sQd[w * MJ_CAP + pos] = dq[w];
+    }
     __syncthreads();
     if (t == 0) {
       int tot = sBase;
@@ -1677,12 +1713,11 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
     matchWidePrep<MJ_T>(pair, pairFirst, pairSecond, kps, nkp, mp, matches12, scratch, scratchStride, capl);
     return;
   }
-  if (q < nQ) {  // every part loads its query
+  if (q < nQ) {  // every part takes its query
     qi = clCount[q];
-    const orbx_keypoint kp = k1[qi];
-    qx = kp.x; qy = kp.y; qang = kp.angle;
+    qx = sQx[q]; qy = sQy[q]; qang = sQa[q];
 #pragma unroll
-    for (int w = 0; w < 8; w++) qd[w] = d1[(long long)qi * 8 + w];
+    for (int w = 0; w < 8; w++) qd[w] = sQd[w * MJ_CAP + q];
   }
   __syncthreads();
   if (t < MJ_CAP) clCount[t] = 0;
@@ -1698,40 +1733,41 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
 
   // ---- candidate list of (my query, my part of the trains), built once: every train inside the window, with its
   //      Hamming distance.  The order inside a list is irrelevant: the comparison key is a total order.
-  //      Two steps: the window test of every train of the part (all threads of a wave walk the same trains: LDS broadcasts)
-  //      leaves a 64-bit mask per thread; the distances are then computed for the set bits only.  (Testing and measuring
-  //      in one loop made every wave pay the 256-bit distance for every train some lane had in its window -- nearly all,
-  //      at 13 % useful lanes: 56 k of the kernel's 86 k cycles.) ----
+  //      Two steps: the distance test |dx| < r && |dy| < r of every train of the part (all threads of a wave walk the same
+  //      trains: one 8-byte LDS broadcast and five vector instructions per train) leaves a 64-bit mask per thread; the cell
+  //      test of GetFeaturesInArea (Frame.cpp:167-177 -- it can only drop a train whose rounded cell lies outside the window's
+  //      cell range) and the 256-bit distance are then evaluated for the set bits only.  (All three in one loop made every
+  //      wave pay the distance for every train some lane had in its window -- nearly all, at 13 % useful lanes: 56 k of the
+  //      kernel's 86 k cycles; the cell test in the first loop still cost 25 k.) ----
   static_assert(MJ_CAP / MJ_P <= 64, "one mask bit per train of a part");
   uint32_t* const myList = candList + (size_t)part * MJ_CP * MJ_CAP + q;
   int nCand = 0;
-  unsigned long long win = 0ull;  // bit i: train part + MJ_P * i lies in my query's window
+  unsigned long long win = 0ull;  // bit i: train part + MJ_P * i passes the distance test of my query
   if (hasWindow) {
-    for (int e0 = part, s4 = 0; e0 < nT; e0 += 4 * MJ_P, s4 += 4) {  // four trains per step: 16 independent LDS broadcasts in flight
-      int cx[4], cy[4];
-      float tx[4], ty[4];
+    for (int e0 = part, s4 = 0; e0 < nT; e0 += 4 * MJ_P, s4 += 4) {  // four trains per step: their LDS broadcasts are in flight together
+      float2 txy[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int ee = min(e0 + j * MJ_P, MJ_CAP - 1);
-        cx[j] = tCx[ee]; cy[j] = tCy[ee]; tx[j] = tX[ee]; ty[j] = tY[ee];
-      }
+      for (int j = 0; j < 4; j++) txy[j] = tXY[min(e0 + j * MJ_P, MJ_CAP - 1)];
       uint32_t nib = 0;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const bool in = (e0 + j * MJ_P) < nT && !(cx[j] < minCX || cx[j] > maxCX || cy[j] < minCY || cy[j] > maxCY) &&
-                        (fabsf(tx[j] - qx) < r && fabsf(ty[j] - qy) < r);
+        const bool in = (e0 + j * MJ_P) < nT && (fabsf(txy[j].x - qx) < r && fabsf(txy[j].y - qy) < r);
         nib |= (uint32_t)in << j;
       }
       win |= (unsigned long long)nib << s4;
     }
   }
-  const bool anyIn = win != 0ull;
+  bool anyIn = false;
+  MJ_STAMP(7);
   while (win) {
     const int e = part + MJ_P * __builtin_ctzll(win);
     win &= win - 1ull;
-    int dist = 0;
-#pragma unroll
-    for (int w = 0; w < 8; w++) dist += __popc(qd[w] ^ tDesc[w][e]);
+    const int cx = tCx[e], cy = tCy[e];
+    if (cx < minCX || cx > maxCX || cy < minCY || cy > maxCY) continue;
+    anyIn = true;
+    const uint4 ta = tDesc[e][0], tb = tDesc[e][1];
+    const int dist = __popc(qd[0] ^ ta.x) + __popc(qd[1] ^ ta.y) + __popc(qd[2] ^ ta.z) + __popc(qd[3] ^ ta.w) +
+                     __popc(qd[4] ^ tb.x) + __popc(qd[5] ^ tb.y) + __popc(qd[6] ^ tb.z) + __popc(qd[7] ^ tb.w);
     if (dist >= mp.dmax) continue;  // can neither be accepted nor fail the ratio test of a nearer train (launch_match)
     if (nCand < MJ_CP) myList[nCand * MJ_CAP] = ((uint32_t)dist << 16) | (uint32_t)e;
     nCand++;
@@ -1825,12 +1861,12 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
       changed = nOutcome != outcome || nBestT != bestT || nBestD != bestD;
       outcome = nOutcome; bestT = nBestT; bestD = nBestD;
     }
-    if (t == 0) sChanged = 0;
-    __syncthreads();
-    if (changed) sChanged = 1;
+    // (one flag per sweep, cleared at the start of the kernel: no barrier to reset it; the claim counters are cleared here, behind
+    // the barrier that ended their last readers)
+    if (changed) sChangedSw[sweep] = 1;
     if (t < MJ_CAP) clCount[t] = 0;
     __syncthreads();
-    if (!sChanged) { converged = true; break; }
+    if (!sChangedSw[sweep]) { converged = true; break; }
     if (outcome == 3) {
       const int slot = atomicAdd(&clCount[bestT], 1);
       if (slot < MJ_K) { clQ[bestT][slot] = (uint16_t)q; clD[bestT][slot] = (uint16_t)bestD; }
@@ -1839,7 +1875,7 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
     __syncthreads();
     if (sOverflow) break;
   }
-  if (!converged) {  // block-uniform (sChanged / sOverflow are read after barriers)
+  if (!converged) {  // block-uniform (the sweep's flag / sOverflow are read after barriers)
     if (t == 0) { nmatchesOut[pair] = MATCH_PENDING; *hostWide = 1; }  // (mapped host memory: the batch needs the wide path)
     matchWidePrep<MJ_T>(pair, pairFirst, pairSecond, kps, nkp, mp, matches12, scratch, scratchStride, capl);
     return;
@@ -1868,21 +1904,26 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
   if (t < nT && lastQ[t] >= 0) atomicAdd(&sNm, 1);
   if (outcome == 3 && lastQ[bestT] == q) m12[qi] = (int)tIdx[bestT];
   if (mp.checkOri) {
-    if (t == 0) {  // ComputeThreeMaxima, ORBmatcher.cpp:152-183
-      int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    // ComputeThreeMaxima, ORBmatcher.cpp:152-183: its strict-greater cascade keeps the three largest bins by (size descending,
+    // index ascending) among the non-empty ones -- bin t's place is the number of bins that come before it in that order
+    if (t < HISTO_LENGTH) {
+      const int v = hist[t];
+      int place = 0;
       for (int i = 0; i < HISTO_LENGTH; i++) {
-        const int s = hist[i];
-        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-        else if (s > max3) { max3 = s; ind3 = i; }
+        const int o = hist[i];
+        place += (o > v) || (o == v && i < t);
       }
-      if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-      else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
-      sKeep[0] = ind1; sKeep[1] = ind2; sKeep[2] = ind3;
+      if (v > 0 && place < 3) { sKeep[place] = t; sKeepV[place] = v; }
     }
     __syncthreads();
+    int ind1 = sKeep[0], ind2 = sKeep[1], ind3 = sKeep[2];
+    {
+      const int max1 = sKeepV[0], max2 = sKeepV[1], max3 = sKeepV[2];
+      if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+      else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+    }
     // every accepted query sits in rotHist, also one whose match was stolen later (double decrement, :130-138)
-    if (bin >= 0 && bin != sKeep[0] && bin != sKeep[1] && bin != sKeep[2]) {
+    if (bin >= 0 && bin != ind1 && bin != ind2 && bin != ind3) {
       m12[qi] = -1;
       atomicSub(&sNm, 1);
       atomicAdd(&sBadOri, 1);

@@ -29,5 +29,6 @@ names = ["stage trains", "order queries", "load queries", "windows + lists", "sw
 dt = st[:, 1:7] - st[:, 0:6]
 tot = st[:, 6] - st[:, 0]
 print("workgroups %d, cycles per workgroup: mean %.0f; sweeps mean %.1f max %d" % (nw, tot.mean(), st[:, 8].mean(), st[:, 8].max()))
+print("  of the lists phase: window tests %.0f cycles, distances of the masked trains %.0f" % ((st[:, 7] - st[:, 3]).mean(), (st[:, 4] - st[:, 7]).mean()))
 for i, nmn in enumerate(names):
     print("  %-18s mean %8.0f cycles  %5.1f %%" % (nmn, dt[:, i].mean(), 100 * dt[:, i].sum() / tot.sum()))
