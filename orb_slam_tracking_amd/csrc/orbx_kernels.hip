@@ -2294,7 +2294,15 @@ __global__ __launch_bounds__(MW_T) void k_match_wide_resolve(const int* __restri
   __syncthreads();
   // outcome of a query: 0 = no candidate in the window, 1 = invalid by distance, 2 = invalid by ratio, 3 = accepted
   bool converged = false;
+  MJ_STAMP(0);
+#ifdef ORBX_MJ_STAMPS
+  int sweepsDone_ = 0;
+#endif
   for (int sweep = 0; sweep < MW_SWEEPS; sweep++) {
+#ifdef ORBX_MJ_STAMPS
+    sweepsDone_ = sweep + 1;
+    if (sweep == 1) MJ_STAMP(1);
+#endif
     bool changed = false;
 #pragma unroll
     for (int rr = 0; rr < MW_R; rr++) {
@@ -2410,6 +2418,10 @@ __global__ __launch_bounds__(MW_T) void k_match_wide_resolve(const int* __restri
       matchGeneral<MW_T>(pair, pairFirst, pairSecond, kps, desc, nkp, mp, matches12, nmatchesOut, statsOut, scratch, scratchStride);
     return;
   }
+  MJ_STAMP(2);
+#ifdef ORBX_MJ_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 1024) g_mjStamps[blockIdx.x * 16 + 8] = (unsigned long long)sweepsDone_;
+#endif
   // ---- final bookkeeping from the converged outcomes: a train belongs to its LAST claimant ----
   int* lastQ = head;
   for (int e = t; e < nT; e += MW_T) lastQ[e] = -1;
@@ -2474,6 +2486,7 @@ __global__ __launch_bounds__(MW_T) void k_match_wide_resolve(const int* __restri
     nmatchesOut[pair] = sNm;
     if (statsOut) { statsOut[pair * 3] = sBadDist; statsOut[pair * 3 + 1] = sBadRatio; statsOut[pair * 3 + 2] = sBadOri; }
   }
+  MJ_STAMP(3);
 }
 
 // =================================================================================================
