@@ -509,6 +509,7 @@ int octDepthBits(int height, float hX) {
 // (k_resize's taps: columns ofs .. ofs + 1 and rows ofs .. ofs + 1, clamped as there); level 0's rectangle is what level 1 reads of
 // the caller's image.  The taps of a tile go into one blob, positions relative to the source rectangle.  Returns false when a tile
 // would not fit the kernel's budgets (then the levels are launched one by one).
+constexpr long long kPyrTilesMaxPixels = 2500000ll;  // pixels per launch up to which k_pyramid_tiles is taken (issueExtract)
 void pyrTileGrid(const Geom& g, int* TX, int* TY) {
   *TX = std::max(1, (g.L[1].w + 35) / 36);
   *TY = std::max(1, (g.L[1].h + 27) / 28);
@@ -759,10 +760,10 @@ int allocAll(orbx_ctx* ctx) {
   }
   ALLOC(ctx->dOctScratch, ctx->octScratchBytes);
   ALLOC(ctx->dOctTab, ctx->octTabEntries * 4);
-  {  // tiles of the largest geometry (no smaller frame has more)
+  {  // tiles of the largest geometry (no smaller frame has more) -- or of the largest frame k_pyramid_tiles is taken for at all
     int TX = 1, TY = 1;
     if (g.nlevels > 1) pyrTileGrid(g, &TX, &TY);
-    ctx->pyrTileCap = (size_t)TX * TY;
+    ctx->pyrTileCap = std::min((size_t)TX * TY, (size_t)(kPyrTilesMaxPixels / (36 * 28) + 256));
   }
   ALLOC(ctx->dPyrTiles, ctx->pyrTileCap * g.nlevels * sizeof(PyrTileRect));
   ALLOC(ctx->dPyrTaps, ctx->pyrTileCap * ORBX_PYR_TILE_TAPS * sizeof(PyrTileTap));
@@ -861,7 +862,8 @@ int ensureGeometry(orbx_ctx* ctx, int w, int h, int stride0) {
   ctx->g = g;
   ctx->oct = oct;
   HIPCHK(hipMemcpyAsync(ctx->dOctTab, ctx->hOctTab.data(), ctx->hOctTab.size() * 4, hipMemcpyHostToDevice, ctx->st));
-  if (!buildPyrTiles(g, tab, &ctx->hPyrTiles, &ctx->hPyrTaps, &ctx->nPyrTiles, &ctx->pyrTileBuf0, &ctx->pyrTileBuf) ||
+  if ((long long)w * h > kPyrTilesMaxPixels ||  // (never taken for such a frame: no tables, no 6 KB of taps per tile)
+      !buildPyrTiles(g, tab, &ctx->hPyrTiles, &ctx->hPyrTaps, &ctx->nPyrTiles, &ctx->pyrTileBuf0, &ctx->pyrTileBuf) ||
       (size_t)ctx->nPyrTiles > ctx->pyrTileCap) {
     ctx->nPyrTiles = 0;
   } else {
@@ -976,7 +978,7 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   // per synchronous call and 22.1 k against 18.3 k frames/s on four lanes, 8 frames level, 16 frames 133 k against 147 k on lanes
   // (and up to eight VGA frames' worth of pixels: 8 frames of 3840x2160 take 0.81 ms in tiles, 0.41 ms level by level)
   static const int tilesMax = getenv("ORBX_TILES_MAX_FRAMES") ? atoi(getenv("ORBX_TILES_MAX_FRAMES")) : 8;
-  static const long long tilesMaxPx = getenv("ORBX_TILES_MAX_PIXELS") ? atoll(getenv("ORBX_TILES_MAX_PIXELS")) : 2500000ll;
+  static const long long tilesMaxPx = getenv("ORBX_TILES_MAX_PIXELS") ? std::min(atoll(getenv("ORBX_TILES_MAX_PIXELS")), kPyrTilesMaxPixels) : kPyrTilesMaxPixels;
   static const int bandsEnv = getenv("ORBX_PYR_BANDS") ? atoi(getenv("ORBX_PYR_BANDS")) : 0;  // diagnostics
   static const int bandsMin = getenv("ORBX_BANDS_MIN_FRAMES") ? atoi(getenv("ORBX_BANDS_MIN_FRAMES")) : 0;  // diagnostics
   // from 32 frames per stream, or from 8 when the frames are large (16 frames 1080p: 0.43 -> 0.30 ms; 16 frames 640x480 are
