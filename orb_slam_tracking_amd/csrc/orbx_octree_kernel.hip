@@ -180,9 +180,12 @@ __global__ __launch_bounds__(1024) void k_octree_global(const uint32_t* __restri
   // scratch of the workgroup-parallel std::sort replay for up to 2048 pending nodes (the level-0 quota of 1080p / 4000 features is
   // 869, of 4K / 8000 features 1737: the one-lane replay took 96 k cycles of such a unit)
   __shared__ uint32_t parScr[OCT_PAR_SCR_FOR(OCT_PAR_BIG)];
+  // a second set of the radix sort's 512 x 16 digit counters: a pass's scatter sweep counts the next pass's digits
+  __shared__ uint32_t radixCnt2[512 * (1024 / 64)];
+  static_assert(sizeof(radixCnt2) == OCT_GLOBAL_XCHG * sizeof(u64), "as many counters as the exchange buffer holds");
   const int level = blockIdx.y + level0, f = blockIdx.x + P.frame0;  // level-major dispatch, see launch_octree
   if (!all && nselLevel[f * P.nlevels + level] != -2) return;
-  t1024::octreeGlobalUnit(cand, cellCount, P, selStage, nselLevel, scratch, level, f, xchg, OCT_GLOBAL_XCHG, parScr, OCT_PAR_BIG);
+  t1024::octreeGlobalUnit(cand, cellCount, P, selStage, nselLevel, scratch, level, f, xchg, OCT_GLOBAL_XCHG, parScr, OCT_PAR_BIG, radixCnt2);
 }
 
 size_t octScratchBytes(int nMax, int qMax) {
