@@ -188,13 +188,14 @@ struct CamD {
 // list, the per-query candidate counts and MW_CP list entries per query, all for min(capacity, MW_CAP) queries / trains.
 constexpr int MW_CAP = 4096;  // octave-0 queries / eligible trains per pair the wide path takes
 constexpr int MW_CP = 128;    // candidates listed per query (a fuller window hands the pair to k_match)
+constexpr int MW_CXS = 80;    // behind the top rows and the queries' column order: start slot of every grid column's trains (65 used)
 constexpr int MW_TOPK = 4;   // per query, behind its list: the four best candidates by (distance, candidate order), sorted (k_match_wide_resolve)
-constexpr int MW_HDR = 16;    // [0] nQ, [1] nT, [2] 1 = too large for the wide path, [3] != 0 = a list overflowed, [4..7] bounding box of the eligible trains (float bits: min x, max x, min y, max y)
+constexpr int MW_HDR = 16;    // [0] nQ, [1] nT, [2] 1 = too large for the wide path, [3] != 0 = a list overflowed, [4..7] bounding box of the eligible trains (float bits: min x, max x, min y, max y), [8] 1 = trains stored by grid column (matchWidePrep)
 inline int matchWideCap(int capacity) { return capacity < MW_CAP ? capacity : MW_CAP; }
 inline long long matchScratchStride(int capacity) {
   const long long capl = matchWideCap(capacity);
   long long s = (long long)capacity * 4;
-  const long long wide = MW_HDR + capl * (4 + 1 + 1) + capl * (MW_CP + MW_TOPK);
+  const long long wide = MW_HDR + capl * (4 + 1 + 1) + capl * (MW_CP + MW_TOPK) + capl + MW_CXS;  // ... + query order by column + column starts
   if (s < wide) s = wide;
   return (s + 3) & ~3LL;  // the train records are uint4
 }

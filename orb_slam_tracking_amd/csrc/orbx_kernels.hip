@@ -1457,14 +1457,18 @@ __device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const 
 
 // matchWidePrep: first step of the wide path (see k_match_wide_lists / k_match_wide_resolve below), run by the workgroup
 // of k_match_jacobi that hands its pair on: ordered compaction of the octave-0 queries (F1 index) and of the eligible
-// trains (x, y, grid cell, cell << 20 | F2 index) into the pair's scratch, and matches12 = -1.  Every thread of the
-// workgroup must call it (it has barriers).
+// trains (x, y, grid cell, cell << 20 | F2 index) into the pair's scratch, and matches12 = -1.  The trains are stored by grid
+// column (a counting sort; the slot numbers are mere names: nothing downstream depends on their order), with the columns' start
+// slots behind them, and the queries get a second order by THEIR column (qPerm): k_match_wide_lists then gives a wave 64
+// queries of neighbouring columns and walks only the trains of the columns their windows reach -- a twelfth of them at
+// 3840x2160 with the 100-pixel window.  Every thread of the workgroup must call it (it has barriers).
 template <int T>
 __device__ void matchWidePrep(const int pair, const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
                               const orbx_keypoint* __restrict__ kps, const int* __restrict__ nkp, const MatchParams& mp,
                               int* __restrict__ matches12, int* __restrict__ scratch, long long scratchStride, int capl) {
   __shared__ int wq[T / 64], wt[T / 64];
   __shared__ int sBaseQ, sBaseT;
+  __shared__ int colT[ORBX_GRID_COLS + 1], colQ[ORBX_GRID_COLS + 1];  // per grid column: count, then start / fill position
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fa = pairFirst[pair], fb = pairSecond[pair];
   const int cap = mp.capacity;
@@ -1475,6 +1479,16 @@ __device__ void matchWidePrep(const int pair, const int* __restrict__ pairFirst,
   int* S = scratch + (long long)pair * scratchStride;
   uint4* trec = reinterpret_cast<uint4*>(S + MW_HDR);
   int* qIdx = S + MW_HDR + 4 * capl;
+  // staging (both regions are written by the later kernels only): the trains in index order, the queries' columns
+  uint4* tmpRec = reinterpret_cast<uint4*>(S + MW_HDR + 6 * capl);  // (the lists' space: MW_CP >= 4 rows)
+  int* tmpQc = S + MW_HDR + 5 * capl;                                 // (the counts' space)
+  int* qPerm = S + MW_HDR + (6 + MW_CP + MW_TOPK) * capl;
+  int* cxStart = qPerm + capl;
+  static_assert(MW_CP >= 4, "the train records are staged in the lists' space");
+  if (t <= ORBX_GRID_COLS) { colT[t] = 0; colQ[t] = 0; }
+  // (only when a window spans less than half of the grid's columns: a window that reaches most columns prunes nothing, and the
+  // brute-force configurations read the descriptors faster in index order -- header [8] tells k_match_wide_lists)
+  const bool byCol = 2.f * (float)mp.window * ((float)ORBX_GRID_COLS / (float)(mp.b.max_x - mp.b.min_x)) + 3.f < 0.5f * (float)ORBX_GRID_COLS;
   const float wInv = (float)ORBX_GRID_COLS / (float)(mp.b.max_x - mp.b.min_x);  // Frame.cpp:46-47
   const float hInv = (float)ORBX_GRID_ROWS / (float)(mp.b.max_y - mp.b.min_y);
   const float fminX = (float)mp.b.min_x, fminY = (float)mp.b.min_y;
@@ -1489,8 +1503,11 @@ __device__ void matchWidePrep(const int pair, const int* __restrict__ pairFirst,
     bool okQ = false, okT = false;
     float tx = 0.f, ty = 0.f;
     int px = 0, py = 0;
+    int qc = 0;
     if (i < n1) {
-      okQ = !(k1[i].octave > 0);  // ORBmatcher.cpp:38-39
+      const orbx_keypoint kq = k1[i];
+      okQ = !(kq.octave > 0);  // ORBmatcher.cpp:38-39
+      qc = min(max((int)floorf((kq.x - fminX) * wInv), 0), ORBX_GRID_COLS - 1);  // the query's own column (an ordering aid only)
       m12[i] = -1;
     }
     if (i < n2) {
@@ -1509,10 +1526,15 @@ __device__ void matchWidePrep(const int pair, const int* __restrict__ pairFirst,
     for (int w2 = 0; w2 < wave; w2++) { beforeQ += wq[w2]; beforeT += wt[w2]; }
     const unsigned long long below = (1ull << lane) - 1ull;
     const int posQ = beforeQ + __popcll(bq & below), posT = beforeT + __popcll(bt & below);
-    if (okQ && posQ < capl) qIdx[posQ] = i;
-    if (okT && posT < capl)
-      trec[posT] = make_uint4(__float_as_uint(tx), __float_as_uint(ty), (uint32_t)px | ((uint32_t)py << 8),
-                              ((uint32_t)(px * ORBX_GRID_ROWS + py) << 20) | (uint32_t)i);
+    if (okQ && posQ < capl) {
+      qIdx[posQ] = i;
+      if (byCol) { tmpQc[posQ] = qc; atomicAdd(&colQ[qc], 1); }
+    }
+    if (okT && posT < capl) {
+      (byCol ? tmpRec : trec)[posT] = make_uint4(__float_as_uint(tx), __float_as_uint(ty), (uint32_t)px | ((uint32_t)py << 8),
+                                                  ((uint32_t)(px * ORBX_GRID_ROWS + py) << 20) | (uint32_t)i);
+      if (byCol) atomicAdd(&colT[px], 1);
+    }
     __syncthreads();
     if (t == 0) {
       int tq = sBaseQ, tt = sBaseT;
@@ -1541,7 +1563,31 @@ __device__ void matchWidePrep(const int pair, const int* __restrict__ pairFirst,
     S[0] = sBaseQ; S[1] = sBaseT;
     S[2] = (sBaseQ > capl || sBaseT > capl || n2 > 0xfffff) ? 1 : 0;
     S[3] = 0;
+    S[8] = byCol ? 1 : 0;
   }
+  if (!byCol) return;  // (uniform)
+  // ---- counting sort by grid column: exclusive starts (one wave), then every staged record / query takes the next free slot of
+  //      its column ----
+  __syncthreads();  // (the staged records and the column counts are complete; global writes of this workgroup are visible to it)
+  if (wave == 0) {
+    const int cT = colT[lane], cQ = colQ[lane];
+    int iT = cT, iQ = cQ;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int uT = __shfl_up(iT, o), uQ = __shfl_up(iQ, o);
+      if (lane >= o) { iT += uT; iQ += uQ; }
+    }
+    colT[lane] = iT - cT; colQ[lane] = iQ - cQ;
+    cxStart[lane] = iT - cT;
+    if (lane == 63) { colT[64] = iT; cxStart[64] = iT; }
+  }
+  __syncthreads();
+  const int nTs = min(sBaseT, capl), nQs = min(sBaseQ, capl);
+  for (int e = t; e < nTs; e += T) {
+    const uint4 r = tmpRec[e];
+    trec[atomicAdd(&colT[r.z & 0xff], 1)] = r;
+  }
+  for (int q = t; q < nQs; q += T) qPerm[atomicAdd(&colQ[tmpQc[q]], 1)] = q;
 }
 
 
@@ -2166,8 +2212,11 @@ __global__ __launch_bounds__(256) void k_match_wide_lists(const int* __restrict_
   const float fminX = (float)mp.b.min_x, fminY = (float)mp.b.min_y;
   if (t < 64) { cnt[t] = 0; anyIn[t] = 0; }
   __syncthreads();
-  const int q = q0 + lane;
-  const bool valid = q < nQ;
+  // lane -> query through the queries' order by grid column (matchWidePrep): the 64 queries of a workgroup are neighbours
+  const bool valid = q0 + lane < nQ;
+  const bool byCol = S[8] != 0;  // (uniform) trains stored by grid column, queries handed out in column order
+  const int q = !valid ? 0 : (byCol ? (S + MW_HDR + (6 + MW_CP + MW_TOPK) * capl)[q0 + lane] : q0 + lane);
+  const int* cxStart = S + MW_HDR + (6 + MW_CP + MW_TOPK) * capl + capl;
   float qx = 0.f, qy = 0.f;
   uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (valid) {
@@ -2183,8 +2232,18 @@ __global__ __launch_bounds__(256) void k_match_wide_lists(const int* __restrict_
   const int maxCX = min(ORBX_GRID_COLS - 1, (int)ceilf((qx - fminX + r) * wInv));
   const int minCY = max(0, (int)floorf((qy - fminY - r) * hInv));
   const int maxCY = min(ORBX_GRID_ROWS - 1, (int)ceilf((qy - fminY + r) * hInv));
-  const int chunk = (nT + 3) >> 2;
-  const int e0 = part * chunk, e1 = min(nT, e0 + chunk);
+  // the trains lie sorted by grid column: only the columns some window of this workgroup's queries reaches are walked (the cell
+  // test of every query stays as it is), a quarter of that range per wave
+  int cLo = valid ? minCX : ORBX_GRID_COLS, cHi = valid ? maxCX : -1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { cLo = min(cLo, __shfl_xor(cLo, o)); cHi = max(cHi, __shfl_xor(cHi, o)); }
+  cLo = __builtin_amdgcn_readfirstlane(cLo);
+  cHi = __builtin_amdgcn_readfirstlane(cHi);
+  const int rLo = !byCol || cHi < cLo ? 0 : cxStart[min(max(cLo, 0), ORBX_GRID_COLS)];
+  const int rHi = !byCol ? nT : (cHi < cLo ? 0 : min(nT, cxStart[min(max(cHi + 1, 0), ORBX_GRID_COLS)]));
+  const int chunk = (rHi - rLo + 3) >> 2;
+  // (the walk's bounds in scalar registers: the train records and descriptors below must stay wave-uniform scalar loads)
+  const int e0 = __builtin_amdgcn_readfirstlane(rLo + part * chunk), e1 = __builtin_amdgcn_readfirstlane(min(rHi, rLo + part * chunk + chunk));
   bool any = false;
   // Brute force (BASELINE config 5's 2000 x 2000 match: the window covers the frame): when, for every query of this wave, the
   // cell range is the whole grid and both ends of the trains' bounding box lie within r -- float subtraction is monotonic, so
