@@ -1703,8 +1703,14 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
         }
       }
     }
+    __syncthreads();
+    if (sNT > MJ_CAP) break;  // (uniform) more eligible trains than this kernel takes: no need to look at the rest
   }
-  __syncthreads();
+  if (sNT > MJ_CAP || sOverflow) {  // block-uniform: the pair goes to the wide path (matchWidePrep starts from the keypoints again)
+    if (t == 0) { nmatchesOut[pair] = MATCH_PENDING; *hostWide = 1; }  // (mapped host memory: the batch needs the wide path)
+    matchWidePrep<MJ_T>(pair, pairFirst, pairSecond, kps, nkp, mp, matches12, scratch, scratchStride, capl);
+    return;
+  }
   MJ_STAMP(1);
   // ---- the q-th octave-0 keypoint of F1 in index order is query q ----
   float qx = 0, qy = 0, qang = 0;
