@@ -220,6 +220,10 @@ def test_wide_matcher_contention(orbx, ext640, oracle, monkeypatch):
         (1800, 150, 8, 4096, 1920, 1080, 0.9, 0.9, True, False),     # heavy contention: may overflow claims / lists
         (2400, 200, 6, 400, 1280, 720, 0.9, 0.9, True, False),       # near-duplicates inside the windows
         (4600, 4600, 40, 200, 3840, 2160, 1.0, 0.9, True, False),    # more than 4096 queries: the general kernel
+        # either side of the point where matchWidePrep stops storing the trains by grid column (a window that spans half the grid)
+        (2000, 2000, 20, 230, 1280, 720, 0.8, 0.9, True, True),
+        (2000, 2000, 20, 300, 1280, 720, 0.8, 0.9, True, True),
+        (1200, 400, 10, 60, 752, 480, 0.9, 0.9, True, False),        # narrow windows, near-duplicates, columns of a small frame
     )
     for (n, npro, flips, win, w, h, share, ratio, ori, must) in cases:
         protos = rng.integers(0, 256, (npro, 32), dtype=np.uint8)
