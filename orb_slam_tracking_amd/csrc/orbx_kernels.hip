@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
   *reinterpret_cast<uint32_t*>(dst + (long long)f * dstFrameStride + (long long)dy * dstride + dx0) = packed;
 }
 
+#define RESIZE_DW_ROWS 4  // output rows per thread of k_resize_dw
 // Same arithmetic, but the source taps of the 4 outputs are fetched as 3 aligned dwords per source row (the taps of
 // 4 consecutive outputs span at most 11 bytes from the aligned start when the scale is <= 2) instead of 8 byte loads,
 // and extracted with v_alignbyte.  Needs 4-byte aligned source rows; the launcher falls back to k_resize otherwise.
@@ -70,15 +71,13 @@ __global__ __launch_bounds__(256) void k_resize_dw(const uint8_t* __restrict__ s
                                                    int sstride, uint8_t* __restrict__ dst, long long dstFrameStride, int dw,
                                                    int dh, int dstride, const ResizeTab* __restrict__ xtab,
                                                    const ResizeTab* __restrict__ ytab) {
+  // RESIZE_DW_ROWS output rows per thread (rows dy, dy + 4, ...: a wave still covers whole row segments): the column taps -- 32
+  // bytes of table per thread, eight times the bytes it stores per row -- are loaded once, and the rows' source dwords are all
+  // in flight together
   const int f = blockIdx.z;
   const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-  const int dy = blockIdx.y * 4 + threadIdx.y;
-  if (dx0 >= dw || dy >= dh) return;
-  const ResizeTab ty = ytab[dy];
-  const int sy0 = min(max(ty.ofs, 0), sh - 1), sy1 = min(max(ty.ofs + 1, 0), sh - 1);
-  const int b0 = ty.coef & 0xffff, b1 = ty.coef >> 16;
-  const uint8_t* S0 = src + (long long)f * srcFrameStride + (long long)sy0 * sstride;
-  const uint8_t* S1 = src + (long long)f * srcFrameStride + (long long)sy1 * sstride;
+  const int dyBase = blockIdx.y * (4 * RESIZE_DW_ROWS) + threadIdx.y;
+  if (dx0 >= dw || dyBase >= dh) return;
   const uint4 tA = reinterpret_cast<const uint4*>(xtab + dx0)[0];  // entries dx0, dx0+1 (ofs, coef, ofs, coef)
   const uint4 tB = reinterpret_cast<const uint4*>(xtab + dx0)[1];  // entries dx0+2, dx0+3
   const int sxs[4] = {(int)tA.x, (int)tA.z, (int)tB.x, (int)tB.z};
@@ -86,28 +85,44 @@ __global__ __launch_bounds__(256) void k_resize_dw(const uint8_t* __restrict__ s
   const int base = sxs[0] & ~3;
   const int lim = (sw - 1) & ~3;  // last dword that holds a pixel of the row: never read beyond it
   const int o0 = base, o1 = min(base + 4, lim), o2 = min(base + 8, lim);
-  const uint32_t r0a = *reinterpret_cast<const uint32_t*>(S0 + o0), r0b = *reinterpret_cast<const uint32_t*>(S0 + o1),
-                 r0c = *reinterpret_cast<const uint32_t*>(S0 + o2);
-  const uint32_t r1a = *reinterpret_cast<const uint32_t*>(S1 + o0), r1b = *reinterpret_cast<const uint32_t*>(S1 + o1),
-                 r1c = *reinterpret_cast<const uint32_t*>(S1 + o2);
-  uint32_t packed = 0;
+  const uint8_t* S = src + (long long)f * srcFrameStride;
+  uint32_t r0a[RESIZE_DW_ROWS], r0b[RESIZE_DW_ROWS], r0c[RESIZE_DW_ROWS], r1a[RESIZE_DW_ROWS], r1b[RESIZE_DW_ROWS], r1c[RESIZE_DW_ROWS];
+  int b0[RESIZE_DW_ROWS], b1[RESIZE_DW_ROWS];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int k = sxs[i] - base;  // 0..10
-    const int sh8 = k & 3;
-    // 32-bit window starting at byte k: low byte = S[sx], next byte = S[sx+1] (a clamped or missing dword can only
-    // supply bytes beyond the last pixel, whose weight is 0)
-    const uint32_t lo0 = k < 4 ? r0a : (k < 8 ? r0b : r0c), hi0 = k < 4 ? r0b : r0c;
-    const uint32_t lo1 = k < 4 ? r1a : (k < 8 ? r1b : r1c), hi1 = k < 4 ? r1b : r1c;
-    const uint32_t w0 = __builtin_amdgcn_alignbyte(hi0, lo0, sh8), w1 = __builtin_amdgcn_alignbyte(hi1, lo1, sh8);
-    const int a0 = cfs[i] & 0xffff, a1 = cfs[i] >> 16;
-    const int t0 = (int)(w0 & 255) * a0 + (int)((w0 >> 8) & 255) * a1;
-    const int t1 = (int)(w1 & 255) * a0 + (int)((w1 >> 8) & 255) * a1;
-    int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
-    v = min(max(v, 0), 255);
-    packed |= (uint32_t)v << (8 * i);
+  for (int k = 0; k < RESIZE_DW_ROWS; k++) {
+    const int dy = min(dyBase + 4 * k, dh - 1);  // (a row beyond the image repeats the last one and is not stored)
+    const ResizeTab ty = ytab[dy];
+    const int sy0 = min(max(ty.ofs, 0), sh - 1), sy1 = min(max(ty.ofs + 1, 0), sh - 1);
+    b0[k] = ty.coef & 0xffff; b1[k] = ty.coef >> 16;
+    const uint8_t* S0 = S + (long long)sy0 * sstride;
+    const uint8_t* S1 = S + (long long)sy1 * sstride;
+    r0a[k] = *reinterpret_cast<const uint32_t*>(S0 + o0); r0b[k] = *reinterpret_cast<const uint32_t*>(S0 + o1);
+    r0c[k] = *reinterpret_cast<const uint32_t*>(S0 + o2);
+    r1a[k] = *reinterpret_cast<const uint32_t*>(S1 + o0); r1b[k] = *reinterpret_cast<const uint32_t*>(S1 + o1);
+    r1c[k] = *reinterpret_cast<const uint32_t*>(S1 + o2);
   }
-  *reinterpret_cast<uint32_t*>(dst + (long long)f * dstFrameStride + (long long)dy * dstride + dx0) = packed;
+#pragma unroll
+  for (int k = 0; k < RESIZE_DW_ROWS; k++) {
+    const int dy = dyBase + 4 * k;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int kk = sxs[i] - base;  // 0..10
+      const int sh8 = kk & 3;
+      // 32-bit window starting at byte kk: low byte = S[sx], next byte = S[sx+1] (a clamped or missing dword can only
+      // supply bytes beyond the last pixel, whose weight is 0)
+      const uint32_t lo0 = kk < 4 ? r0a[k] : (kk < 8 ? r0b[k] : r0c[k]), hi0 = kk < 4 ? r0b[k] : r0c[k];
+      const uint32_t lo1 = kk < 4 ? r1a[k] : (kk < 8 ? r1b[k] : r1c[k]), hi1 = kk < 4 ? r1b[k] : r1c[k];
+      const uint32_t w0 = __builtin_amdgcn_alignbyte(hi0, lo0, sh8), w1 = __builtin_amdgcn_alignbyte(hi1, lo1, sh8);
+      const int a0 = cfs[i] & 0xffff, a1 = cfs[i] >> 16;
+      const int t0 = (int)(w0 & 255) * a0 + (int)((w0 >> 8) & 255) * a1;
+      const int t1 = (int)(w1 & 255) * a0 + (int)((w1 >> 8) & 255) * a1;
+      int v = (((b0[k] * (t0 >> 4)) >> 16) + ((b1[k] * (t1 >> 4)) >> 16) + 2) >> 2;
+      v = min(max(v, 0), 255);
+      packed |= (uint32_t)v << (8 * i);
+    }
+    if (dy < dh) *reinterpret_cast<uint32_t*>(dst + (long long)f * dstFrameStride + (long long)dy * dstride + dx0) = packed;
+  }
 }
 
 // The whole pyramid of a frame in one launch for SMALL batches (one frame per call is what the reference's Frame constructor
@@ -2777,7 +2792,7 @@ hipError_t launch_resize(hipStream_t st, int nFrames, const uint8_t* src, long l
                          const ResizeTab* ytab, int dwordPath) {
   dim3 block(64, 4, 1), grid((dw + 255) / 256, (dh + 3) / 4, nFrames);
   if (dwordPath)
-    hipLaunchKernelGGL(k_resize_dw, grid, block, 0, st, src, srcFrameStride, sw, sh, sstride, dst, dstFrameStride, dw, dh,
+    hipLaunchKernelGGL(k_resize_dw, dim3(grid.x, (dh + 4 * RESIZE_DW_ROWS - 1) / (4 * RESIZE_DW_ROWS), nFrames), block, 0, st, src, srcFrameStride, sw, sh, sstride, dst, dstFrameStride, dw, dh,
                        dstride, xtab, ytab);
   else
     hipLaunchKernelGGL(k_resize, grid, block, 0, st, src, srcFrameStride, sw, sh, sstride, dst, dstFrameStride, dw, dh, dstride,
