@@ -347,6 +347,11 @@ int orbx_debug_sincos(orbx_ctx* ctx, const float* angle_deg, int n, float* cos_o
  * halves on two streams; [5] frames per kernel launch; [6] 1 = the wide matcher kernels went with the batch; [7] lane the batch
  * went to (1-based; 0 = the context itself) }. */
 int orbx_debug_last_launch(const orbx_ctx* ctx, int32_t* info8);
+/* Host only, no device needed: the quadtree path codes (root << 32 | 16 quadrant digits of ExtractorNode::DivideNode,
+ * Features/ORBextractor.cpp:617-676, 747) of n points (xs[i], ys[i]) of a width x height candidate region, from the per-level
+ * x / y tables the selection kernels look up and by walking the 16 splits per point; the two agree for every point. */
+int orbx_debug_path_codes(int width, int height, int n, const int32_t* xs, const int32_t* ys, uint64_t* from_tables,
+                          uint64_t* from_walk);
 
 #ifdef __cplusplus
 }

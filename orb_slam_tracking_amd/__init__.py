@@ -133,6 +133,7 @@ def lib() -> ctypes.CDLL:
     L.orbx_debug_std_sort.argtypes = [vp, vp, i32]
     L.orbx_debug_sincos.argtypes = [vp, vp, i32, vp, vp]
     L.orbx_debug_last_launch.argtypes = [vp, vp]
+    L.orbx_debug_path_codes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
     _LIB = L
     return L
 

@@ -2285,6 +2285,44 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
   return res[1];
 }
 
+// Host only (no device is touched): the path codes of n points of a width x height candidate region, once from the per-level
+// tables the selection kernels look up (octCodeTable: x and y digits separately) and once by walking DivideNode's 16 splits
+// for the point (cpp:617-676, 747) -- the two must agree for every point.  Codes: root << 32 | 16 quadrant digits.
+int orbx_debug_path_codes(int width, int height, int n, const int32_t* xs, const int32_t* ys, uint64_t* from_tables,
+                          uint64_t* from_walk) {
+  if (width <= 0 || height <= 0 || width > 4096 || height > 4096 || n < 0 || (n > 0 && (!xs || !ys || !from_tables || !from_walk)))
+    return ORBX_E_BADARG;
+  OctLevel O{};
+  O.width = width;
+  O.height = height;
+  O.nIni = (int)std::round((float)width / (float)height);  // cpp:706
+  if (O.nIni < 1 || O.nIni > 255) return ORBX_E_TOOSMALL;
+  O.hX = (float)width / (float)O.nIni;                      // cpp:709
+  O.tabW = width;
+  O.tabH = height;
+  std::vector<uint32_t> tab((size_t)2 * width + height + 2);
+  octCodeTable(O, tab.data());
+  for (int i = 0; i < n; i++) {
+    const int xi = xs[i], yi = ys[i];
+    if (xi < 0 || xi >= width || yi < 0 || yi >= height) return ORBX_E_BADARG;
+    from_tables[i] = ((uint64_t)tab[2 * (size_t)xi + 1] << 32) | (uint64_t)(tab[2 * (size_t)xi] | tab[2 * (size_t)width + yi]);
+    const float x = (float)xi, y = (float)yi;
+    int root = (int)(x / O.hX);
+    root = std::min(std::max(root, 0), O.nIni - 1);
+    int ulx = (int)(O.hX * (float)root), brx = (int)(O.hX * (float)(root + 1)), uly = 0, bry = height;
+    uint64_t code = (uint64_t)root;
+    for (int d = 0; d < 16; d++) {  // DivideNode: half = ceil(extent / 2); the point goes right / down unless it is < the middle
+      const int midX = ulx + ((brx - ulx + 1) >> 1), midY = uly + ((bry - uly + 1) >> 1);
+      const int qx = !(x < (float)midX), qy = !(y < (float)midY);
+      if (qx) ulx = midX; else brx = midX;
+      if (qy) uly = midY; else bry = midY;
+      code = (code << 2) | (uint64_t)(qy * 2 + qx);
+    }
+    from_walk[i] = code;
+  }
+  return ORBX_OK;
+}
+
 int orbx_debug_last_launch(const orbx_ctx* ctx, int32_t* info8) {
   if (!ctx || !info8) return ORBX_E_BADARG;
   for (int i = 0; i < 8; i++) info8[i] = ctx->lastLaunch[i];

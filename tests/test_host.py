@@ -133,6 +133,31 @@ def test_octree_edge_cases(orbx, oracle):
         assert np.array_equal(a, b)
 
 
+def test_path_code_tables_equal_the_divide_node_walk(orbx):
+    """The selection kernels take a candidate's quadtree path code from two per-level tables (x digits + root by x, y digits by y:
+    DivideNode routes the two coordinates independently, Features/ORBextractor.cpp:656-668).  Host-only hook, no device: for
+    real level geometries (nIni 1 and 2, non-integral hX), thin strips (nIni up to 10) and small regions the table code equals
+    the code of the 16-split walk for EVERY pixel, incl. the columns at the roots' boundaries (cpp:715-716, 747), and points
+    that differ anywhere differ in their codes (the code identifies the pixel)."""
+    L = orbx.lib()
+    rng = np.random.default_rng(3)
+    shapes = [(608, 448), (720, 448), (1888, 1048), (3808, 2128), (147, 102), (501, 167), (1000, 99), (97, 97), (35, 31),
+              (767, 256), (1535, 512), (4096, 409)]
+    for (W, H) in shapes:
+        if W * H <= 400000:
+            ys, xs = np.divmod(np.arange(W * H, dtype=np.int32), W)
+        else:  # large regions: every pixel of a random third of the rows
+            rows = np.sort(rng.choice(H, H // 3, replace=False)).astype(np.int32)
+            ys, xs = np.repeat(rows, W), np.tile(np.arange(W, dtype=np.int32), len(rows))
+        xs, ys = np.ascontiguousarray(xs, np.int32), np.ascontiguousarray(ys, np.int32)
+        a, b = np.zeros(len(xs), np.uint64), np.zeros(len(xs), np.uint64)
+        r = L.orbx_debug_path_codes(W, H, len(xs), xs.ctypes.data, ys.ctypes.data, a.ctypes.data, b.ctypes.data)
+        assert r == 0, (W, H, r)
+        assert np.array_equal(a, b), (W, H, np.nonzero(a != b)[0][:5])
+        assert len(np.unique(a)) == len(a), (W, H)  # 16 splits separate every pixel of a region up to 4096 wide
+    assert L.orbx_debug_path_codes(0, 10, 0, None, None, None, None) < 0
+
+
 def test_synth_is_deterministic():
     from orb_slam_tracking_amd import synth
     a, b = synth.synth_pair(160, 120, 5)
