@@ -2306,7 +2306,66 @@ __global__ __launch_bounds__(256) void k_match_wide_lists(const int* __restrict_
       }
     }
   };
-  if (allPass) scan(std::true_type{});
+  // Brute force: the wave stages the descriptors of 64 trains at a time in LDS (lane = train: two 16-byte loads, the next chunk's
+  // in flight while this one is matched) and every query lane then reads a train's 256 bits as two LDS broadcasts -- the scalar
+  // loads of the general path left the wave waiting for every group of four trains (0.55 of the issue cycles; 217 us per
+  // 64 x 2000^2 pairs).  The loop is the 16 xor / bcnt operations, a compare and, rarely, an append.
+  __shared__ uint4 stageD[4][2][64][2];  // [wave][buffer][train][half]
+  auto scanAllLds = [&]() {
+    uint4 (*st)[64][2] = stageD[part];
+    auto fetch = [&](const int eb, uint4& a, uint4& b) {
+      a = make_uint4(0, 0, 0, 0); b = a;
+      const int e = eb + lane;
+      if (e < e1) {
+        const uint32_t idx = reinterpret_cast<const uint32_t*>(trec + e)[3] & 0xfffffu;
+        const uint4* p = reinterpret_cast<const uint4*>(d2 + (long long)idx * 8);
+        a = p[0]; b = p[1];
+      }
+    };
+    uint4 na, nb;
+    fetch(e0, na, nb);
+    int cur = 0;
+    st[0][lane][0] = na; st[0][lane][1] = nb;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int eb = e0; eb < e1; eb += 64) {
+      const bool more = eb + 64 < e1;  // (uniform)
+      if (more) fetch(eb + 64, na, nb);
+      const int cntT = min(64, e1 - eb);
+      for (int j0 = 0; j0 < cntT; j0 += 4) {
+        uint4 b0[4], b1[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { b0[j] = st[cur][min(j0 + j, 63)][0]; b1[j] = st[cur][min(j0 + j, 63)][1]; }
+        // v_bcnt_u32_b32 adds its count to an accumulator: eight of them in a chain per train, the four trains' chains
+        // interleaved (the compiler builds a tree of counts and three-operand adds instead: three more 4-cycle instructions a train)
+        int dd[4] = {0, 0, 0, 0};
+#define ORBX_BCNT4(QW, F)                                                                                          \
+  _Pragma("unroll") for (int j = 0; j < 4; j++)                                                                    \
+      asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(dd[j]) : "v"(qd[QW] ^ F), "v"(dd[j]));
+        ORBX_BCNT4(0, b0[j].x) ORBX_BCNT4(1, b0[j].y) ORBX_BCNT4(2, b0[j].z) ORBX_BCNT4(3, b0[j].w)
+        ORBX_BCNT4(4, b1[j].x) ORBX_BCNT4(5, b1[j].y) ORBX_BCNT4(6, b1[j].z) ORBX_BCNT4(7, b1[j].w)
+#undef ORBX_BCNT4
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (j0 + j >= cntT) break;  // (uniform)
+          const int dist = dd[j];
+          if (valid && dist < mp.dmax) {  // a farther train can neither be accepted nor fail the ratio test of a nearer one
+            const int slot = atomicAdd(&cnt[lane], 1);
+            if (slot < MW_CP) lists[(size_t)slot * capl + q] = ((uint32_t)dist << 16) | (uint32_t)(eb + j0 + j);
+          }
+        }
+      }
+      if (valid && cntT > 0) any = true;
+      if (more) {
+        __builtin_amdgcn_wave_barrier();  // (this chunk's LDS reads are issued before the other buffer is overwritten: it is the other one)
+        st[cur ^ 1][lane][0] = na; st[cur ^ 1][lane][1] = nb;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        cur ^= 1;
+      }
+    }
+  };
+  if (allPass) scanAllLds();
   else scan(std::false_type{});
   if (any) anyIn[lane] = 1;  // vIndices2 of the query is not empty (the four parts may all store the same 1)
   __syncthreads();
