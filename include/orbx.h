@@ -329,7 +329,10 @@ int orbx_debug_candidates(orbx_ctx* ctx, int frame, int level, float* xyr, int c
  * variant 0 = LDS-resident kernel (redoing a unit that does not fit on global scratch), variant 1 = global-scratch kernel
  * only, variant 2 = the smaller LDS instance (<= 1024 candidates) and variant 3 = the smallest one (<= 512 candidates, quota
  * <= 128) that the pipeline picks per pyramid level when the previous batch allows; variant 4 = the 2048-candidate LDS instance
- * with 64-bit sort keys (variants 0, 2, 3 use 32-bit keys whenever the rectangle's quadtree path codes fit 21 bits). */
+ * with 64-bit sort keys (variants 0, 2, 3 use 32-bit keys whenever the rectangle's quadtree path codes fit 21 bits); variant 5 =
+ * the many-workgroup kernels the pipeline takes for levels with large units (a workgroup per bucket of keys sorts, one per unit
+ * does the tree arithmetic; a unit they cannot take falls to the global-scratch kernel), variant 6 = the same without that
+ * fallback (ORBX_E_CAPACITY instead). */
 int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min_x, int max_x, int min_y, int max_y,
                                  int n_features, int variant, float* out_xyr, int cap);
 /* The device's literal replay of libstdc++ std::sort with the reference's compareNodes (cpp:684-696, 912) on n

@@ -56,7 +56,8 @@ class _Stats(ctypes.Structure):
 
 
 def lib_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "liborbx.so")
+    # ORBX_LIB (diagnostics): an instrumented build of the same sources, e.g. `make -C csrc VARIANT=octstamps EXTRA=-DORBX_OCT_STAMPS`
+    return os.environ.get("ORBX_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "liborbx.so")
 
 
 _LIB = None

@@ -615,21 +615,88 @@ void octCodeTable(const OctLevel& O, uint32_t* out) {
     ty[yi] = s;
   }
 }
-// places the levels' tables one behind the other (tabW / tabH set by the caller); returns the dwords they take
+// Plan of the many-workgroup selection of large units (k_octree_buckets + k_octree_big) for one level: the bucket depth D0, the
+// number of buckets nIni * 4^D0 and the keys a bucket's slot holds.  (a) D0 never exceeds the depth the full passes are
+// GUARANTEED to reach: the pass loop of DistributeOctTree (cpp:781-895) stops at the first depth k where the list holds N nodes
+// or one more pass would overshoot (size + 3 nToExpand > N), and either needs 4 size_k > N with size_k <= nIni 4^k -- so
+// k >= min{k : nIni 4^(k+1) > N}, and every node the list ever holds lies inside one bucket (the device checks k again).
+// (b) a bucket covers at most ~16 k pixels, so that even a dense level (FAST threshold 0) stays below a slot's capacity; a
+// fuller bucket sends its unit to the one-workgroup kernel.  (c) the buckets' slots fill the unit's key array (nPad entries).
+void octBigPlan(OctLevel* O, int nMax) {
+  O->bigD0 = 0; O->bigBuckets = 0; O->bigCapB = 0;
+  if (O->nIni < 1 || O->quota < 1) return;
+  int kq = 0;
+  while ((long long)O->nIni << (2 * (kq + 1)) <= (long long)O->quota && kq < 8) kq++;
+  const double rootArea = (double)std::ceil(O->hX) * (double)O->height;
+  int dArea = 0;
+  while (rootArea / (double)(1ll << (2 * dArea)) > 16384.0 && dArea < 8) dArea++;
+  int d0 = std::min(kq, dArea);
+  while (d0 > 0 && ((long long)O->nIni << (2 * d0)) > ORBX_OCTB_MAX_BUCKETS) d0--;
+  const long long nb = (long long)O->nIni << (2 * d0);
+  if (nb > ORBX_OCTB_MAX_BUCKETS) return;
+  long long nPad = 1024;
+  while (nPad < nMax) nPad <<= 1;
+  int cap = ORBX_OCTB_CAP;
+  while (cap > 0 && (long long)cap * nb > nPad) cap >>= 1;
+  if (cap < 256) return;
+  O->bigD0 = d0; O->bigBuckets = (int32_t)nb; O->bigCapB = cap;
+}
+inline size_t octBigTabDwords(const OctLevel& O) {
+  return O.bigBuckets > 0 ? ((size_t)O.nIni << O.bigD0) + 1 + ((size_t)1 << O.bigD0) + 1 : 0;
+}
+// places the levels' tables one behind the other (tabW / tabH and the big plan set by the caller); returns the dwords they take
 size_t octTabLayout(OctLaunch* P) {
   size_t off = 0;
   for (int l = 0; l < P->nlevels; l++) {
     OctLevel& O = P->lev[l];
     O.tabOff = (int32_t)off;
     off += (2 * (size_t)O.tabW + (size_t)O.tabH + 1) & ~(size_t)1;  // (the x pairs are read as 8-byte words)
+    O.bigTabOff = (int32_t)off;
+    off += (octBigTabDwords(O) + 1) & ~(size_t)1;
   }
   return off;
 }
-void octCodeTables(const OctLaunch& P, std::vector<uint32_t>* out) {
+// The buckets' coordinate intervals (OctLevel::bigTabOff): a key's top D0 x digits (and its root) grow with x, its top D0 y
+// digits with y, so every prefix owns an interval of columns / rows; xs[(root << D0 | x prefix)] = its first column, one more
+// entry = the end; ys likewise.  k_octree_buckets reads only the FAST cells that overlap its bucket's rectangle.  Returns false
+// when a prefix sequence is not monotonic (it always is; the level then simply keeps the one-workgroup kernel).
+bool octBigTable(const OctLevel& O, const uint32_t* codeTab, uint32_t* out) {
+  const int d0 = O.bigD0, nx = O.nIni << d0, ny = 1 << d0;
+  auto topBits = [&](uint32_t s, int odd) {  // the digits of depths 1 .. d0: bit 2 (16 - d) + odd - 2 ... of the digit word
+    uint32_t v = 0;
+    for (int d = 1; d <= d0; d++) v = (v << 1) | ((s >> (2 * (16 - d) + odd)) & 1u);
+    return v;
+  };
+  std::vector<int> first((size_t)std::max(nx, ny) + 1);
+  auto fill = [&](int n, int count, auto keyOf, uint32_t* dst) {
+    for (int i = 0; i <= n; i++) first[i] = -1;
+    int prev = -1;
+    for (int v = 0; v < count; v++) {
+      const int key = keyOf(v);
+      if (key < prev || key >= n) return false;
+      if (first[key] < 0) first[key] = v;
+      prev = key;
+    }
+    int nxt = count;
+    for (int i = n; i >= 0; i--) {
+      if (i < n && first[i] >= 0) nxt = first[i];
+      dst[i] = (uint32_t)(i == n ? count : nxt);
+    }
+    return true;
+  };
+  if (!fill(nx, O.width, [&](int x) { return (int)((codeTab[2 * (size_t)x + 1] << d0) | topBits(codeTab[2 * (size_t)x], 0)); }, out)) return false;
+  const uint32_t* ty = codeTab + 2 * (size_t)O.tabW;
+  return fill(ny, O.height, [&](int y) { return (int)topBits(ty[y], 1); }, out + nx + 1);
+}
+void octCodeTables(OctLaunch* P, std::vector<uint32_t>* out) {
   size_t total = 0;
-  for (int l = 0; l < P.nlevels; l++) total = std::max(total, (size_t)P.lev[l].tabOff + 2 * (size_t)P.lev[l].tabW + (size_t)P.lev[l].tabH + 1);
+  for (int l = 0; l < P->nlevels; l++) total = std::max(total, (size_t)P->lev[l].bigTabOff + octBigTabDwords(P->lev[l]) + 1);
   out->assign(total, 0u);
-  for (int l = 0; l < P.nlevels; l++) octCodeTable(P.lev[l], out->data() + P.lev[l].tabOff);
+  for (int l = 0; l < P->nlevels; l++) {
+    OctLevel& O = P->lev[l];
+    octCodeTable(O, out->data() + O.tabOff);
+    if (O.bigBuckets > 0 && !octBigTable(O, out->data() + O.tabOff, out->data() + O.bigTabOff)) O.bigBuckets = 0;
+  }
 }
 
 // launch constants of the quadtree selection stage; returns the bytes of global scratch it needs
@@ -668,6 +735,7 @@ size_t buildOctLaunch(const orbx_ctx* c, const Geom& g, OctLaunch* out) {
     P.scrStride[l] = (int64_t)octScratchBytes(P.scrNMax[l], std::max(L.quota, O.nIni));  // = octreeGlobalUnit's qMax
     P.scrOff[l] = scr;
     scr += P.scrStride[l] * c->maxB;
+    if (O.nCells < 65536) octBigPlan(&O, P.scrNMax[l]);  // (a bucket's scores carry the FAST cell index in 16 bits)
   }
   P.nCellsTotal = g.nCellsTotal;
   octTabLayout(&P);
@@ -754,7 +822,8 @@ int allocAll(orbx_ctx* ctx) {
   {
     OctLaunch oct;
     ctx->octScratchBytes = buildOctLaunch(ctx, g, &oct) + 4096;
-    ctx->octTabEntries = octTabLayout(&oct) + 64;  // (no level of a smaller frame is larger than the same level of the largest one)
+    // (no level of a smaller frame is larger than the same level of the largest one; its bucket tables may be: bounded by the most buckets)
+    ctx->octTabEntries = octTabLayout(&oct) + 64 + (size_t)ctx->p.nlevels * (ORBX_OCTB_MAX_BUCKETS + 64);
     ctx->maxQuota = 0;
     for (int q : ctx->quota) ctx->maxQuota = std::max(ctx->maxQuota, q);
   }
@@ -854,7 +923,7 @@ int ensureGeometry(orbx_ctx* ctx, int w, int h, int stride0) {
     return ORBX_E_BADARG;
   }
   oct.codeTab = ctx->dOctTab;  // (growTo may have replaced the buffer since buildOctLaunch read the pointer: it did not, but keep one source)
-  octCodeTables(oct, &ctx->hOctTab);
+  octCodeTables(&oct, &ctx->hOctTab);
   if (ctx->hOctTab.size() > ctx->octTabEntries) {
     ctx->err = "internal: geometry exceeds the buffers sized at orbx_create";
     return ORBX_E_BADARG;
@@ -2210,7 +2279,9 @@ extern "C" {
 // relative to (min_x, min_y) in [0, 4095], integer responses in [0, 255].  variant 0 = LDS kernel (falls through to
 // the global-scratch kernel when it cannot take the unit), 1 = global-scratch kernel only, 2 / 3 = the 1024- / 512-candidate
 // LDS instances (a unit that does not fit is redone by the same workgroup on global scratch), 4 = the 2048-candidate LDS instance
-// with 64-bit sort keys (the others take 32-bit keys whenever the rectangle's path codes fit 21 bits).
+// with 64-bit sort keys (the others take 32-bit keys whenever the rectangle's path codes fit 21 bits); 5 = the many-workgroup
+// kernels of large units (k_octree_buckets + k_octree_big, k_octree_global behind them for a unit they hand on), 6 = those two
+// alone (ORBX_E_CAPACITY when they hand the unit on).
 int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min_x, int max_x, int min_y, int max_y,
                                  int n_features, int variant, float* out_xyr, int cap) {
   if (!ctx || n < 0 || (n > 0 && !xyr) || max_x <= min_x || max_y <= min_y || n_features < 0 || n > ORBX_OCT_MAX_CAND)
@@ -2233,7 +2304,9 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
   O.cellBase = 0; O.nCells = 1; O.segCap = alignUp(std::max(n, 1), 4);  // all candidates in the segment of one cell
   P.nCellsTotal = 1;
   P.candCap[0] = std::max(n, 1);
-  P.scrNMax[0] = std::max(n, 1);
+  // (the pipeline sizes a unit's scratch for the level's worst case; here: eight times the candidates at hand, so that the
+  // buckets of the many-workgroup kernels get slots with the same kind of headroom)
+  P.scrNMax[0] = std::min(std::max(8 * n, 16384), ORBX_OCT_MAX_CAND);
   P.scrStride[0] = (int64_t)octScratchBytes(P.scrNMax[0], std::max(n_features, O.nIni));  // = octreeGlobalUnit's qMax
   std::vector<uint32_t> packed((size_t)alignUp(std::max(n, 1), 4));
   for (int i = 0; i < n; i++) {
@@ -2241,9 +2314,12 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
     if (x < 0 || x > 4095 || y < 0 || y > 4095 || r < 0 || r > 255) return ORBX_E_BADARG;
     packed[i] = packCand(x, y, r);
   }
+  O.tabW = std::max(O.tabW, O.width);  // (the bucket tables of the many-workgroup path walk the region's own columns / rows)
+  O.tabH = std::max(O.tabH, O.height);
+  octBigPlan(&O, P.scrNMax[0]);
   octTabLayout(&P);
   std::vector<uint32_t> codeTab;
-  octCodeTables(P, &codeTab);
+  octCodeTables(&P, &codeTab);
   uint32_t* dC = nullptr;
   uint32_t* dT = nullptr;
   int* dI = nullptr;
@@ -2263,7 +2339,8 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
     int hi[2] = {n, -7};
     HIPCHK(hipMemcpyAsync(dI, hi, sizeof hi, hipMemcpyHostToDevice, ctx->st));
     HIPCHK(launch_octree(ctx->st, 1, dC, dI, P, dS, dI + 1, dScr, nullptr, nullptr,
-                         variant == 1 ? -1 : variant == 2 ? 1024 : variant == 3 ? 512 : variant == 4 ? (2048 | 0x10000) : 0, nullptr));
+                         variant == 1 ? -1 : variant == 2 ? 1024 : variant == 3 ? 512 : variant == 4 ? (2048 | 0x10000) : variant == 5 ? -2 :
+                         variant == 6 ? -3 : 0, nullptr));
     HIPCHK(hipMemcpyAsync(res, dI, sizeof res, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(sel.data(), dS, sel.size() * sizeof(SelKp), hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));

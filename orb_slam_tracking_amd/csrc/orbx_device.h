@@ -85,7 +85,17 @@ struct OctLevel {
   int32_t tabOff, tabW, tabH;  // the level's path-code tables inside OctLaunch::codeTab (dword offset, even): tabW pairs
                            // {x digits of the 16 DivideNode splits at bit 2 (15 - d), root} by x, then tabH words of y digits
                            // (bit 2 (15 - d) + 1) by y (octCodeTable on the host); tabW >= width, tabH >= height
+  // Large units on many workgroups (k_octree_buckets + k_octree_big): the level's keys are cut into nIni * 4^bigD0 BUCKETS, one
+  // per tree node of depth bigD0 (0 = not usable for this level).  bigD0 never exceeds the depth the quota guarantees the full
+  // passes to reach (octBigPlan), so no list node ever spans two buckets.  A bucket's keys are sorted in LDS by one workgroup
+  // and land in the bucket's own slot of bigCapB entries of the unit's key / score / divergence arrays.
+  int32_t bigD0, bigBuckets, bigCapB;
+  int32_t bigTabOff;       // dword offset in codeTab: first x of every (root, top bigD0 x digits) prefix [nIni << bigD0, + 1 end],
+                           // then first y of every top-bigD0-y-digits prefix [(1 << bigD0) + 1]
 };
+#define ORBX_OCTB_CAP 2048        // keys of one bucket (LDS sort of k_octree_buckets)
+#define ORBX_OCTB_MAX_BUCKETS 1024
+#define ORBX_OCTB_INFO 40         // ints of a bucket's record: count, first / last inner divergence, overflow, 18 + 18 histogram bins
 
 struct OctLaunch {
   OctLevel lev[ORBX_MAX_LEVELS];

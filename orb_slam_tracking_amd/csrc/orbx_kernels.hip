@@ -1495,11 +1495,11 @@ __device__ void matchWidePrep(const int pair, const int* __restrict__ pairFirst,
   uint4* trec = reinterpret_cast<uint4*>(S + MW_HDR);
   int* qIdx = S + MW_HDR + 4 * capl;
   // staging (both regions are written by the later kernels only): the trains in index order, the queries' columns
-  uint4* tmpRec = reinterpret_cast<uint4*>(S + MW_HDR + 6 * capl);  // (the lists' space: MW_CP >= 4 rows)
+  uint4* tmpRec = reinterpret_cast<uint4*>(S + MW_HDR + ((6 * capl + 3) & ~3));  // (the lists' space: MW_CP >= 5 rows; 16-byte aligned also with an odd capacity)
   int* tmpQc = S + MW_HDR + 5 * capl;                                 // (the counts' space)
   int* qPerm = S + MW_HDR + (6 + MW_CP + MW_TOPK) * capl;
   int* cxStart = qPerm + capl;
-  static_assert(MW_CP >= 4, "the train records are staged in the lists' space");
+  static_assert(MW_CP >= 5, "the train records are staged in the lists' space");
   if (t <= ORBX_GRID_COLS) { colT[t] = 0; colQ[t] = 0; }
   // (only when a window spans less than half of the grid's columns: a window that reaches most columns prunes nothing, and the
   // brute-force configurations read the descriptors faster in index order -- header [8] tells k_match_wide_lists)
@@ -1666,6 +1666,7 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
   __shared__ int hist[HISTO_LENGTH];
   __shared__ int sChangedSw[MJ_SWEEPS];
   __shared__ int sNT, sBase, sOverflow, sNm, sBadDist, sBadRatio, sBadOri, sKeep[3], sKeepV[3];
+  __shared__ int sTooMany[2];  // per parity of the train-staging chunk: more than MJ_CAP eligible trains so far
   __shared__ int wcnt[MJ_T / 64];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1684,7 +1685,7 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
   const float hInv = (float)ORBX_GRID_ROWS / (float)(mp.b.max_y - mp.b.min_y);
   const float fminX = (float)mp.b.min_x, fminY = (float)mp.b.min_y;
   MJ_STAMP(0);
-  if (t == 0) { sNT = 0; sBase = 0; sOverflow = n2 > 65535 ? 1 : 0; sNm = 0; sBadDist = 0; sBadRatio = 0; sBadOri = 0; }
+  if (t == 0) { sNT = 0; sBase = 0; sOverflow = n2 > 65535 ? 1 : 0; sNm = 0; sBadDist = 0; sBadRatio = 0; sBadOri = 0; sTooMany[0] = 0; sTooMany[1] = 0; }
   if (t < 3) { sKeep[t] = -1; sKeepV[t] = 0; }
   if (t < MJ_SWEEPS) sChangedSw[t] = 0;
   if (t < HISTO_LENGTH) hist[t] = 0;
@@ -1718,8 +1719,13 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
         }
       }
     }
+    // more eligible trains than this kernel takes: no need to look at the rest.  The decision must not be read from sNT behind
+    // the barrier (a wave that has passed it may already be adding the next chunk's trains while a slower one still compares):
+    // every thread looks at the counter BEFORE the barrier -- the thread whose add came last sees the chunk's total -- and raises
+    // the chunk's own flag, which nothing writes again before every wave has read it (the other parity's flag is the next chunk's)
+    if (sNT > MJ_CAP) sTooMany[(j0 / MJ_T) & 1] = 1;
     __syncthreads();
-    if (sNT > MJ_CAP) break;  // (uniform) more eligible trains than this kernel takes: no need to look at the rest
+    if (sTooMany[(j0 / MJ_T) & 1]) break;  // (uniform)
   }
   if (sNT > MJ_CAP || sOverflow) {  // block-uniform: the pair goes to the wide path (matchWidePrep starts from the keypoints again)
     if (t == 0) { nmatchesOut[pair] = MATCH_PENDING; *hostWide = 1; }  // (mapped host memory: the batch needs the wide path)
@@ -2462,7 +2468,7 @@ __global__ __launch_bounds__(MW_T) void k_match_wide_resolve(const int* __restri
         return md;
       };
       bool fromTop = false;
-      if (topReady & (1u << rr)) {
+      if ((topReady & (1u << rr)) && nc > 0) {  // (a query whose window trains all lie at dmax or beyond has no top rows: its empty list is "re-read")
         uint32_t tc[MW_TOPK], ord[MW_TOPK];
         int hd[MW_TOPK];
         const int tn = min(nc, MW_TOPK);

@@ -188,6 +188,183 @@ __global__ __launch_bounds__(1024) void k_octree_global(const uint32_t* __restri
   t1024::octreeGlobalUnit(cand, cellCount, P, selStage, nselLevel, scratch, level, f, xchg, OCT_GLOBAL_XCHG, parScr, OCT_PAR_BIG, radixCnt2);
 }
 
+// ---- large units on many workgroups -----------------------------------------------------------------------------------
+// k_octree_buckets: one workgroup per BUCKET of a (frame, level) unit -- the keys of one tree node of depth bigD0 (octBigPlan).
+// A key's path depends on its coordinates only, so the bucket owns a rectangle of the level, and its candidates lie in the
+// segments of the FAST cells that overlap it: the workgroup lists those cells' survivors, keeps the ones whose path code has the
+// bucket's prefix, sorts them in LDS by the rest of the code and writes, into the bucket's slot of the unit's arrays, the
+// sorted keys, a score per key (response << 40 | inverted reference candidate order: the emit's "first of the highest
+// responses" is a maximum) and the divergence depth between neighbours; the bucket's record gets its count, the histograms of
+// the inner divergences / first lonely depths, and the first and last inner divergence (what the neighbouring BUCKETS decide
+// -- the divergence at the slot's two ends and the lonely depth of its first and last key -- is left to k_octree_big).
+#define OCTB_T 256
+#define OCTB_MAXCELLS 2048
+__global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __restrict__ cand, const int* __restrict__ cellCount,
+                                                          const OctLaunch P, uint8_t* __restrict__ scratch, int level0) {
+  const int level = blockIdx.z + level0, f = blockIdx.y + P.frame0, b = blockIdx.x;
+  const OctLevel& L = P.lev[level];
+  if (b >= L.bigBuckets) return;
+  __shared__ __attribute__((aligned(16))) u64 keysL[ORBX_OCTB_CAP];
+  __shared__ uint32_t ceL[ORBX_OCTB_CAP];
+  __shared__ int cpre[OCTB_MAXCELLS + 1];
+  __shared__ int hD[OCT_DEPTH + 2], hA[OCT_DEPTH + 2];
+  __shared__ int sCnt, sOver;
+  __shared__ int ws[OCTB_T / 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  uint32_t* candBuf;
+  int mCap, fCap, qMax;
+  OctScratch S = octCarve(P, level, f, scratch, &candBuf, &mCap, &fCap, &qMax);
+  int* info = reinterpret_cast<int*>(candBuf) + (size_t)b * ORBX_OCTB_INFO;
+  u64* score = S.sortTmp;
+  const int d0 = L.bigD0, capB = L.bigCapB;
+  const size_t base = (size_t)b * capB;
+  if (tid < OCT_DEPTH + 2) { hD[tid] = 0; hA[tid] = 0; }
+  if (tid == 0) { sCnt = 0; sOver = 0; }
+  // the bucket's rectangle: root, x prefix and y prefix from the bucket id (root << 2 D0 | D0 quadrant digits, y bit above x bit)
+  const int root = b >> (2 * d0);
+  uint32_t xp = 0, yp = 0;
+  for (int d = 0; d < d0; d++) {
+    xp |= ((uint32_t)(b >> (2 * d)) & 1u) << d;
+    yp |= ((uint32_t)(b >> (2 * d + 1)) & 1u) << d;
+  }
+  const uint32_t* bt = P.codeTab + L.bigTabOff;
+  const int xlo = (int)bt[(root << d0) + (int)xp], xhi = (int)bt[(root << d0) + (int)xp + 1];
+  const uint32_t* bty = bt + (L.nIni << d0) + 1;
+  const int ylo = (int)bty[yp], yhi = (int)bty[yp + 1];
+  // FAST cell (ci, cj) holds the candidates with (x - 3) / wCell == cj and (y - 3) / hCell == ci (k_fast: detection areas tile)
+  const int nRowsC = L.nCells / L.nCols;
+  int cx0 = 0, cx1 = -1, cy0 = 0, cy1 = -1;
+  if (xhi > xlo && yhi > ylo) {
+    cx0 = min(max(xlo - 3, 0) / L.wCell, L.nCols - 1); cx1 = min(max(xhi - 1 - 3, 0) / L.wCell, L.nCols - 1);
+    cy0 = min(max(ylo - 3, 0) / L.hCell, nRowsC - 1); cy1 = min(max(yhi - 1 - 3, 0) / L.hCell, nRowsC - 1);
+  }
+  const int cw = cx1 - cx0 + 1, nc = cw * (cy1 - cy0 + 1);
+  const int* cellCnt = cellCount + (int64_t)f * P.nCellsTotal + L.cellBase;
+  __syncthreads();
+  int nRaw = 0;
+  if (nc > OCTB_MAXCELLS) {
+    if (tid == 0) sOver = 1;
+  } else if (nc > 0) {
+    // exclusive prefix of the cells' counts (a thread owns consecutive cells of the rectangle, row-major)
+    const int per = (nc + OCTB_T - 1) / OCTB_T;
+    const int c0 = min(tid * per, nc), c1 = min(c0 + per, nc);
+    int sum = 0;
+    for (int c = c0; c < c1; c++) sum += cellCnt[(cy0 + c / cw) * L.nCols + cx0 + c % cw];
+    int acc = blockScanExcl(sum, tid, ws, &nRaw, false);
+    for (int c = c0; c < c1; c++) {
+      cpre[c] = acc;
+      acc += cellCnt[(cy0 + c / cw) * L.nCols + cx0 + c % cw];
+    }
+    if (tid == 0) cpre[nc] = nRaw;
+  }
+  __syncthreads();
+  const uint32_t* segBase = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
+  const uint2* __restrict__ tabX = reinterpret_cast<const uint2*>(P.codeTab + L.tabOff);
+  const uint32_t* __restrict__ tabY = P.codeTab + L.tabOff + 2 * L.tabW;
+  const int pshift = 2 * (OCT_DEPTH - d0);  // the bucket id = code >> pshift
+  if (!sOver) {
+    for (int r0 = 0; r0 < nRaw; r0 += OCTB_T) {
+      const int r = r0 + tid;
+      bool in = false;
+      uint32_t ce = 0, digits = 0;
+      if (r < nRaw) {
+        int lo = 0, hi = nc;  // cpre[lo] <= r < cpre[hi]
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (cpre[mid] <= r) lo = mid; else hi = mid;
+        }
+        const int cell = (cy0 + lo / cw) * L.nCols + cx0 + lo % cw;
+        ce = segBase[(size_t)cell * L.segCap + (r - cpre[lo])];
+        const uint2 tx = tabX[min((int)(ce & 0xfff), L.tabW - 1)];
+        digits = tx.x | tabY[min((int)((ce >> 12) & 0xfff), L.tabH - 1)];
+        const u64 code = ((u64)tx.y << 32) | (u64)digits;
+        in = (int)(code >> pshift) == b;
+      }
+      const unsigned long long m = __ballot(in);
+      int wbase = 0;
+      if (lane == 0 && m) wbase = atomicAdd(&sCnt, __popcll(m));
+      wbase = __shfl(wbase, 0);
+      if (in) {
+        const int slot = wbase + __popcll(m & ((1ull << lane) - 1ull));
+        if (slot < ORBX_OCTB_CAP) {
+          // sort key: the digits below the bucket's depth (the top ones are the same for all its keys), then the slot
+          keysL[slot] = ((u64)(d0 > 0 ? digits << (2 * d0) : digits) << 16) | (u64)slot;
+          ceL[slot] = ce;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int n = sCnt;
+  if (sOver || n >= capB || n > ORBX_OCTB_CAP) {  // (n == capB: the slot's last entry holds the divergence to the next bucket)
+    if (tid == 0) { info[0] = 0; info[3] = 1; }
+    return;
+  }
+  int nPad = OCTB_T;
+  while (nPad < n) nPad <<= 1;
+  for (int i = n + tid; i < nPad; i += OCTB_T) keysL[i] = ~0ull;
+  __syncthreads();
+  if (n > 1) {
+    const int e = nPad / OCTB_T;
+    if (e == 1) bitonicSortRegs<1>(keysL, tid);
+    else if (e == 2) bitonicSortRegs<2>(keysL, tid);
+    else if (e == 4) bitonicSortRegs<4>(keysL, tid);
+    else bitonicSortRegs<8>(keysL, tid);
+  }
+  static_assert(ORBX_OCTB_CAP <= 8 * OCTB_T, "register sort: at most eight keys per thread");
+  const uint32_t topDigits = d0 > 0 ? (uint32_t)(b & ((1 << (2 * d0)) - 1)) << (32 - 2 * d0) : 0u;
+  auto codeAt = [&](int i) {
+    const uint32_t rem = (uint32_t)(keysL[i] >> 16);
+    return ((u64)root << 32) | (u64)(topDigits | (d0 > 0 ? rem >> (2 * d0) : rem));
+  };
+  for (int i = tid; i < n; i += OCTB_T) {
+    const u64 code = codeAt(i);
+    const uint32_t ce = ceL[(int)(keysL[i] & 0xffff)];
+    S.keys[base + i] = (code >> S.keyShift) << 24;
+    score[base + i] = ((u64)(ce >> 24) << 40) | (((1ull << 40) - 1ull) - candRank(ce, L));
+    const int dl = i > 0 ? divDepth(codeAt(i - 1), code) : -1;
+    const int dr = i + 1 < n ? divDepth(code, codeAt(i + 1)) : -1;
+    if (i > 0) {
+      S.div[base + i] = (uint8_t)dl;
+      atomicAdd(&hD[dl], 1);
+      if (i + 1 < n) atomicAdd(&hA[max(dl, dr)], 1);
+      if (i == 1) info[1] = dl;
+      if (i == n - 1) info[2] = dl;
+    }
+  }
+  __syncthreads();
+  if (tid < OCT_DEPTH + 2) { info[4 + tid] = hD[tid]; info[4 + OCT_DEPTH + 2 + tid] = hA[tid]; }
+  if (tid == 0) {
+    info[0] = n; info[3] = 0;
+    if (n < 2) { info[1] = 255; info[2] = 255; }
+  }
+}
+static_assert(ORBX_OCTB_INFO >= 4 + 2 * (OCT_DEPTH + 2), "a bucket's record holds both histograms");
+
+// k_octree_big: the tree arithmetic of the units k_octree_buckets has prepared, one workgroup of 1024 threads per unit
+// (octreeSelectBig).  A unit it cannot take (a bucket overflowed, the full passes stopped above the bucket depth, node tables
+// beyond the scratch) is left at -2 for k_octree_global, which runs behind it.
+#define OCTBIG_XCHG 8192
+__global__ __launch_bounds__(1024) void k_octree_big(const OctLaunch P, SelKp* __restrict__ selStage, int* __restrict__ nselLevel,
+                                                    uint8_t* __restrict__ scratch, int* __restrict__ maxN, int level0) {
+  __shared__ __attribute__((aligned(16))) u64 xchg[OCTBIG_XCHG];
+  __shared__ uint32_t parScr[OCT_PAR_SCR_FOR(OCT_PAR_BIG)];
+  const int level = blockIdx.y + level0, f = blockIdx.x + P.frame0;  // level-major dispatch, see launch_octree
+  int* nOut = &nselLevel[f * P.nlevels + level];
+  uint32_t* candBuf;
+  int mCap, fCap, qMax;
+  t1024::OctScratch S = t1024::octCarve(P, level, f, scratch, &candBuf, &mCap, &fCap, &qMax);
+  S.xchg = xchg; S.xchgCap = OCTBIG_XCHG;
+  S.parScr = parScr; S.parCap = OCT_PAR_BIG;
+  if (P.lev[level].bigBuckets <= 0) {  // (uniform) no bucket plan for this level: k_octree_global takes the unit
+    if (threadIdx.x == 0) *nOut = -2;
+    return;
+  }
+  t1024::octreeSelectBig(S, S.sortTmp, reinterpret_cast<const int*>(candBuf), P.lev[level], level,
+                         selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, mCap, fCap, qMax,
+                         maxN ? maxN + (f * P.nlevels + level) : nullptr);
+}
+
 size_t octScratchBytes(int nMax, int qMax) {
   size_t nPad = 1024;
   while ((int)nPad < nMax) nPad <<= 1;
@@ -299,6 +476,25 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
   // so every group adds its own tail, and that costs more than the smaller units' LDS gives back to the other lanes.
   static const int splitMin = getenv("ORBX_OCT_SPLIT_MIN") ? atoi(getenv("ORBX_OCT_SPLIT_MIN")) : (1 << 30);
   if (usedInstance) *usedInstance = 0;
+  // Large units (levels that expect them): k_octree_buckets sorts every unit's keys bucket by bucket on many workgroups,
+  // k_octree_big does the tree arithmetic with one workgroup per unit, and k_octree_global (one workgroup per unit for everything,
+  // the round-1..3 path) runs behind them for the units they could not take.  ORBX_OCT_NO_BIG (diagnostics): the old path alone.
+  static const bool noBig = getenv("ORBX_OCT_NO_BIG") != nullptr;
+  auto launchBig = [&](int l0, int l1, bool fallback) {
+    int maxBuckets = 0;
+    for (int l = l0; l < l1; l++) maxBuckets = std::max(maxBuckets, P.lev[l].bigBuckets);
+    if (maxBuckets > 0) {
+      hipLaunchKernelGGL(k_octree_buckets, dim3(maxBuckets, nFrames, l1 - l0), dim3(OCTB_T), 0, st, cand, cellCount, P, scratch, l0);
+      hipLaunchKernelGGL(k_octree_big, dim3(nFrames, l1 - l0, 1), dim3(1024), 0, st, P, selStage, nselLevel, scratch, maxN, l0);
+    }
+    if (fallback || maxBuckets == 0)
+      hipLaunchKernelGGL(k_octree_global, dim3(nFrames, l1 - l0, 1), dim3(1024), 0, st, cand, cellCount, P, selStage, nselLevel, scratch,
+                         maxBuckets > 0 ? 0 : 1, l0);
+  };
+  if (force == -2 || force == -3) {  // (test hook) the many-workgroup path for every unit, with / without the fallback behind it
+    launchBig(0, P.nlevels, force == -2);
+    return hipGetLastError();
+  }
   if (force < 0) {
     hipLaunchKernelGGL(k_octree_global, dim3(nFrames, P.nlevels, 1), dim3(1024), 0, st, cand, cellCount, P, selStage, nselLevel, scratch,
                        1, 0);
@@ -355,10 +551,17 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
       case 512: ORBX_OCT_LAUNCH(512, 128, 0); break;
       case 1024: ORBX_OCT_LAUNCH(1024, 256, 0); break;
       case 2048: ORBX_OCT_LAUNCH(2048, 256, 0); break;
-      default:  // the level expects large units: what fits the LDS layout is done there, the rest is deferred
-        ORBX_OCT_LAUNCH(2048, 256, 1);
-        hipLaunchKernelGGL(k_octree_global, grid, dim3(1024), 0, st, cand, cellCount, P, selStage, nselLevel, scratch, 0, l0);
+      default: {  // the level expects large units
+        bool planned = !noBig;
+        for (int l = l0; l < l1; l++) planned = planned && P.lev[l].bigBuckets > 0;
+        if (planned) {
+          launchBig(l0, l1, true);
+        } else {  // what fits the LDS layout is done there, the rest is deferred to the one-workgroup kernel
+          ORBX_OCT_LAUNCH(2048, 256, 1);
+          hipLaunchKernelGGL(k_octree_global, grid, dim3(1024), 0, st, cand, cellCount, P, selStage, nselLevel, scratch, 0, l0);
+        }
         break;
+      }
     }
 #undef ORBX_OCT_LAUNCH
     const hipError_t e = hipGetLastError();

@@ -24,10 +24,15 @@ L.orbx_diag_oct_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert L.orbx_diag_oct_stamps(st.ctypes.data, nb) == 0
 names = ["codes", "keysort", "div/alone", "passloop", "nodelist", "nodesort", "noderec", "(a)sized", "(b)introsort", "(b2)ranksort", "(c)children", "(d)cut", "(e)create", "emit"]
 st = st.astype(np.int64)
+big = bool(os.environ.get("OCT_BIG"))  # the units ran on k_octree_big (levels with large units): its stamps 0, 3 .. 15
+if big:
+    names = ["buckets'records", "passloop", "nodelist", "nodesort", "noderec", "(a)sized", "(b)std::sort", "-", "(c)children", "(d)cut", "(e)create", "emit"]
 for lvl in range(8):
     s = st[lvl * B:(lvl + 1) * B]  # workgroups are dispatched level-major: block = level * nFrames + frame
     d = [s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], s[:, 4] - s[:, 3], s[:, 5] - s[:, 4], s[:, 6] - s[:, 5], s[:, 7] - s[:, 6],
          s[:, 8], s[:, 9], s[:, 10], s[:, 11], s[:, 12], s[:, 13], s[:, 15] - s[:, 14]]
+    if big:
+        d = [s[:, 3] - s[:, 0]] + d[3:7] + d[7:13] + [d[13]]
     tot = s[:, 15] - s[:, 0]
     print("level %d total %.0f cyc:" % (lvl, tot.mean()), " ".join("%s=%.0f" % (n, x.mean()) for n, x in zip(names, d)))
 if os.environ.get("OCT_TIMELINE"):  # when the units' first phase starts and ends and when the units end, from the launch's first stamp
