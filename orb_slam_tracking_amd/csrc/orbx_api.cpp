@@ -615,34 +615,25 @@ void octCodeTable(const OctLevel& O, uint32_t* out) {
     ty[yi] = s;
   }
 }
-// Plan of the many-workgroup selection of large units (k_octree_buckets + k_octree_big) for one level: the bucket depth D0, the
-// number of buckets nIni * 4^D0 and the keys a bucket's slot holds.  (a) D0 never exceeds the depth the full passes are
-// GUARANTEED to reach: the pass loop of DistributeOctTree (cpp:781-895) stops at the first depth k where the list holds N nodes
-// or one more pass would overshoot (size + 3 nToExpand > N), and either needs 4 size_k > N with size_k <= nIni 4^k -- so
-// k >= min{k : nIni 4^(k+1) > N}, and every node the list ever holds lies inside one bucket (the device checks k again).
-// (b) a bucket covers at most ~16 k pixels, so that even a dense level (FAST threshold 0) stays below a slot's capacity; a
-// fuller bucket sends its unit to the one-workgroup kernel.  (c) the buckets' slots fill the unit's key array (nPad entries).
+// Plan of the many-workgroup selection of large units (k_octree_buckets + k_octree_big) for one level: the deepest bucket depth
+// the level allows; the depth of a launch is chosen below it from the previous batch's candidate counts (octBigChoose).  A
+// bucket depth D0 must never exceed the depth the full passes are GUARANTEED to reach: the pass loop of DistributeOctTree
+// (cpp:781-895) stops at the first depth k where the list holds N nodes or one more pass would overshoot (size + 3 nToExpand
+// > N), and either needs 4 size_k > N with size_k <= nIni 4^k -- so k >= min{k : nIni 4^(k+1) > N}, and every node the list
+// ever holds lies inside one bucket (the device checks k again).  At most ORBX_OCTB_MAX_BUCKETS buckets.
 void octBigPlan(OctLevel* O, int nMax) {
+  O->bigDMax = -1;
   O->bigD0 = 0; O->bigBuckets = 0; O->bigCapB = 0;
-  if (O->nIni < 1 || O->quota < 1) return;
+  if (O->nIni < 1 || O->nIni > ORBX_OCTB_MAX_BUCKETS || O->quota < 1) return;
   int kq = 0;
   while ((long long)O->nIni << (2 * (kq + 1)) <= (long long)O->quota && kq < 8) kq++;
-  const double rootArea = (double)std::ceil(O->hX) * (double)O->height;
-  int dArea = 0;
-  while (rootArea / (double)(1ll << (2 * dArea)) > 16384.0 && dArea < 8) dArea++;
-  int d0 = std::min(kq, dArea);
-  while (d0 > 0 && ((long long)O->nIni << (2 * d0)) > ORBX_OCTB_MAX_BUCKETS) d0--;
-  const long long nb = (long long)O->nIni << (2 * d0);
-  if (nb > ORBX_OCTB_MAX_BUCKETS) return;
-  long long nPad = 1024;
-  while (nPad < nMax) nPad <<= 1;
-  int cap = ORBX_OCTB_CAP;
-  while (cap > 0 && (long long)cap * nb > nPad) cap >>= 1;
-  if (cap < 256) return;
-  O->bigD0 = d0; O->bigBuckets = (int32_t)nb; O->bigCapB = cap;
+  int d = kq;
+  while (d > 0 && ((long long)O->nIni << (2 * d)) > ORBX_OCTB_MAX_BUCKETS) d--;
+  O->bigDMax = d;
+  octBigChoose(O, nMax, 0);
 }
 inline size_t octBigTabDwords(const OctLevel& O) {
-  return O.bigBuckets > 0 ? ((size_t)O.nIni << O.bigD0) + 1 + ((size_t)1 << O.bigD0) + 1 : 0;
+  return O.bigDMax >= 0 ? ((size_t)O.nIni << O.bigDMax) + 1 + ((size_t)1 << O.bigDMax) + 1 : 0;
 }
 // places the levels' tables one behind the other (tabW / tabH and the big plan set by the caller); returns the dwords they take
 size_t octTabLayout(OctLaunch* P) {
@@ -656,12 +647,12 @@ size_t octTabLayout(OctLaunch* P) {
   }
   return off;
 }
-// The buckets' coordinate intervals (OctLevel::bigTabOff): a key's top D0 x digits (and its root) grow with x, its top D0 y
-// digits with y, so every prefix owns an interval of columns / rows; xs[(root << D0 | x prefix)] = its first column, one more
-// entry = the end; ys likewise.  k_octree_buckets reads only the FAST cells that overlap its bucket's rectangle.  Returns false
+// The buckets' coordinate intervals (OctLevel::bigTabOff), at the level's deepest bucket depth D = bigDMax: a key's top D x
+// digits (and its root) grow with x, its top D y digits with y, so every prefix owns an interval of columns / rows;
+// xs[(root << D | x prefix)] = its first column, one more entry = the end; ys likewise.  k_octree_buckets reads only the FAST cells that overlap its bucket's rectangle.  Returns false
 // when a prefix sequence is not monotonic (it always is; the level then simply keeps the one-workgroup kernel).
 bool octBigTable(const OctLevel& O, const uint32_t* codeTab, uint32_t* out) {
-  const int d0 = O.bigD0, nx = O.nIni << d0, ny = 1 << d0;
+  const int d0 = O.bigDMax, nx = O.nIni << d0, ny = 1 << d0;
   auto topBits = [&](uint32_t s, int odd) {  // the digits of depths 1 .. d0: bit 2 (16 - d) + odd - 2 ... of the digit word
     uint32_t v = 0;
     for (int d = 1; d <= d0; d++) v = (v << 1) | ((s >> (2 * (16 - d) + odd)) & 1u);
@@ -695,7 +686,7 @@ void octCodeTables(OctLaunch* P, std::vector<uint32_t>* out) {
   for (int l = 0; l < P->nlevels; l++) {
     OctLevel& O = P->lev[l];
     octCodeTable(O, out->data() + O.tabOff);
-    if (O.bigBuckets > 0 && !octBigTable(O, out->data() + O.tabOff, out->data() + O.bigTabOff)) O.bigBuckets = 0;
+    if (O.bigDMax >= 0 && !octBigTable(O, out->data() + O.tabOff, out->data() + O.bigTabOff)) { O.bigDMax = -1; O.bigBuckets = 0; }
   }
 }
 
@@ -735,6 +726,7 @@ size_t buildOctLaunch(const orbx_ctx* c, const Geom& g, OctLaunch* out) {
     P.scrStride[l] = (int64_t)octScratchBytes(P.scrNMax[l], std::max(L.quota, O.nIni));  // = octreeGlobalUnit's qMax
     P.scrOff[l] = scr;
     scr += P.scrStride[l] * c->maxB;
+    O.bigDMax = -1;
     if (O.nCells < 65536) octBigPlan(&O, P.scrNMax[l]);  // (a bucket's scores carry the FAST cell index in 16 bits)
   }
   P.nCellsTotal = g.nCellsTotal;
@@ -2338,7 +2330,8 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
     HIPCHK(hipMemcpyAsync(dC, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->st));
     int hi[2] = {n, -7};
     HIPCHK(hipMemcpyAsync(dI, hi, sizeof hi, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(launch_octree(ctx->st, 1, dC, dI, P, dS, dI + 1, dScr, nullptr, nullptr,
+    const int hintN[ORBX_MAX_LEVELS] = {n};  // (variant 5: the bucket depth from the candidate count, as in the pipeline; 6: from the area)
+    HIPCHK(launch_octree(ctx->st, 1, dC, dI, P, dS, dI + 1, dScr, nullptr, variant == 5 ? hintN : nullptr,
                          variant == 1 ? -1 : variant == 2 ? 1024 : variant == 3 ? 512 : variant == 4 ? (2048 | 0x10000) : variant == 5 ? -2 :
                          variant == 6 ? -3 : 0, nullptr));
     HIPCHK(hipMemcpyAsync(res, dI, sizeof res, hipMemcpyDeviceToHost, ctx->st));

@@ -52,7 +52,13 @@ __device__ unsigned long long g_octStamps[4096 * OCT_NSTAMP];
       (t0) = now_;                                                                                           \
     }                                                                                                        \
   } while (0)
+// ... and which XCD the bucket waves / the unit's workgroup of the many-workgroup selection ran on (placement check)
+__device__ unsigned int g_octXcc[4096 * 9];
+#define OCT_XCC_B1(u) atomicAdd(&g_octXcc[((u) & 4095) * 9 + (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 7)], 1u)
+#define OCT_XCC_B2(u) g_octXcc[((u) & 4095) * 9 + 8] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 7
 #else
+#define OCT_XCC_B1(u) do {} while (0)
+#define OCT_XCC_B2(u) do {} while (0)
 #define OCT_STAMP(k) do {} while (0)
 #define OCT_STAMP_ACC(k, t0) do {} while (0)
 #endif
@@ -68,6 +74,9 @@ typedef unsigned long long u64;
 #define OCT_PAR_RANGES_FOR(capN) ((capN) / 16 < 64 ? 64 : (capN) / 16)  // ranges of more than 16 keys alive at a time: < capN / 16
 #define OCT_PAR_SCR_FOR(capN) (4 * (((capN) + 8) / 2) + 5 * OCT_PAR_RANGES_FOR(capN) + 4)
 #define OCT_PAR_SCR OCT_PAR_SCR_FOR(OCT_PAR_MAX)
+#define OCTBIG_NODES 8192   // k_octree_big: list nodes of a unit (LDS tables; M < 4 N)
+#define OCTBIG_PEND 2048    // ... pending nodes of a partial-pass round (< N)
+#define OCTBIG_XCHG 4096    // ... u64 entries of its sort exchange buffer (8192 32-bit node keys, 4096 64-bit ones)
 
 #define OCT_T 256
 namespace t256 {
@@ -78,6 +87,11 @@ namespace t256 {
 namespace t1024 {
 #include "orbx_octree_body.inc"
 }  // namespace t1024
+#undef OCT_T
+#define OCT_T 64
+namespace t64 {  // single-wave workgroups (k_octree_buckets): the register sort without any cross-wave stage
+#include "orbx_octree_body.inc"
+}  // namespace t64
 #undef OCT_T
 #define OCT_T 256  // the kernels below run 256 threads unless they say otherwise
 using namespace t256;
@@ -189,37 +203,106 @@ __global__ __launch_bounds__(1024) void k_octree_global(const uint32_t* __restri
 }
 
 // ---- large units on many workgroups -----------------------------------------------------------------------------------
-// k_octree_buckets: one workgroup per BUCKET of a (frame, level) unit -- the keys of one tree node of depth bigD0 (octBigPlan).
+// k_octree_buckets: ONE WAVE per BUCKET of a (frame, level) unit -- the keys of one tree node of depth bigD0 (octBigChoose).
 // A key's path depends on its coordinates only, so the bucket owns a rectangle of the level, and its candidates lie in the
-// segments of the FAST cells that overlap it: the workgroup lists those cells' survivors, keeps the ones whose path code has the
-// bucket's prefix, sorts them in LDS by the rest of the code and writes, into the bucket's slot of the unit's arrays, the
-// sorted keys, a score per key (response << 40 | inverted reference candidate order: the emit's "first of the highest
-// responses" is a maximum) and the divergence depth between neighbours; the bucket's record gets its count, the histograms of
-// the inner divergences / first lonely depths, and the first and last inner divergence (what the neighbouring BUCKETS decide
-// -- the divergence at the slot's two ends and the lonely depth of its first and last key -- is left to k_octree_big).
-#define OCTB_T 256
-#define OCTB_MAXCELLS 2048
+// segments of the FAST cells that overlap it: the wave lists those cells' survivors, keeps the ones whose path code has the
+// bucket's prefix, sorts them (registers + shuffles, no barrier) by the rest of the code and writes, into the bucket's slot of
+// the unit's arrays, the sorted keys, a score per key (response << 40 | inverted reference candidate order: the emit's "first
+// of the highest responses" is a maximum) and the divergence depth between neighbours; the bucket's record gets its count,
+// the histograms of the inner divergences / first lonely depths, and the first and last inner divergence (what the
+// neighbouring BUCKETS decide -- the divergence at the slot's two ends and the lonely depth of its first and last key -- is
+// left to k_octree_big).  A bucket is a chain of memory round trips (cell counts, candidates, code tables) and ~40 sort stages
+// for a few hundred keys; single-wave workgroups with 13 KB of LDS put twelve of them on a CU (four-wave workgroups around a
+// 2048-key LDS sort: 54-78 us per launch instead of ~20).
+// Placement: workgroups go round-robin to the 8 XCDs, and the buckets of unit u = (level - level0) * nFrames + frame are given to
+// the workgroups of XCD u % 8 -- the XCD k_octree_big's workgroup of that unit runs on (its grid index is u), so what is
+// written here is read there from the same L2 instead of through the fabric.
+#define OCTB_WAVES 4      // buckets (= independent waves) per workgroup: the dispatcher starts ~400 workgroups a microsecond
+#define OCTB_T (64 * OCTB_WAVES)
+#define OCTB_MAXCELLS 255
+
+// bitonic sort of 64 E keys of ONE wave, E per lane (lane t owns a[t E .. t E + E)); partners at distance < E are registers of
+// the same lane, the others lanes of the wave (shuffles); no workgroup barrier anywhere (the waves of k_octree_buckets are
+// independent).  `a` is LDS private to the wave.
+template <int E>
+__device__ __forceinline__ void waveSort32(uint32_t* a, int lane) {
+  constexpr int NTOT = 64 * E;
+  uint32_t v[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) v[e] = a[lane * E + e];
+  for (int k = 2; k <= NTOT; k <<= 1) {
+    for (int j = k >> 1; j >= E; j >>= 1) {
+      const int lm = j / E;
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        const int i = lane * E + e;
+        const uint32_t o = __shfl_xor(v[e], lm);
+        const bool lower = (i & j) == 0, asc = (i & k) == 0;
+        const bool keepMin = lower == asc;
+        v[e] = keepMin ? min(o, v[e]) : max(o, v[e]);
+      }
+    }
+#pragma unroll
+    for (int jj = E / 2; jj > 0; jj >>= 1) {
+      if (jj < k) {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          const int pe = e ^ jj;
+          if (pe > e) {
+            const bool asc = ((lane * E + e) & k) == 0;
+            const uint32_t x = v[e], y = v[pe];
+            const bool sw = (x > y) == asc;
+            v[e] = sw ? y : x;
+            v[pe] = sw ? x : y;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; e++) a[lane * E + e] = v[e];
+}
+// (orders a wave's own LDS traffic: what its lanes wrote is what its lanes read behind this point)
+#define OCTB_WAVE_SYNC()                                        \
+  do {                                                          \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      \
+    __builtin_amdgcn_wave_barrier();                            \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      \
+  } while (0)
+
 __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __restrict__ cand, const int* __restrict__ cellCount,
-                                                          const OctLaunch P, uint8_t* __restrict__ scratch, int level0) {
-  const int level = blockIdx.z + level0, f = blockIdx.y + P.frame0, b = blockIdx.x;
+                                                          const OctLaunch P, uint8_t* __restrict__ scratch, int level0, int level1,
+                                                          int nFrames) {
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int level, f, b;
+  {
+    const int nUnits = (level1 - level0) * nFrames;
+    int u = blockIdx.x & 7, k = (blockIdx.x >> 3) * OCTB_WAVES + wv;
+    for (;; u += 8) {
+      if (u >= nUnits) return;
+      const int nb = P.lev[level0 + u / nFrames].bigBuckets;
+      if (k < nb) break;
+      k -= nb;
+    }
+    level = level0 + u / nFrames; f = P.frame0 + u % nFrames; b = k;
+    if (lane == 0) OCT_XCC_B1(u);
+  }
   const OctLevel& L = P.lev[level];
-  if (b >= L.bigBuckets) return;
-  __shared__ __attribute__((aligned(16))) u64 keysL[ORBX_OCTB_CAP];
-  __shared__ uint32_t ceL[ORBX_OCTB_CAP];
-  __shared__ int cpre[OCTB_MAXCELLS + 1];
-  __shared__ int hD[OCT_DEPTH + 2], hA[OCT_DEPTH + 2];
-  __shared__ int sCnt, sOver;
-  __shared__ int ws[OCTB_T / 64];
-  const int tid = threadIdx.x, lane = tid & 63;
+  __shared__ uint32_t keysAll[OCTB_WAVES][ORBX_OCTB_CAP];
+  __shared__ uint32_t ceAll[OCTB_WAVES][ORBX_OCTB_CAP];
+  __shared__ uint16_t cellAll[OCTB_WAVES][ORBX_OCTB_CAP];
+  __shared__ int cpreAll[OCTB_WAVES][OCTB_MAXCELLS + 1];
+  uint32_t* keysL = keysAll[wv];
+  uint32_t* ceL = ceAll[wv];
+  uint16_t* cellL = cellAll[wv];
+  int* cpre = cpreAll[wv];
   uint32_t* candBuf;
   int mCap, fCap, qMax;
-  OctScratch S = octCarve(P, level, f, scratch, &candBuf, &mCap, &fCap, &qMax);
+  t64::OctScratch S = t64::octCarve(P, level, f, scratch, &candBuf, &mCap, &fCap, &qMax);
   int* info = reinterpret_cast<int*>(candBuf) + (size_t)b * ORBX_OCTB_INFO;
   u64* score = S.sortTmp;
   const int d0 = L.bigD0, capB = L.bigCapB;
   const size_t base = (size_t)b * capB;
-  if (tid < OCT_DEPTH + 2) { hD[tid] = 0; hA[tid] = 0; }
-  if (tid == 0) { sCnt = 0; sOver = 0; }
   // the bucket's rectangle: root, x prefix and y prefix from the bucket id (root << 2 D0 | D0 quadrant digits, y bit above x bit)
   const int root = b >> (2 * d0);
   uint32_t xp = 0, yp = 0;
@@ -227,10 +310,12 @@ __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __res
     xp |= ((uint32_t)(b >> (2 * d)) & 1u) << d;
     yp |= ((uint32_t)(b >> (2 * d + 1)) & 1u) << d;
   }
+  // (the interval tables are kept at the level's deepest bucket depth: a coarser prefix owns the union of its refinements)
   const uint32_t* bt = P.codeTab + L.bigTabOff;
-  const int xlo = (int)bt[(root << d0) + (int)xp], xhi = (int)bt[(root << d0) + (int)xp + 1];
-  const uint32_t* bty = bt + (L.nIni << d0) + 1;
-  const int ylo = (int)bty[yp], yhi = (int)bty[yp + 1];
+  const int dm = L.bigDMax, ds = dm - d0;
+  const int xlo = (int)bt[(root << dm) + ((int)xp << ds)], xhi = (int)bt[(root << dm) + (((int)xp + 1) << ds)];
+  const uint32_t* bty = bt + (L.nIni << dm) + 1;
+  const int ylo = (int)bty[(int)yp << ds], yhi = (int)bty[((int)yp + 1) << ds];
   // FAST cell (ci, cj) holds the candidates with (x - 3) / wCell == cj and (y - 3) / hCell == ci (k_fast: detection areas tile)
   const int nRowsC = L.nCells / L.nCols;
   int cx0 = 0, cx1 = -1, cy0 = 0, cy1 = -1;
@@ -240,101 +325,142 @@ __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __res
   }
   const int cw = cx1 - cx0 + 1, nc = cw * (cy1 - cy0 + 1);
   const int* cellCnt = cellCount + (int64_t)f * P.nCellsTotal + L.cellBase;
-  __syncthreads();
+  // the sort key of a candidate: the digits of its path code between the bucket's depth and the level's one-pixel depth D (all
+  // below are 0, all above the same for the whole bucket) -- at most 2 (D - D0) <= 22 bits -- then its slot (10 bits)
+  const int dBits = L.depthBits >= 1 && L.depthBits <= OCT_DEPTH ? L.depthBits : OCT_DEPTH;
+  const int remBits = 2 * (dBits - d0);
+  bool over = nc > OCTB_MAXCELLS || remBits > 22 || remBits < 0;
   int nRaw = 0;
-  if (nc > OCTB_MAXCELLS) {
-    if (tid == 0) sOver = 1;
-  } else if (nc > 0) {
-    // exclusive prefix of the cells' counts (a thread owns consecutive cells of the rectangle, row-major)
-    const int per = (nc + OCTB_T - 1) / OCTB_T;
-    const int c0 = min(tid * per, nc), c1 = min(c0 + per, nc);
-    int sum = 0;
-    for (int c = c0; c < c1; c++) sum += cellCnt[(cy0 + c / cw) * L.nCols + cx0 + c % cw];
-    int acc = blockScanExcl(sum, tid, ws, &nRaw, false);
-    for (int c = c0; c < c1; c++) {
-      cpre[c] = acc;
-      acc += cellCnt[(cy0 + c / cw) * L.nCols + cx0 + c % cw];
+  if (!over && nc > 0) {
+    // exclusive prefix of the cells' counts, row-major over the rectangle (a wave scan per 64 cells)
+    for (int c0 = 0; c0 < nc; c0 += 64) {
+      const int c = c0 + lane;
+      const int v = c < nc ? cellCnt[(cy0 + c / cw) * L.nCols + cx0 + c % cw] : 0;
+      int inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+      }
+      if (c < nc) cpre[c] = nRaw + inc - v;
+      nRaw += __shfl(inc, 63);
     }
-    if (tid == 0) cpre[nc] = nRaw;
+    if (lane == 0) cpre[nc] = nRaw;
   }
-  __syncthreads();
+  OCTB_WAVE_SYNC();
   const uint32_t* segBase = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
   const uint2* __restrict__ tabX = reinterpret_cast<const uint2*>(P.codeTab + L.tabOff);
   const uint32_t* __restrict__ tabY = P.codeTab + L.tabOff + 2 * L.tabW;
   const int pshift = 2 * (OCT_DEPTH - d0);  // the bucket id = code >> pshift
-  if (!sOver) {
-    for (int r0 = 0; r0 < nRaw; r0 += OCTB_T) {
-      const int r = r0 + tid;
-      bool in = false;
-      uint32_t ce = 0, digits = 0;
-      if (r < nRaw) {
+  const int rshift = 2 * (OCT_DEPTH - dBits);
+  const uint32_t remMask = remBits > 0 ? (1u << remBits) - 1u : 0u;
+  int n = 0;
+#ifdef ORBX_OCTB_EXP_NOGATHER
+  if (nRaw > 100000)
+#endif
+  if (!over) {
+    // four raw candidates per lane and step: their searches, candidate words and table words are in flight together
+    for (int r0 = 0; r0 < nRaw; r0 += 256) {
+      uint32_t ce[4], digits[4];
+      uint2 tx[4];
+      int cellOf[4];
+      bool valid[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int r = r0 + 64 * j + lane;
+        valid[j] = r < nRaw;
         int lo = 0, hi = nc;  // cpre[lo] <= r < cpre[hi]
         while (hi - lo > 1) {
           const int mid = (lo + hi) >> 1;
           if (cpre[mid] <= r) lo = mid; else hi = mid;
         }
-        const int cell = (cy0 + lo / cw) * L.nCols + cx0 + lo % cw;
-        ce = segBase[(size_t)cell * L.segCap + (r - cpre[lo])];
-        const uint2 tx = tabX[min((int)(ce & 0xfff), L.tabW - 1)];
-        digits = tx.x | tabY[min((int)((ce >> 12) & 0xfff), L.tabH - 1)];
-        const u64 code = ((u64)tx.y << 32) | (u64)digits;
-        in = (int)(code >> pshift) == b;
+        cellOf[j] = (cy0 + lo / cw) * L.nCols + cx0 + lo % cw;
+        ce[j] = valid[j] ? segBase[(size_t)cellOf[j] * L.segCap + (r - cpre[lo])] : 0u;
       }
-      const unsigned long long m = __ballot(in);
-      int wbase = 0;
-      if (lane == 0 && m) wbase = atomicAdd(&sCnt, __popcll(m));
-      wbase = __shfl(wbase, 0);
-      if (in) {
-        const int slot = wbase + __popcll(m & ((1ull << lane) - 1ull));
-        if (slot < ORBX_OCTB_CAP) {
-          // sort key: the digits below the bucket's depth (the top ones are the same for all its keys), then the slot
-          keysL[slot] = ((u64)(d0 > 0 ? digits << (2 * d0) : digits) << 16) | (u64)slot;
-          ceL[slot] = ce;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        tx[j] = tabX[min((int)(ce[j] & 0xfff), L.tabW - 1)];
+        digits[j] = tabY[min((int)((ce[j] >> 12) & 0xfff), L.tabH - 1)];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        digits[j] |= tx[j].x;
+        const u64 code = ((u64)tx[j].y << 32) | (u64)digits[j];
+        const bool in = valid[j] && (int)(code >> pshift) == b;
+        const unsigned long long m = __ballot(in);
+        if (in) {
+          const int slot = n + __popcll(m & ((1ull << lane) - 1ull));
+          if (slot < ORBX_OCTB_CAP) {
+            keysL[slot] = (((digits[j] >> rshift) & remMask) << 10) | (uint32_t)slot;
+            ceL[slot] = ce[j];
+            cellL[slot] = (uint16_t)cellOf[j];
+          }
         }
+        n += __popcll(m);
       }
     }
   }
-  __syncthreads();
-  const int n = sCnt;
-  if (sOver || n >= capB || n > ORBX_OCTB_CAP) {  // (n == capB: the slot's last entry holds the divergence to the next bucket)
-    if (tid == 0) { info[0] = 0; info[3] = 1; }
+  if (over || n >= capB || n > ORBX_OCTB_CAP) {  // (n == capB: the slot's last entry holds the divergence to the next bucket)
+    if (lane == 0) { info[0] = 0; info[3] = 1; }
     return;
   }
-  int nPad = OCTB_T;
+  static_assert(ORBX_OCTB_CAP <= 1024, "ten slot bits in a sort key");
+  static_assert(ORBX_OCTB_CAP <= 8 * 64, "register sort: at most eight keys per lane");
+  int nPad = 64;
   while (nPad < n) nPad <<= 1;
-  for (int i = n + tid; i < nPad; i += OCTB_T) keysL[i] = ~0ull;
-  __syncthreads();
+  for (int i = n + lane; i < nPad; i += 64) keysL[i] = ~0u;
+  OCTB_WAVE_SYNC();
+#ifndef ORBX_OCTB_EXP_NOSORT
   if (n > 1) {
-    const int e = nPad / OCTB_T;
-    if (e == 1) bitonicSortRegs<1>(keysL, tid);
-    else if (e == 2) bitonicSortRegs<2>(keysL, tid);
-    else if (e == 4) bitonicSortRegs<4>(keysL, tid);
-    else bitonicSortRegs<8>(keysL, tid);
+    const int e = nPad / 64;
+    if (e == 1) waveSort32<1>(keysL, lane);
+    else if (e == 2) waveSort32<2>(keysL, lane);
+    else if (e == 4) waveSort32<4>(keysL, lane);
+    else waveSort32<8>(keysL, lane);
   }
-  static_assert(ORBX_OCTB_CAP <= 8 * OCTB_T, "register sort: at most eight keys per thread");
-  const uint32_t topDigits = d0 > 0 ? (uint32_t)(b & ((1 << (2 * d0)) - 1)) << (32 - 2 * d0) : 0u;
-  auto codeAt = [&](int i) {
-    const uint32_t rem = (uint32_t)(keysL[i] >> 16);
-    return ((u64)root << 32) | (u64)(topDigits | (d0 > 0 ? rem >> (2 * d0) : rem));
-  };
-  for (int i = tid; i < n; i += OCTB_T) {
-    const u64 code = codeAt(i);
-    const uint32_t ce = ceL[(int)(keysL[i] & 0xffff)];
-    S.keys[base + i] = (code >> S.keyShift) << 24;
-    score[base + i] = ((u64)(ce >> 24) << 40) | (((1ull << 40) - 1ull) - candRank(ce, L));
-    const int dl = i > 0 ? divDepth(codeAt(i - 1), code) : -1;
-    const int dr = i + 1 < n ? divDepth(code, codeAt(i + 1)) : -1;
-    if (i > 0) {
-      S.div[base + i] = (uint8_t)dl;
-      atomicAdd(&hD[dl], 1);
-      if (i + 1 < n) atomicAdd(&hA[max(dl, dr)], 1);
-      if (i == 1) info[1] = dl;
-      if (i == n - 1) info[2] = dl;
+#endif
+  OCTB_WAVE_SYNC();
+  // the 16-level path code of sorted key i: root | the bucket's digits | the sorted digits | zeros
+  const u64 codeTop = ((u64)root << 32) | (d0 > 0 ? (u64)((uint32_t)(b & ((1 << (2 * d0)) - 1)) << (32 - 2 * d0)) : 0ull);
+  auto codeAt = [&](int i) { return codeTop | ((u64)(keysL[i] >> 10) << rshift); };
+  int hD[OCT_DEPTH + 2], hA[OCT_DEPTH + 2];  // (wave-uniform counters: ballots, no LDS atomics on a handful of addresses)
+#pragma unroll
+  for (int d = 0; d < OCT_DEPTH + 2; d++) { hD[d] = 0; hA[d] = 0; }
+#ifdef ORBX_OCTB_EXP_NOOUT
+  if (n > 100000)
+#endif
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const int i = i0 + lane;
+    int dl = -1, al = -1;
+    if (i < n) {
+      const u64 code = codeAt(i);
+      const int slot = (int)(keysL[i] & 1023u);
+      const uint32_t ce = ceL[slot];
+      S.keys[base + i] = (code >> S.keyShift) << 24;
+      // reference candidate order (cell row, cell col, y, x), cpp:1078-1137: the cell index came with the gather
+      const u64 rank = ((u64)cellL[slot] << 24) | (u64)(ce & 0xffffffu);
+      score[base + i] = ((u64)(ce >> 24) << 40) | (((1ull << 40) - 1ull) - rank);
+      if (i > 0) {
+        dl = t64::divDepth(codeAt(i - 1), code);
+        S.div[base + i] = (uint8_t)dl;
+        if (i + 1 < n) al = max(dl, t64::divDepth(code, codeAt(i + 1)));
+        if (i == 1) info[1] = dl;
+        if (i == n - 1) info[2] = dl;
+      }
+    }
+#pragma unroll
+    for (int d = 1; d < OCT_DEPTH + 2; d++) {  // (inside a bucket no two keys part at depth 0)
+      hD[d] += __popcll(__ballot(dl == d));
+      hA[d] += __popcll(__ballot(al == d));
     }
   }
-  __syncthreads();
-  if (tid < OCT_DEPTH + 2) { info[4 + tid] = hD[tid]; info[4 + OCT_DEPTH + 2 + tid] = hA[tid]; }
-  if (tid == 0) {
+  if (lane < OCT_DEPTH + 2) {
+    int vd = 0, va = 0;
+#pragma unroll
+    for (int d = 0; d < OCT_DEPTH + 2; d++) { vd = lane == d ? hD[d] : vd; va = lane == d ? hA[d] : va; }
+    info[4 + lane] = vd; info[4 + OCT_DEPTH + 2 + lane] = va;
+  }
+  if (lane == 0) {
     info[0] = n; info[3] = 0;
     if (n < 2) { info[1] = 255; info[2] = 255; }
   }
@@ -344,11 +470,15 @@ static_assert(ORBX_OCTB_INFO >= 4 + 2 * (OCT_DEPTH + 2), "a bucket's record hold
 // k_octree_big: the tree arithmetic of the units k_octree_buckets has prepared, one workgroup of 1024 threads per unit
 // (octreeSelectBig).  A unit it cannot take (a bucket overflowed, the full passes stopped above the bucket depth, node tables
 // beyond the scratch) is left at -2 for k_octree_global, which runs behind it.
-#define OCTBIG_XCHG 8192
 __global__ __launch_bounds__(1024) void k_octree_big(const OctLaunch P, SelKp* __restrict__ selStage, int* __restrict__ nselLevel,
                                                     uint8_t* __restrict__ scratch, int* __restrict__ maxN, int level0) {
   __shared__ __attribute__((aligned(16))) u64 xchg[OCTBIG_XCHG];
   __shared__ uint32_t parScr[OCT_PAR_SCR_FOR(OCT_PAR_BIG)];
+  __shared__ __attribute__((aligned(16))) uint32_t nodeLH[OCTBIG_NODES];
+  __shared__ uint16_t nodeUlx[OCTBIG_NODES];
+  __shared__ int pNd[OCTBIG_PEND], pLo[OCTBIG_PEND], pHiD[OCTBIG_PEND];
+  __shared__ uint16_t pUlx[OCTBIG_PEND];
+  static_assert(OCT_PAR_BIG <= OCTBIG_PEND && OCTBIG_PEND <= OCTBIG_XCHG, "the replay's keys live in the exchange buffer");
   const int level = blockIdx.y + level0, f = blockIdx.x + P.frame0;  // level-major dispatch, see launch_octree
   int* nOut = &nselLevel[f * P.nlevels + level];
   uint32_t* candBuf;
@@ -356,6 +486,8 @@ __global__ __launch_bounds__(1024) void k_octree_big(const OctLaunch P, SelKp* _
   t1024::OctScratch S = t1024::octCarve(P, level, f, scratch, &candBuf, &mCap, &fCap, &qMax);
   S.xchg = xchg; S.xchgCap = OCTBIG_XCHG;
   S.parScr = parScr; S.parCap = OCT_PAR_BIG;
+  S.nodeLH = nodeLH; S.nodeUlx = nodeUlx; S.pNd = pNd; S.pLo = pLo; S.pHiD = pHiD; S.pUlx = pUlx;
+  if (threadIdx.x == 0) OCT_XCC_B2(blockIdx.y * gridDim.x + blockIdx.x);
   if (P.lev[level].bigBuckets <= 0) {  // (uniform) no bucket plan for this level: k_octree_global takes the unit
     if (threadIdx.x == 0) *nOut = -2;
     return;
@@ -363,6 +495,40 @@ __global__ __launch_bounds__(1024) void k_octree_big(const OctLaunch P, SelKp* _
   t1024::octreeSelectBig(S, S.sortTmp, reinterpret_cast<const int*>(candBuf), P.lev[level], level,
                          selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, mCap, fCap, qMax,
                          maxN ? maxN + (f * P.nlevels + level) : nullptr);
+}
+
+// k_octree_emit: the units' output lists (k_octree_big: key ranges of the first N alive nodes in list order) -> SelKp records: a
+// range's first key with the highest response (cpp:984-1007) is the key with the largest score.  One thread per range, 256 per
+// workgroup, every range's scores in flight sixteen at a time.
+__global__ __launch_bounds__(256) void k_octree_emit(const OctLaunch P, SelKp* __restrict__ selStage, const int* __restrict__ nselLevel,
+                                                    uint8_t* __restrict__ scratch, int level0) {
+  const int level = blockIdx.y + level0, f = blockIdx.x + P.frame0;
+  if (P.lev[level].bigBuckets <= 0) return;
+  const int nOutNodes = nselLevel[f * P.nlevels + level];
+  const int p = blockIdx.z * 256 + threadIdx.x;
+  if (p >= nOutNodes) return;
+  uint32_t* candBuf;
+  int mCap, fCap, qMax;
+  const OctScratch S = octCarve(P, level, f, scratch, &candBuf, &mCap, &fCap, &qMax);
+  const u64* __restrict__ score = S.sortTmp;
+  const uint32_t e = (uint32_t)S.pending[p];
+  const int lo = (int)(e & 0x7ffffu), hi = lo + (int)(e >> 19);
+  u64 best = 0ull;
+  for (int i = lo; i < hi; i += 16) {
+    u64 sv[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) sv[q] = score[min(i + q, hi - 1)];
+#pragma unroll
+    for (int q = 0; q < 16; q++) best = sv[q] > best ? sv[q] : best;
+  }
+  const u64 rank = ((1ull << 40) - 1ull) - (best & ((1ull << 40) - 1ull));
+  SelKp kp;
+  kp.x = (uint16_t)((uint32_t)(rank & 0xfff) + ORBX_MIN_BORDER);  // cpp:1171-1172
+  kp.y = (uint16_t)((uint32_t)((rank >> 12) & 0xfff) + ORBX_MIN_BORDER);
+  kp.level = (uint8_t)level;
+  kp.response = (uint8_t)(best >> 40);
+  kp.pad = 0;
+  selStage[(int64_t)f * P.selStride + P.selOff[level] + p] = kp;
 }
 
 size_t octScratchBytes(int nMax, int qMax) {
@@ -373,7 +539,8 @@ size_t octScratchBytes(int nMax, int qMax) {
   size_t mPad = 1024;
   while (mPad < mCap) mPad <<= 1;
   size_t b = nPad * 8 + mPad * 8 + (size_t)2 * qMax * 8 + nPad * 4 + (mCap + fCap) * 8 + (size_t)3 * qMax * 4 + 2 * (nPad + 8) +
-             2 * (mCap + fCap + 8) + 16 + nPad * 4 /* gathered candidates */ + nPad * 8 /* radix sort buffer */;
+             2 * (mCap + fCap + 8) + 16 + nPad * 4 /* gathered candidates */ + nPad * 8 /* radix sort buffer */ +
+             16 /* the divergence bytes start 16-byte aligned */;
   return (b + 255) / 256 * 256;
 }
 
@@ -480,16 +647,26 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
   // k_octree_big does the tree arithmetic with one workgroup per unit, and k_octree_global (one workgroup per unit for everything,
   // the round-1..3 path) runs behind them for the units they could not take.  ORBX_OCT_NO_BIG (diagnostics): the old path alone.
   static const bool noBig = getenv("ORBX_OCT_NO_BIG") != nullptr;
+  OctLaunch Q = P;  // the launch's bucket depths: from the candidate counts of the previous batch (octBigChoose)
+  for (int l = 0; l < Q.nlevels; l++) octBigChoose(&Q.lev[l], Q.scrNMax[l], hintL ? hintL[l] : 0);
   auto launchBig = [&](int l0, int l1, bool fallback) {
-    int maxBuckets = 0;
-    for (int l = l0; l < l1; l++) maxBuckets = std::max(maxBuckets, P.lev[l].bigBuckets);
-    if (maxBuckets > 0) {
-      hipLaunchKernelGGL(k_octree_buckets, dim3(maxBuckets, nFrames, l1 - l0), dim3(OCTB_T), 0, st, cand, cellCount, P, scratch, l0);
-      hipLaunchKernelGGL(k_octree_big, dim3(nFrames, l1 - l0, 1), dim3(1024), 0, st, P, selStage, nselLevel, scratch, maxN, l0);
+    int nBuckets = 0;
+    for (int l = l0; l < l1; l++) nBuckets += Q.lev[l].bigBuckets;
+    if (nBuckets > 0) {
+      // workgroup i of k_octree_buckets runs on XCD i % 8 and takes the (i / 8)-th bucket of the units u = i % 8, i % 8 + 8, ...
+      long long perXcd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, most = 0;
+      for (int u = 0; u < (l1 - l0) * nFrames; u++) perXcd[u & 7] += Q.lev[l0 + u / nFrames].bigBuckets;
+      for (int x = 0; x < 8; x++) most = std::max(most, perXcd[x]);
+      hipLaunchKernelGGL(k_octree_buckets, dim3((unsigned)(8 * ((most + OCTB_WAVES - 1) / OCTB_WAVES)), 1, 1), dim3(OCTB_T), 0, st, cand,
+                         cellCount, Q, scratch, l0, l1, nFrames);
+      hipLaunchKernelGGL(k_octree_big, dim3(nFrames, l1 - l0, 1), dim3(1024), 0, st, Q, selStage, nselLevel, scratch, maxN, l0);
+      int qMost = 1;
+      for (int l = l0; l < l1; l++) qMost = std::max(qMost, Q.lev[l].quota);
+      hipLaunchKernelGGL(k_octree_emit, dim3(nFrames, l1 - l0, (qMost + 255) / 256), dim3(256), 0, st, Q, selStage, nselLevel, scratch, l0);
     }
-    if (fallback || maxBuckets == 0)
+    if (fallback || nBuckets == 0)
       hipLaunchKernelGGL(k_octree_global, dim3(nFrames, l1 - l0, 1), dim3(1024), 0, st, cand, cellCount, P, selStage, nselLevel, scratch,
-                         maxBuckets > 0 ? 0 : 1, l0);
+                         nBuckets > 0 ? 0 : 1, l0);
   };
   if (force == -2 || force == -3) {  // (test hook) the many-workgroup path for every unit, with / without the fallback behind it
     launchBig(0, P.nlevels, force == -2);
@@ -553,7 +730,7 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
       case 2048: ORBX_OCT_LAUNCH(2048, 256, 0); break;
       default: {  // the level expects large units
         bool planned = !noBig;
-        for (int l = l0; l < l1; l++) planned = planned && P.lev[l].bigBuckets > 0;
+        for (int l = l0; l < l1; l++) planned = planned && Q.lev[l].bigBuckets > 0;
         if (planned) {
           launchBig(l0, l1, true);
         } else {  // what fits the LDS layout is done there, the rest is deferred to the one-workgroup kernel
@@ -582,6 +759,9 @@ hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage
 #ifdef ORBX_OCT_STAMPS
 extern "C" int orbx_diag_oct_stamps(unsigned long long* out, int nBlocks) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_octStamps), sizeof(unsigned long long) * OCT_NSTAMP * nBlocks);
+}
+extern "C" int orbx_diag_oct_xcc(unsigned int* out, int nUnits) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_octXcc), sizeof(unsigned int) * 9 * nUnits);
 }
 #endif
 

@@ -26,13 +26,13 @@ names = ["codes", "keysort", "div/alone", "passloop", "nodelist", "nodesort", "n
 st = st.astype(np.int64)
 big = bool(os.environ.get("OCT_BIG"))  # the units ran on k_octree_big (levels with large units): its stamps 0, 3 .. 15
 if big:
-    names = ["buckets'records", "passloop", "nodelist", "nodesort", "noderec", "(a)sized", "(b)std::sort", "-", "(c)children", "(d)cut", "(e)create", "emit"]
+    names = ["records:load+scan", "records:neighbours", "records:histogram", "passloop", "nodelist", "nodesort", "noderec", "(a)sized", "(b)std::sort", "-", "(c)children", "(d)cut", "(e)create", "emit"]
 for lvl in range(8):
     s = st[lvl * B:(lvl + 1) * B]  # workgroups are dispatched level-major: block = level * nFrames + frame
     d = [s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], s[:, 4] - s[:, 3], s[:, 5] - s[:, 4], s[:, 6] - s[:, 5], s[:, 7] - s[:, 6],
          s[:, 8], s[:, 9], s[:, 10], s[:, 11], s[:, 12], s[:, 13], s[:, 15] - s[:, 14]]
     if big:
-        d = [s[:, 3] - s[:, 0]] + d[3:7] + d[7:13] + [d[13]]
+        d = d[0:3] + d[3:7] + d[7:13] + [d[13]]
     tot = s[:, 15] - s[:, 0]
     print("level %d total %.0f cyc:" % (lvl, tot.mean()), " ".join("%s=%.0f" % (n, x.mean()) for n, x in zip(names, d)))
 if os.environ.get("OCT_TIMELINE"):  # when the units' first phase starts and ends and when the units end, from the launch's first stamp
@@ -46,3 +46,10 @@ if os.environ.get("OCT_TIMELINE"):  # when the units' first phase starts and end
         s = rel[lvl * B:(lvl + 1) * B]
         print("level %d: step 1 starts at %6.0f .. %6.0f (mean %6.0f), ends at %6.0f .. %6.0f (mean %6.0f); unit ends at %6.0f .. %6.0f (mean %6.0f)" % (
             lvl, s[:, 0].min(), s[:, 0].max(), s[:, 0].mean(), s[:, 1].min(), s[:, 1].max(), s[:, 1].mean(), s[:, 15].min(), s[:, 15].max(), s[:, 15].mean()))
+
+if big:  # where the buckets' waves of a unit ran (counts per XCD) and where its k_octree_big workgroup did
+    xc = np.zeros((nb, 9), np.uint32)
+    L.orbx_diag_oct_xcc.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    assert L.orbx_diag_oct_xcc(xc.ctypes.data, nb) == 0
+    same = sum(int(r[:8].argmax() == r[8]) for r in xc)
+    print("XCD placement: %d of %d units have their bucket waves on the XCD of their k_octree_big workgroup; first units: %s" % (same, nb, xc[:6].tolist()))
