@@ -2347,6 +2347,7 @@ int orbx_debug_distribute_device(orbx_ctx* ctx, const float* xyr, int n, int min
   if (dT) (void)hipFree(dT);
   if (rc != ORBX_OK) return rc;
   if (res[1] < 0) return ORBX_E_CAPACITY;
+  res[1] &= ~0x40000000;  // (ORBX_OCT_REDONE: the many-workgroup kernels handed the unit to the one-workgroup code)
   for (int i = 0; i < res[1] && i < cap; i++) {
     out_xyr[3 * i] = (float)(sel[i].x - ORBX_MIN_BORDER);
     out_xyr[3 * i + 1] = (float)(sel[i].y - ORBX_MIN_BORDER);

@@ -94,7 +94,7 @@ struct OctLevel {
   int32_t bigTabOff;       // dword offset in codeTab: first x of every (root, top bigDMax x digits) prefix [nIni << bigDMax, + 1 end],
                            // then first y of every top-bigDMax-y-digits prefix [(1 << bigDMax) + 1]; a coarser prefix owns the union
 };
-#define ORBX_OCTB_CAP 512         // keys of one bucket (one wave's register sort in k_octree_buckets)
+#define ORBX_OCTB_CAP 1024        // keys of one bucket (one wave's register sort in k_octree_buckets)
 #define ORBX_OCTB_MAX_BUCKETS 1024
 #define ORBX_OCTB_INFO 40         // ints of a bucket's record: count, first / last inner divergence, overflow, 18 + 18 histogram bins
 
@@ -114,19 +114,21 @@ struct OctLaunch {
 #define ORBX_OCT_MAX_CAND ((1 << 19) - 1)  // candidates per (frame, level) the selection stage can index
 
 // Bucket depth of a level for one launch of the many-workgroup selection (k_octree_buckets / k_octree_big): the coarsest depth
-// that leaves a bucket at most 128 keys on average of the `hint` candidates a unit of that level had in the previous batch (a
+// that leaves a bucket at most 256 keys on average of the `hint` candidates a unit of that level had in the previous batch (a
 // bucket is one wave's sort of up to ORBX_OCTB_CAP keys: four times that average before a dense corner of the frame overfills
-// its slot and the unit falls to the one-workgroup kernel) -- or, without a hint, about 8 k pixels: 120 keys at 1.5 %.  nMax = the candidates the unit's scratch is sized for (OctLaunch::scrNMax):
+// its slot and the unit falls to the one-workgroup kernel; a wave spends ~1200 instructions on a bucket before its first key, so
+// many small buckets cost more than few full ones: 40 us against 13 for the 600 k keys of four 4K frames) -- or, without a hint,
+// about 16 k pixels: 250 keys at 1.5 %.  nMax = the candidates the unit's scratch is sized for (OctLaunch::scrNMax):
 // the buckets' slots share its key array.  bigBuckets == 0: no plan, the level keeps the one-workgroup kernel.
 inline void octBigChoose(OctLevel* O, int nMax, int hint) {
   O->bigD0 = 0; O->bigBuckets = 0; O->bigCapB = 0;
   if (O->bigDMax < 0) return;
   int d = 0;
   if (hint > 0) {
-    while (d < O->bigDMax && (long long)hint > 128ll * ((long long)O->nIni << (2 * d))) d++;
+    while (d < O->bigDMax && (long long)hint > 256ll * ((long long)O->nIni << (2 * d))) d++;
   } else {
     const double rootArea = (double)(O->width / O->nIni + 1) * (double)O->height;
-    while (d < O->bigDMax && rootArea / (double)(1ll << (2 * d)) > 8192.0) d++;
+    while (d < O->bigDMax && rootArea / (double)(1ll << (2 * d)) > 16384.0) d++;
   }
   long long nPad = 1024;
   while (nPad < nMax) nPad <<= 1;

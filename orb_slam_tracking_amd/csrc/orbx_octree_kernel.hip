@@ -56,7 +56,17 @@ __device__ unsigned long long g_octStamps[4096 * OCT_NSTAMP];
 __device__ unsigned int g_octXcc[4096 * 9];
 #define OCT_XCC_B1(u) atomicAdd(&g_octXcc[((u) & 4095) * 9 + (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 7)], 1u)
 #define OCT_XCC_B2(u) g_octXcc[((u) & 4095) * 9 + 8] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 7
+// ... and per bucket wave of k_octree_buckets: s_memtime behind its phases, the bucket's key count (tools/octb_stamps.py)
+#define OCTB_NSTAMP 8
+__device__ unsigned long long g_octbStamps[65536 * OCTB_NSTAMP];
+#define OCTB_STAMP(k) do { if (lane == 0) g_octbStamps[((blockIdx.x * OCTB_WAVES + wv) & 65535) * OCTB_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define OCTB_STAMP_V(k, v) do { if (lane == 0) g_octbStamps[((blockIdx.x * OCTB_WAVES + wv) & 65535) * OCTB_NSTAMP + (k)] = (unsigned long long)(v); } while (0)
+extern "C" int orbx_diag_octb_stamps(unsigned long long* out, int nWaves) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_octbStamps), sizeof(unsigned long long) * 8 * (size_t)nWaves);
+}
 #else
+#define OCTB_STAMP(k) do {} while (0)
+#define OCTB_STAMP_V(k, v) do {} while (0)
 #define OCT_XCC_B1(u) do {} while (0)
 #define OCT_XCC_B2(u) do {} while (0)
 #define OCT_STAMP(k) do {} while (0)
@@ -74,6 +84,7 @@ typedef unsigned long long u64;
 #define OCT_PAR_RANGES_FOR(capN) ((capN) / 16 < 64 ? 64 : (capN) / 16)  // ranges of more than 16 keys alive at a time: < capN / 16
 #define OCT_PAR_SCR_FOR(capN) (4 * (((capN) + 8) / 2) + 5 * OCT_PAR_RANGES_FOR(capN) + 4)
 #define OCT_PAR_SCR OCT_PAR_SCR_FOR(OCT_PAR_MAX)
+#define ORBX_OCT_REDONE 0x40000000  // bit of a (frame, level) count: k_octree_emit redid the unit with the one-workgroup code
 #define OCTBIG_NODES 8192   // k_octree_big: list nodes of a unit (LDS tables; M < 4 N)
 #define OCTBIG_PEND 2048    // ... pending nodes of a partial-pass round (< N)
 #define OCTBIG_XCHG 4096    // ... u64 entries of its sort exchange buffer (8192 32-bit node keys, 4096 64-bit ones)
@@ -274,13 +285,22 @@ __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __res
                                                           const OctLaunch P, uint8_t* __restrict__ scratch, int level0, int level1,
                                                           int nFrames) {
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  OCTB_STAMP(0);
+  OCTB_STAMP_V(6, 0);
   int level, f, b;
   {
     const int nUnits = (level1 - level0) * nFrames;
+    // (the levels' bucket counts first, all scalar loads in flight together: the walk below then costs no memory round trips)
+    int nbL[ORBX_MAX_LEVELS];
+#pragma unroll
+    for (int l = 0; l < ORBX_MAX_LEVELS; l++) nbL[l] = level0 + l < level1 ? P.lev[min(level0 + l, ORBX_MAX_LEVELS - 1)].bigBuckets : 0;
     int u = blockIdx.x & 7, k = (blockIdx.x >> 3) * OCTB_WAVES + wv;
     for (;; u += 8) {
       if (u >= nUnits) return;
-      const int nb = P.lev[level0 + u / nFrames].bigBuckets;
+      const int li = u / nFrames;
+      int nb = 0;
+#pragma unroll
+      for (int l = 0; l < ORBX_MAX_LEVELS; l++) nb = li == l ? nbL[l] : nb;
       if (k < nb) break;
       k -= nb;
     }
@@ -290,12 +310,12 @@ __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __res
   const OctLevel& L = P.lev[level];
   __shared__ uint32_t keysAll[OCTB_WAVES][ORBX_OCTB_CAP];
   __shared__ uint32_t ceAll[OCTB_WAVES][ORBX_OCTB_CAP];
-  __shared__ uint16_t cellAll[OCTB_WAVES][ORBX_OCTB_CAP];
   __shared__ int cpreAll[OCTB_WAVES][OCTB_MAXCELLS + 1];
+  __shared__ uint16_t cidxAll[OCTB_WAVES][OCTB_MAXCELLS + 1];
   uint32_t* keysL = keysAll[wv];
   uint32_t* ceL = ceAll[wv];
-  uint16_t* cellL = cellAll[wv];
   int* cpre = cpreAll[wv];
+  uint16_t* cidx = cidxAll[wv];  // FAST cell (row-major index in the level's grid) of the rectangle's c-th cell
   uint32_t* candBuf;
   int mCap, fCap, qMax;
   t64::OctScratch S = t64::octCarve(P, level, f, scratch, &candBuf, &mCap, &fCap, &qMax);
@@ -335,7 +355,9 @@ __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __res
     // exclusive prefix of the cells' counts, row-major over the rectangle (a wave scan per 64 cells)
     for (int c0 = 0; c0 < nc; c0 += 64) {
       const int c = c0 + lane;
-      const int v = c < nc ? cellCnt[(cy0 + c / cw) * L.nCols + cx0 + c % cw] : 0;
+      const int cell = (cy0 + c / cw) * L.nCols + cx0 + c % cw;
+      const int v = c < nc ? cellCnt[cell] : 0;
+      if (c < nc) cidx[c] = (uint16_t)cell;
       int inc = v;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
@@ -348,6 +370,7 @@ __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __res
     if (lane == 0) cpre[nc] = nRaw;
   }
   OCTB_WAVE_SYNC();
+  OCTB_STAMP(1);
   const uint32_t* segBase = cand + P.candOff[level] + (int64_t)f * P.candCap[level];
   const uint2* __restrict__ tabX = reinterpret_cast<const uint2*>(P.codeTab + L.tabOff);
   const uint32_t* __restrict__ tabY = P.codeTab + L.tabOff + 2 * L.tabW;
@@ -355,9 +378,6 @@ __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __res
   const int rshift = 2 * (OCT_DEPTH - dBits);
   const uint32_t remMask = remBits > 0 ? (1u << remBits) - 1u : 0u;
   int n = 0;
-#ifdef ORBX_OCTB_EXP_NOGATHER
-  if (nRaw > 100000)
-#endif
   if (!over) {
     // four raw candidates per lane and step: their searches, candidate words and table words are in flight together
     for (int r0 = 0; r0 < nRaw; r0 += 256) {
@@ -374,7 +394,7 @@ __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __res
           const int mid = (lo + hi) >> 1;
           if (cpre[mid] <= r) lo = mid; else hi = mid;
         }
-        cellOf[j] = (cy0 + lo / cw) * L.nCols + cx0 + lo % cw;
+        cellOf[j] = cidx[lo];
         ce[j] = valid[j] ? segBase[(size_t)cellOf[j] * L.segCap + (r - cpre[lo])] : 0u;
       }
 #pragma unroll
@@ -393,7 +413,6 @@ __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __res
           if (slot < ORBX_OCTB_CAP) {
             keysL[slot] = (((digits[j] >> rshift) & remMask) << 10) | (uint32_t)slot;
             ceL[slot] = ce[j];
-            cellL[slot] = (uint16_t)cellOf[j];
           }
         }
         n += __popcll(m);
@@ -405,30 +424,32 @@ __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __res
     return;
   }
   static_assert(ORBX_OCTB_CAP <= 1024, "ten slot bits in a sort key");
-  static_assert(ORBX_OCTB_CAP <= 8 * 64, "register sort: at most eight keys per lane");
+  OCTB_STAMP(2);
+  OCTB_STAMP_V(6, n + 1);
+  OCTB_STAMP_V(7, nRaw);
+  static_assert(ORBX_OCTB_CAP <= 16 * 64, "register sort: at most sixteen keys per lane");
   int nPad = 64;
   while (nPad < n) nPad <<= 1;
   for (int i = n + lane; i < nPad; i += 64) keysL[i] = ~0u;
   OCTB_WAVE_SYNC();
-#ifndef ORBX_OCTB_EXP_NOSORT
   if (n > 1) {
     const int e = nPad / 64;
     if (e == 1) waveSort32<1>(keysL, lane);
     else if (e == 2) waveSort32<2>(keysL, lane);
     else if (e == 4) waveSort32<4>(keysL, lane);
-    else waveSort32<8>(keysL, lane);
+    else if (e == 8) waveSort32<8>(keysL, lane);
+    else waveSort32<16>(keysL, lane);
   }
-#endif
   OCTB_WAVE_SYNC();
+  OCTB_STAMP(3);
   // the 16-level path code of sorted key i: root | the bucket's digits | the sorted digits | zeros
   const u64 codeTop = ((u64)root << 32) | (d0 > 0 ? (u64)((uint32_t)(b & ((1 << (2 * d0)) - 1)) << (32 - 2 * d0)) : 0ull);
   auto codeAt = [&](int i) { return codeTop | ((u64)(keysL[i] >> 10) << rshift); };
+  const uint32_t wInv = (uint32_t)(((1u << 24) + (uint32_t)L.wCell - 1u) / (uint32_t)L.wCell);
+  const uint32_t hInv = (uint32_t)(((1u << 24) + (uint32_t)L.hCell - 1u) / (uint32_t)L.hCell);
   int hD[OCT_DEPTH + 2], hA[OCT_DEPTH + 2];  // (wave-uniform counters: ballots, no LDS atomics on a handful of addresses)
 #pragma unroll
   for (int d = 0; d < OCT_DEPTH + 2; d++) { hD[d] = 0; hA[d] = 0; }
-#ifdef ORBX_OCTB_EXP_NOOUT
-  if (n > 100000)
-#endif
   for (int i0 = 0; i0 < n; i0 += 64) {
     const int i = i0 + lane;
     int dl = -1, al = -1;
@@ -437,8 +458,12 @@ __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __res
       const int slot = (int)(keysL[i] & 1023u);
       const uint32_t ce = ceL[slot];
       S.keys[base + i] = (code >> S.keyShift) << 24;
-      // reference candidate order (cell row, cell col, y, x), cpp:1078-1137: the cell index came with the gather
-      const u64 rank = ((u64)cellL[slot] << 24) | (u64)(ce & 0xffffffu);
+      // reference candidate order (cell row, cell col, y, x), cpp:1078-1137; the FAST cell of a candidate from its coordinates,
+      // (x - 3) / wCell and (y - 3) / hCell (k_fast: the cells' detection areas tile the level), by 2^24 reciprocals: exact for
+      // coordinates below 4096 and cells of at least 16 pixels (the error term x (m - 2^24 / w) stays below 2^24 / w)
+      const uint32_t cx = ce & 0xfffu, cy = (ce >> 12) & 0xfffu;
+      const uint32_t cc = (uint32_t)(((u64)(cx > 3u ? cx - 3u : 0u) * (u64)wInv) >> 24), cr = (uint32_t)(((u64)(cy > 3u ? cy - 3u : 0u) * (u64)hInv) >> 24);
+      const u64 rank = ((u64)(cr * (uint32_t)L.nCols + cc) << 24) | (u64)(ce & 0xffffffu);
       score[base + i] = ((u64)(ce >> 24) << 40) | (((1ull << 40) - 1ull) - rank);
       if (i > 0) {
         dl = t64::divDepth(codeAt(i - 1), code);
@@ -449,9 +474,11 @@ __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __res
       }
     }
 #pragma unroll
-    for (int d = 1; d < OCT_DEPTH + 2; d++) {  // (inside a bucket no two keys part at depth 0)
-      hD[d] += __popcll(__ballot(dl == d));
-      hA[d] += __popcll(__ballot(al == d));
+    for (int d = 1; d < OCT_DEPTH + 2; d++) {  // (inside a bucket keys part below the bucket's depth, down to the one-pixel depth)
+      if (d > d0 && d <= dBits + 1) {            // (uniform)
+        hD[d] += __popcll(__ballot(dl == d));
+        hA[d] += __popcll(__ballot(al == d));
+      }
     }
   }
   if (lane < OCT_DEPTH + 2) {
@@ -464,14 +491,16 @@ __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __res
     info[0] = n; info[3] = 0;
     if (n < 2) { info[1] = 255; info[2] = 255; }
   }
+  OCTB_STAMP(4);
 }
 static_assert(ORBX_OCTB_INFO >= 4 + 2 * (OCT_DEPTH + 2), "a bucket's record holds both histograms");
 
 // k_octree_big: the tree arithmetic of the units k_octree_buckets has prepared, one workgroup of 1024 threads per unit
 // (octreeSelectBig).  A unit it cannot take (a bucket overflowed, the full passes stopped above the bucket depth, node tables
-// beyond the scratch) is left at -2 for k_octree_global, which runs behind it.
-__global__ __launch_bounds__(1024) void k_octree_big(const OctLaunch P, SelKp* __restrict__ selStage, int* __restrict__ nselLevel,
-                                                    uint8_t* __restrict__ scratch, int* __restrict__ maxN, int level0) {
+// beyond its LDS) is redone by the same workgroup with the one-workgroup code (octreeGlobalUnit).
+__global__ __launch_bounds__(1024) void k_octree_big(const uint32_t* __restrict__ cand, const int* __restrict__ cellCount, const OctLaunch P,
+                                                    SelKp* __restrict__ selStage, int* __restrict__ nselLevel,
+                                                    uint8_t* __restrict__ scratch, int* __restrict__ maxN, int level0, int fallback) {
   __shared__ __attribute__((aligned(16))) u64 xchg[OCTBIG_XCHG];
   __shared__ uint32_t parScr[OCT_PAR_SCR_FOR(OCT_PAR_BIG)];
   __shared__ __attribute__((aligned(16))) uint32_t nodeLH[OCTBIG_NODES];
@@ -488,25 +517,39 @@ __global__ __launch_bounds__(1024) void k_octree_big(const OctLaunch P, SelKp* _
   S.parScr = parScr; S.parCap = OCT_PAR_BIG;
   S.nodeLH = nodeLH; S.nodeUlx = nodeUlx; S.pNd = pNd; S.pLo = pLo; S.pHiD = pHiD; S.pUlx = pUlx;
   if (threadIdx.x == 0) OCT_XCC_B2(blockIdx.y * gridDim.x + blockIdx.x);
-  if (P.lev[level].bigBuckets <= 0) {  // (uniform) no bucket plan for this level: k_octree_global takes the unit
-    if (threadIdx.x == 0) *nOut = -2;
-    return;
+  __shared__ int handedOn, redoneCount;
+  if (threadIdx.x == 0) handedOn = 1;
+  __syncthreads();
+  if (P.lev[level].bigBuckets > 0) {  // (uniform; no bucket plan for the level: straight to the one-workgroup code)
+    t1024::octreeSelectBig(S, S.sortTmp, reinterpret_cast<const int*>(candBuf), P.lev[level], level,
+                           selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, mCap, fCap, qMax,
+                           maxN ? maxN + (f * P.nlevels + level) : nullptr);
+    __syncthreads();
+    if (threadIdx.x == 0) handedOn = *nOut == -2;
+    __syncthreads();
   }
-  t1024::octreeSelectBig(S, S.sortTmp, reinterpret_cast<const int*>(candBuf), P.lev[level], level,
-                         selStage + (int64_t)f * P.selStride + P.selOff[level], nOut, mCap, fCap, qMax,
-                         maxN ? maxN + (f * P.nlevels + level) : nullptr);
+  if (!handedOn || !fallback) return;  // (block-uniform)
+  // The unit could not be taken (a bucket overflowed, the full passes stopped above the bucket depth, node tables beyond the LDS
+  // ones): this workgroup redoes it from the candidates with the one-workgroup code of k_octree_global, in place -- no second
+  // kernel waits behind every batch for a case that hardly ever occurs.  The count is published with ORBX_OCT_REDONE set:
+  // k_octree_emit must not take it for an output list's (k_sel_compact strips the bit).
+  static_assert(OCTBIG_XCHG >= OCT_GLOBAL_XCHG && OCTBIG_NODES * 4 >= 512 * (1024 / 64) * 4, "the one-workgroup code's LDS buffers fit this kernel's");
+  const int idx = f * P.nlevels + level;
+  t1024::octreeGlobalUnit(cand, cellCount, P, selStage, &redoneCount - idx, scratch, level, f, xchg, OCT_GLOBAL_XCHG, parScr, OCT_PAR_BIG, nodeLH);
+  __syncthreads();
+  if (threadIdx.x == 0) *nOut = redoneCount >= 0 ? (redoneCount | ORBX_OCT_REDONE) : redoneCount;
 }
 
 // k_octree_emit: the units' output lists (k_octree_big: key ranges of the first N alive nodes in list order) -> SelKp records: a
 // range's first key with the highest response (cpp:984-1007) is the key with the largest score.  One thread per range, 256 per
-// workgroup, every range's scores in flight sixteen at a time.
+// workgroup (many workgroups: one CU's L1 takes ~4 cycles per scattered line, 45 k cycles for the 1737 ranges of a 4K level 0),
+// every range's scores in flight sixteen at a time.
 __global__ __launch_bounds__(256) void k_octree_emit(const OctLaunch P, SelKp* __restrict__ selStage, const int* __restrict__ nselLevel,
                                                     uint8_t* __restrict__ scratch, int level0) {
   const int level = blockIdx.y + level0, f = blockIdx.x + P.frame0;
-  if (P.lev[level].bigBuckets <= 0) return;
   const int nOutNodes = nselLevel[f * P.nlevels + level];
   const int p = blockIdx.z * 256 + threadIdx.x;
-  if (p >= nOutNodes) return;
+  if (nOutNodes < 0 || (nOutNodes & ORBX_OCT_REDONE) || p >= nOutNodes) return;  // (a redone unit's records are in place already)
   uint32_t* candBuf;
   int mCap, fCap, qMax;
   const OctScratch S = octCarve(P, level, f, scratch, &candBuf, &mCap, &fCap, &qMax);
@@ -592,7 +635,8 @@ __global__ __launch_bounds__(256) void k_sel_compact(const SelKp* __restrict__ s
     bool bad = false;
     for (int l = 0; l < P.nlevels; l++) {
       off[l] = acc;
-      const int c = nselLevel[f * P.nlevels + l];
+      int c = nselLevel[f * P.nlevels + l];
+      if (c >= 0) c &= ~ORBX_OCT_REDONE;  // (k_octree_emit marks the count of a unit it redid)
       bad |= c < 0;
       acc += max(c, 0);
     }
@@ -644,8 +688,8 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
   static const int splitMin = getenv("ORBX_OCT_SPLIT_MIN") ? atoi(getenv("ORBX_OCT_SPLIT_MIN")) : (1 << 30);
   if (usedInstance) *usedInstance = 0;
   // Large units (levels that expect them): k_octree_buckets sorts every unit's keys bucket by bucket on many workgroups,
-  // k_octree_big does the tree arithmetic with one workgroup per unit, and k_octree_global (one workgroup per unit for everything,
-  // the round-1..3 path) runs behind them for the units they could not take.  ORBX_OCT_NO_BIG (diagnostics): the old path alone.
+  // k_octree_big does the tree arithmetic with one workgroup per unit (and redoes a unit it cannot take with the one-workgroup
+  // code of k_octree_global, the round-1..3 path), k_octree_emit picks the keypoints.  ORBX_OCT_NO_BIG (diagnostics): the old path.
   static const bool noBig = getenv("ORBX_OCT_NO_BIG") != nullptr;
   OctLaunch Q = P;  // the launch's bucket depths: from the candidate counts of the previous batch (octBigChoose)
   for (int l = 0; l < Q.nlevels; l++) octBigChoose(&Q.lev[l], Q.scrNMax[l], hintL ? hintL[l] : 0);
@@ -659,14 +703,14 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
       for (int x = 0; x < 8; x++) most = std::max(most, perXcd[x]);
       hipLaunchKernelGGL(k_octree_buckets, dim3((unsigned)(8 * ((most + OCTB_WAVES - 1) / OCTB_WAVES)), 1, 1), dim3(OCTB_T), 0, st, cand,
                          cellCount, Q, scratch, l0, l1, nFrames);
-      hipLaunchKernelGGL(k_octree_big, dim3(nFrames, l1 - l0, 1), dim3(1024), 0, st, Q, selStage, nselLevel, scratch, maxN, l0);
+      hipLaunchKernelGGL(k_octree_big, dim3(nFrames, l1 - l0, 1), dim3(1024), 0, st, cand, cellCount, Q, selStage, nselLevel, scratch, maxN, l0,
+                         fallback ? 1 : 0);
       int qMost = 1;
       for (int l = l0; l < l1; l++) qMost = std::max(qMost, Q.lev[l].quota);
       hipLaunchKernelGGL(k_octree_emit, dim3(nFrames, l1 - l0, (qMost + 255) / 256), dim3(256), 0, st, Q, selStage, nselLevel, scratch, l0);
+    } else {
+      hipLaunchKernelGGL(k_octree_global, dim3(nFrames, l1 - l0, 1), dim3(1024), 0, st, cand, cellCount, P, selStage, nselLevel, scratch, 1, l0);
     }
-    if (fallback || nBuckets == 0)
-      hipLaunchKernelGGL(k_octree_global, dim3(nFrames, l1 - l0, 1), dim3(1024), 0, st, cand, cellCount, P, selStage, nselLevel, scratch,
-                         nBuckets > 0 ? 0 : 1, l0);
   };
   if (force == -2 || force == -3) {  // (test hook) the many-workgroup path for every unit, with / without the fallback behind it
     launchBig(0, P.nlevels, force == -2);
