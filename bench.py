@@ -37,6 +37,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # cvt / every three-operand integer op / packed 16-bit / dot4 / dot2): tools/microbench/valu_rate.hip, measured on gfx950.
 VALU_PEAK_SIMD_CYCLES = 256 * 4 * 2.4e9
 KERNEL_OF = {"pyramid": "k_pyramid_bands", "fast": "k_fast_wave", "describe": "k_describe_patch"}
+PMC_WORKLOAD = "bench: 256 frames 640x480 / 1000 features per launch"
 
 
 def level_sizes(w, h, nlevels=8, sf=1.2):
@@ -64,12 +65,16 @@ def load_pmc():
     """The committed counter profile of this round (profiles/r*_pmc.json, made by tools/pmc_to_json.py from rocprofv3 --pmc
     passes of this very command): per kernel and per frame, VALU wave-instructions, VALU issue cycles and HBM bytes."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
-    if not files:
-        return None, None
-    try:
-        return json.load(open(files[-1])), os.path.basename(files[-1])
-    except Exception:
-        return None, None
+    # the newest file collected from THIS workload (tools/pmc_to_json.py records it; files of rounds 1-3 carry no workload and are
+    # the bench workload's): a counter file of another configuration must never become the source of `frac`
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload", PMC_WORKLOAD) == PMC_WORKLOAD:
+            return d, os.path.basename(f)
+    return None, None
 
 
 def kernel_sources_sha16():
@@ -161,6 +166,10 @@ def main():
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 path)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle comparison of the last batch (after the timed regions)")
+    ap.add_argument("--force-collective", action="store_true", help="N = 1: initialise the nccl (RCCL) process group with one rank and "
+                    "all_gather the keypoint counts every step, as the N > 1 runs do (exercises the RCCL path on a one-GPU box)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE configurations 3 and 5 and the 2000 x 2000 "
+                    "brute-force match that follow the headline (N = 1, outside its timed regions)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # before torch is imported or anything touches the GPU: start the ranks as fresh child processes (never an exec)
@@ -182,11 +191,22 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll = world > 1 or args.force_collective  # the counts are all-gathered every step
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+    elif args.force_collective:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.backend == "nccl":  # a one-rank RCCL communicator: ncclCommInitRank, all_gather, destroy -- on one GPU
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
 
     B = args.batch
@@ -250,14 +270,14 @@ def main():
         ext.extract_match_batch_device_async(d_imgs[k % nsets], B, W, H, W, W * H, o["k"], o["d"], o["n"], first, second, (0, W, 0, H),
                                              o["m"], o["nm"], None, 100, 0.9, True, cap)
         nstep[0] = k + 1
-        if world > 1 and k + 1 - ngathered[0] >= nout:  # as many in flight as there are output sets: wait for the oldest
+        if coll and k + 1 - ngathered[0] >= nout:  # as many in flight as there are output sets: wait for the oldest
             ext.wait_one()                              # (batch ngathered) and gather its counts
             gather_counts(ngathered[0])
             ngathered[0] += 1
 
     def barrier():
         ext.wait()  # every batch issued so far is complete
-        while world > 1 and ngathered[0] < nstep[0]:  # the counts of the last batches (the earlier ones were gathered in step())
+        while coll and ngathered[0] < nstep[0]:  # the counts of the last batches (the earlier ones were gathered in step())
             gather_counts(ngathered[0])
             ngathered[0] += 1
         finish_gather()
@@ -316,10 +336,23 @@ def main():
     last = nstep[0] - 1
     d_n, d_nm = outs[last % nout]["n"], outs[last % nout]["nm"]
     gathered_ok = None
-    if world > 1:  # the last all_gather's result: every rank's block holds the counts of that rank's last batch
+    if coll:  # the last all_gather's result: every rank's block holds the counts of that rank's last batch
         ca = counts_all.cpu().numpy()
         gathered_ok = bool(ngather_calls[0] > 0 and (ca > 0).all() and np.array_equal(ca[lo:hi], d_n.cpu().numpy()))
 
+    # not timed: the last batch's complete output set against the CPU oracle -- every rank its own shard, the
+    # verdict reduced to rank 0; a mismatch makes the process exit non-zero behind the JSON line
+    check_ok, check_what = None, "skipped (--no-check)"
+    if not args.no_check:
+        got = {k_: v.cpu().numpy() for k_, v in outs[last % nout].items()}
+        check_ok, check_what = oracle_check(host_sets[last % nsets], got, max(1, cpu_share() // max(world, 1)))
+        if world > 1:
+            t = torch.tensor([1 if check_ok else 0], dtype=torch.int32, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if check_ok and int(t.item()) == 0:
+                check_ok, check_what = False, "MISMATCH on another rank"
+            elif check_ok:
+                check_what = "every rank: " + check_what
     if rank == 0:
         n_kp = float(d_n.float().mean().item())
         nm_mean = float(d_nm.float().mean().item())
@@ -392,9 +425,9 @@ def main():
                                    "(window 100, ratio 0.9)" % (B, B // 2),
                        "frames_per_gpu": B, "pairs_per_gpu": B // 2, "mean_keypoints": n_kp, "mean_nmatches": nm_mean,
                        "pipeline_depth": depth, "prime_steps": args.prime,
-                       "rccl_ranks": (dist.get_world_size() if world > 1 and args.backend == "nccl" else (0 if world > 1 else 1)),
+                       "rccl_ranks": (dist.get_world_size() if coll and args.backend == "nccl" else (0 if world > 1 else 1)),
                        "collective": ({"backend": args.backend, "world_size": dist.get_world_size(), "all_gathers": ngather_calls[0],
-                                       "gathered_counts_ok": gathered_ok} if world > 1 else None),
+                                       "gathered_counts_ok": gathered_ok} if coll else None),
                        "parallelism": "frames sharded per GPU (%d ranks), RCCL all_gather of keypoint counts" % world},
             "spread": {"regions": len(region_dts), "steps_per_region": args.steps, "median": rates[len(rates) // 2],
                        "min": rates[0], "max": rates[-1], "first_region": B * world * args.steps / dt_first,
@@ -407,15 +440,8 @@ def main():
             "stage_ms_source": "warmup steps, every stage bracketed by HIP events (sums over the lanes / half-batch streams); the "
                                "timed steps bracket only the dominant kernel",
         }
-        # not timed: the last batch's complete output set against the CPU oracle
-        if args.no_check:
-            out["checked"] = False
-            out["check"] = "skipped (--no-check)"
-        else:
-            got = {k_: v.cpu().numpy() for k_, v in outs[last % nout].items()}
-            ok, what = oracle_check(host_sets[last % nsets], got, cpu_share())
-            out["checked"] = bool(ok)
-            out["check"] = what
+        out["checked"] = bool(check_ok) if check_ok is not None else False
+        out["check"] = check_what
         # second figure: the call the reference actually makes -- one frame per call through the host API
         # (Frame.cpp:58-60: host image in, keypoints + descriptors back on the host), and one SearchForInitialization per call
         try:
@@ -440,6 +466,38 @@ def main():
             e1.close()
         except Exception as ex:  # never let the second figure break the line
             out["single_frame"] = {"error": str(ex)[:200]}
+        # BASELINE configurations 3 and 5 and config 5's 2000 x 2000 brute-force match: rates of the same
+        # library right behind the headline (before the CPU legs: a GPU that has idled through them starts its next kernels at low
+        # clocks), outside the timed regions, each compared with the CPU oracle on one pair (not timed)
+        if world == 1 and not args.no_other_configs:
+            try:
+                ext.close()
+                del d_imgs, outs
+                torch.cuda.empty_cache()
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_config as BC
+                oc = {}
+                for cfg in ("c3", "c5"):
+                    r = BC.measure(cfg, steps=20, depth=3, device=local_rank)
+                    oc[cfg] = {"workload": "%d frames %dx%d / %d features + %d consecutive-pair matches (window %d) per call" % (
+                                   r["batch"], r["frame"][0], r["frame"][1], r["nfeatures"], r["batch"] // 2, r["window"]),
+                               "frames_per_s_synchronous": r["sync"]["frames_per_s"], "frames_per_s_on_lanes": r["lanes"]["frames_per_s"],
+                               "lanes": r["lanes"]["depth"], "ms_per_batch_synchronous": r["sync"]["ms_per_batch"],
+                               "stage_ms": r["sync"]["stage_ms"], "dominant_stage": r["sync"]["dominant_stage"],
+                               "hbm_algorithmic_frac_synchronous": r["sync"]["algorithmic_frac_of_8TBs"],
+                               "hbm_algorithmic_frac_on_lanes": r["lanes"]["algorithmic_frac_of_8TBs"],
+                               "mean_keypoints": r["sync"]["mean_keypoints"], "mean_nmatches": r["sync"]["mean_nmatches"],
+                               "checked": BC.check(cfg, device=local_rank)}
+                bf, bf_data = BC.measure_bf(steps=20, device=local_rank)
+                oc["bf_2000x2000"] = {"us_per_2000x2000": bf["ms_per_2000x2000"] * 1e3, "descriptor_pairs_per_s": bf["descriptor_pairs_per_s"],
+                                      "frac_of_4.9T_popcount_bound": bf["frac_of_4.9T_pairs_per_s"],
+                                      "frac_of_3.3T_bcnt_issue_bound": bf["frac_of_3.3T_pairs_per_s"], "sets_per_call": bf["sets_per_call"],
+                                      "nmatches": bf["nmatches"], "checked": BC.check_bf(bf_data)}
+                out["other_configs"] = oc
+                if not all(v["checked"] for v in oc.values()):
+                    check_ok = False
+            except Exception as ex:  # never let them break the line
+                out["other_configs"] = {"error": str(ex)[:300]}
         if not args.no_cpu_baseline and world == 1:  # (the CPU baseline is an N = 1 figure: rank 0's host cores, one GPU beside it)
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O
@@ -466,8 +524,10 @@ def main():
                                    "all_cores": allc, "one_core": one, "all_cores_march_native": alln}
             out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if coll:
         dist.destroy_process_group()
+    if check_ok is False:
+        raise SystemExit(3)  # (the line above says what differed)
 
 
 if __name__ == "__main__":

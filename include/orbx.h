@@ -83,7 +83,8 @@ void orbx_destroy(orbx_ctx* ctx);
  *   gray_variant      cv::cvtColor RGB/BGR -> gray on 8-bit (Converter.cpp:11-13):
  *     ORBX_GRAY_14BIT (default)             (R*4899 + G*9617 + B*1868 + 2^13) >> 14: OpenCV 3.x .. 4.0
  *     ORBX_GRAY_15BIT                       (R*9798 + G*19235 + B*3735 + 2^14) >> 15: OpenCV >= 4.1
- * Takes effect for the calls that follow (batches in flight are waited for). */
+ * Takes effect for the calls that follow (batches in flight are waited for; like every call that has to wait for an earlier
+ * stream-ordered batch, this one returns that batch's error WITHOUT having done its own work: call it again). */
 #define ORBX_GAUSS_ERROR_DIFFUSION 0
 #define ORBX_GAUSS_ROUNDED 1
 #define ORBX_GRAY_14BIT 0
@@ -176,8 +177,9 @@ int orbx_extract_match_batch_device_async(orbx_ctx* ctx, int n_frames, const uin
  * streams, at most two batches in flight.  depth >= 1: the context keeps `depth` lanes (each with its own stream and its own
  * copy of the internal buffers, sized like the context) and every stream-ordered batch goes, whole, to the next lane; at most
  * `depth` batches are in flight (the call that would exceed it first waits for the oldest), so batches in flight together need
- * `depth` different output arrays.  Whole batches on four lanes measure 304 k frames/s against 296 k with the two halves at
- * 256 frames 640x480 per batch, and 230 k against 126 k at 32 frames per batch on three lanes (MI355X).  Waits for everything in flight; 0 <= depth <= 8; costs depth times the context's
+ * `depth` different output arrays.  Whole batches on four lanes measure 341 k frames/s against 323 k with the two halves at
+ * 256 frames 640x480 per batch, and 239 k against 109 k at 32 frames per batch on three lanes (MI355X, rounds 3-4).  Waits for
+ * everything in flight (and returns an earlier batch's error without changing the depth: call it again); 0 <= depth <= 8; costs depth times the context's
  * device memory; not available (ORBX_E_BADARG) on a context created on a caller's stream, whose order the lanes' own streams could
  * not keep.  orbx_download_pyramid and the profile / debug hooks of the context keep referring to the batches the context
  * ran itself (synchronous calls, depth 0); orbx_profile_get adds what the lanes ran.  (The reference has no counterpart: it
@@ -281,7 +283,12 @@ int orbx_profile_get(orbx_ctx* ctx, double* ms, int64_t* launches);
 /* ---- several MI355X from one host process ---------------------------------------- */
 /* One orbx_ctx per device; a batch is cut into contiguous even-sized blocks, one per device (consecutive pairs (2k, 2k + 1)
  * never straddle devices); the only exchange is an ncclAllGather of the per-frame keypoint counts over xGMI.  RCCL is loaded
- * with dlopen when a context with more than one device is created (ORBX_E_RCCL if that fails); device ids must be distinct. */
+ * with dlopen when a context with more than one device is created (ORBX_E_RCCL if that fails); device ids must be distinct.
+ * ORBX_MULTI_FORCE_RCCL=1 in the environment makes a ONE-device context go through RCCL as well (dlopen, ncclCommInitAll(1),
+ * grouped ncclAllGather on the collective stream, ncclCommDestroy): the way to exercise these code paths on a one-GPU box.
+ * If a device fails to queue its block of a batch, the batches issued before it are still completed as documented below
+ * (blocks waited for, counts gathered into their counts_all) before the call returns the error; only the partly issued batch
+ * is dropped. */
 typedef struct orbx_multi orbx_multi;
 int orbx_multi_create(const orbx_params* params, int n_devices, const int* device_ids, int max_width, int max_height,
                       int max_batch_per_device, orbx_multi** out);

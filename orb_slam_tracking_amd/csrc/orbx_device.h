@@ -11,6 +11,15 @@
 #define ORBX_GRID_COLS 64     // FRAME_GRID_COLS, SlamTypes/Frame.hpp:16
 #define ORBX_GRID_ROWS 48     // FRAME_GRID_ROWS, SlamTypes/Frame.hpp:15
 
+// Wave priority of the latency-bound kernels (quadtree selection, Jacobi matcher, banded pyramid): their ~90 barrier-separated
+// phases issue a few instructions each and then wait; on the lanes they share every SIMD with the issue-bound FAST / descriptor
+// waves of other batches, behind which their few instructions queue.  ORBX_PRIO=n (build flag, experiment of round 4) raises them.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ORBX_PRIO)
+#define ORBX_SETPRIO() __builtin_amdgcn_s_setprio(ORBX_PRIO)
+#else
+#define ORBX_SETPRIO() do {} while (0)
+#endif
+
 namespace orbx {
 
 // geometry of one pyramid level for the current frame size
@@ -226,7 +235,7 @@ struct CamD {
 constexpr int MW_CAP = 4096;  // octave-0 queries / eligible trains per pair the wide path takes
 constexpr int MW_CP = 128;    // candidates listed per query (a fuller window hands the pair to k_match)
 constexpr int MW_CXS = 80;    // behind the top rows and the queries' column order: start slot of every grid column's trains (65 used)
-constexpr int MW_TOPK = 4;   // per query, behind its list: the four best candidates by (distance, candidate order), sorted (k_match_wide_resolve)
+constexpr int MW_TOPK = 4;   // four spare rows behind every query's list (round 3 kept the best candidates there; the lists are sorted in place now)
 constexpr int MW_HDR = 16;    // [0] nQ, [1] nT, [2] 1 = too large for the wide path, [3] != 0 = a list overflowed, [4..7] bounding box of the eligible trains (float bits: min x, max x, min y, max y), [8] 1 = trains stored by grid column (matchWidePrep)
 inline int matchWideCap(int capacity) { return capacity < MW_CAP ? capacity : MW_CAP; }
 inline long long matchScratchStride(int capacity) {

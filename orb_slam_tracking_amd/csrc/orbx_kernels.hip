@@ -290,6 +290,7 @@ __global__ __launch_bounds__(PYR_T) void k_pyramid_bands(const uint8_t* __restri
                                                        const uint4* __restrict__ ptab, const PyrBands pb) {
   // the band's PyrYRow entries of the current level (and, filled meanwhile, of the next one): a step's row constants then
   // cost an LDS read instead of a global load in front of the source loads that depend on them
+  ORBX_SETPRIO();
   extern __shared__ uint4 yrows[];  // [2][pb.maxRows]
   const int f = blockIdx.y + g.frame0, band = blockIdx.x, tid = threadIdx.x;
   const int nl = g.nlevels;
@@ -1651,6 +1652,7 @@ __global__ __launch_bounds__(MJ_CAP * MJ_P) void k_match_jacobi(const int* __res
                                                                int* __restrict__ scratch, long long scratchStride, int capl,
                                                                int* __restrict__ hostWide) {
   constexpr int MJ_T = MJ_CAP * MJ_P;
+  ORBX_SETPRIO();
   __shared__ float2 tXY[MJ_CAP];
   __shared__ float tAng[MJ_CAP];
   __shared__ uint4 tDesc[MJ_CAP][2];  // a train's 256 bits: two 16-byte reads per distance
@@ -2382,6 +2384,66 @@ __global__ __launch_bounds__(256) void k_match_wide_lists(const int* __restrict_
   }
 }
 
+// k_match_wide_sort: every query's candidate list (k_match_wide_lists: at most MW_CP entries in no particular order) sorted by
+// the comparison key (distance, reference candidate order = cell << 20 | F2 index), a wave per query (sixteen queries per
+// workgroup), over the whole GPU.  k_match_wide_resolve then walks a list from its head and stops at the second candidate that no
+// earlier query hides: a sweep touches a few entries per query instead of all ~100 (the synthetic 1080p scene repeats its corners:
+// half of the queries found fewer than two visible candidates among their four best and re-read their whole list in every sweep
+// -- 140 us for eight pairs on eight CUs).
+static_assert(MW_CP == 128, "k_match_wide_sort: two list entries per lane");
+__global__ __launch_bounds__(256) void k_match_wide_sort(const MatchParams mp, const int* __restrict__ nmatchesOut, int* __restrict__ scratch,
+                                                        long long scratchStride, int capl) {
+  const int lane = threadIdx.x & 63;
+  const int pair = blockIdx.y + mp.pair0;
+  if (nmatchesOut[pair] != MATCH_PENDING) return;
+  int* S = scratch + (long long)pair * scratchStride;
+  if (S[2] | S[3]) return;  // (the reference's loop takes the pair: k_match_wide_resolve)
+  const uint4* trec = reinterpret_cast<const uint4*>(S + MW_HDR);
+  const int nQ = S[0];
+  for (int qi = 0; qi < 4; qi++) {  // (four queries per wave: a quarter of the workgroups, most of which find no query at all)
+  const int q = blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + qi;
+  if (q >= nQ) return;
+  const int nc = S[MW_HDR + 5 * capl + q] & 0xffff;
+  if (nc < 2) continue;
+  uint32_t* myList = reinterpret_cast<uint32_t*>(S + MW_HDR + 6 * capl) + q;
+  unsigned long long v[2];
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const int k = 2 * lane + e;
+    v[e] = ~0ull;
+    if (k < nc) {
+      const uint32_t ce = myList[(size_t)k * capl];
+      const uint32_t slot = ce & 0xffffu;
+      v[e] = ((unsigned long long)(ce >> 16) << 44) | ((unsigned long long)trec[slot].w << 12) | (unsigned long long)slot;
+    }
+  }
+  static_assert(MW_CAP <= 4096, "twelve slot bits in k_match_wide_sort's keys");
+  // bitonic sort of 128 keys, two per lane (lane t owns 2 t, 2 t + 1): partner lanes by shuffle, the pair in registers
+  for (int k = 2; k <= 128; k <<= 1) {
+    for (int j = k >> 1; j >= 2; j >>= 1) {
+      const int lm = j >> 1;
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const int i = 2 * lane + e;
+        const unsigned long long o = ((unsigned long long)__shfl_xor((uint32_t)(v[e] >> 32), lm) << 32) | __shfl_xor((uint32_t)v[e], lm);
+        const bool keepMin = ((i & j) == 0) == ((i & k) == 0);
+        v[e] = keepMin ? (o < v[e] ? o : v[e]) : (o > v[e] ? o : v[e]);
+      }
+    }
+    const bool asc = ((2 * lane) & k) == 0;
+    const unsigned long long x = v[0], y = v[1];
+    const bool sw = (x > y) == asc;
+    v[0] = sw ? y : x;
+    v[1] = sw ? x : y;
+  }
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const int k = 2 * lane + e;
+    if (k < nc) myList[(size_t)k * capl] = ((uint32_t)(v[e] >> 44) << 16) | (uint32_t)(v[e] & 0xfffu);
+  }
+  }
+}
+
 __global__ __launch_bounds__(MW_T) void k_match_wide_resolve(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
                                                             const orbx_keypoint* __restrict__ kps,
                                                             const uint8_t* __restrict__ desc, const int* __restrict__ nkp,
@@ -2411,17 +2473,11 @@ __global__ __launch_bounds__(MW_T) void k_match_wide_resolve(const int* __restri
   const int* qIdx = S + MW_HDR + 4 * capl;
   const int* cntIn = S + MW_HDR + 5 * capl;
   const uint32_t* lists = reinterpret_cast<const uint32_t*>(S + MW_HDR + 6 * capl);
-  // behind the MW_CP list rows: MW_TOPK rows with every query's best candidates by (distance, candidate order), ascending --
-  // written by the query's first full scan.  A later sweep only needs the first two of them that no earlier query hides
-  // (best, and the distance of the second); only a query that finds fewer than two among its top ones re-reads its whole list.
-  // (A sweep used to re-read all lists: a dozen dependent L2 round trips per sweep, 170 us for eight 1080p pairs.)
-  uint32_t* top = reinterpret_cast<uint32_t*>(scratch + (long long)pair * scratchStride + MW_HDR + 6 * capl) + (size_t)MW_CP * capl;
   const int fa = pairFirst[pair], fb = pairSecond[pair];
   const int cap = mp.capacity;
   const orbx_keypoint* k1 = kps + (long long)fa * cap;
   const orbx_keypoint* k2 = kps + (long long)fb * cap;
   int* m12 = matches12 + (long long)pair * cap;
-  unsigned topReady = 0;  // bit rr: the top rows of query t + rr * MW_T are written
 
   if (t == 0) { sNm = 0; sBadDist = 0; sBadRatio = 0; sBadOri = 0; }
   if (t < HISTO_LENGTH) hist[t] = 0;
@@ -2455,8 +2511,6 @@ __global__ __launch_bounds__(MW_T) void k_match_wide_resolve(const int* __restri
       const int nc = nCand[rr];
       if (!hasCand[rr]) continue;  // vIndices2.empty() -> continue (ORBmatcher.cpp:46-47): outcome stays 0
       const uint32_t* myList = lists + q;
-      unsigned long long best = MATCH_NONE;  // dist << 32 | cell << 20 | train index
-      int second = INF_DIST, bt = 0;
       // vMatchedDistance[e] as query q sees it: smallest distance of an earlier accepted query that chose e
       auto hiddenBelow = [&](int hd) {
         int md = INF_DIST;
@@ -2467,78 +2521,27 @@ __global__ __launch_bounds__(MW_T) void k_match_wide_resolve(const int* __restri
         }
         return md;
       };
-      bool fromTop = false;
-      if ((topReady & (1u << rr)) && nc > 0) {  // (a query whose window trains all lie at dmax or beyond has no top rows: its empty list is "re-read")
-        uint32_t tc[MW_TOPK], ord[MW_TOPK];
-        int hd[MW_TOPK];
-        const int tn = min(nc, MW_TOPK);
+      // the list is sorted by (distance, candidate order) (k_match_wide_sort): the first candidate no earlier query hides is the
+      // best one, the next such carries the second-smallest distance -- nothing behind it matters
+      int found = 0, bd = 0, bt = 0, second = INF_DIST;
+      for (int k = 0; k < nc && found < 2; k += 4) {
+        uint32_t ce[4];
+        int hd[4];
 #pragma unroll
-        for (int j = 0; j < MW_TOPK; j++) tc[j] = top[(size_t)min(j, tn - 1) * capl + q];
+        for (int j = 0; j < 4; j++) ce[j] = myList[(size_t)min(k + j, nc - 1) * capl];
 #pragma unroll
-        for (int j = 0; j < MW_TOPK; j++) { hd[j] = head[tc[j] & 0xffff]; ord[j] = tOrd[tc[j] & 0xffff]; }
-        int found = 0;
+        for (int j = 0; j < 4; j++) hd[j] = head[ce[j] & 0xffff];
 #pragma unroll
-        for (int j = 0; j < MW_TOPK; j++) {
-          if (j >= tn || found == 2) break;
-          const int e = tc[j] & 0xffff, dist = (int)(tc[j] >> 16);
+        for (int j = 0; j < 4; j++) {
+          if (k + j >= nc || found == 2) break;
+          const int e = ce[j] & 0xffff, dist = (int)(ce[j] >> 16);
           if (hiddenBelow(hd[j]) <= dist) continue;  // ORBmatcher.cpp:67
-          if (found == 0) { best = ((unsigned long long)dist << 32) | ord[j]; bt = e; }
-          else second = dist;  // sorted by (distance, order): the second visible one carries the second-smallest distance
+          if (found == 0) { bd = dist; bt = e; } else second = dist;
           found++;
-        }
-        fromTop = found == 2 || nc <= MW_TOPK;  // (all of a short list is in the top rows)
-        if (!fromTop) { best = MATCH_NONE; second = INF_DIST; bt = 0; }
-      }
-      if (!fromTop) {
-        const bool record = !(topReady & (1u << rr));
-        unsigned long long tk[MW_TOPK];  // the MW_TOPK smallest keys seen, ascending, and their list entries
-        uint32_t tce[MW_TOPK];
-#pragma unroll
-        for (int j = 0; j < MW_TOPK; j++) { tk[j] = MATCH_NONE; tce[j] = 0u; }
-        for (int k = 0; k < nc; k += 4) {
-          uint32_t ce[4], ord[4];
-          int hd[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) ce[j] = myList[(size_t)min(k + j, nc - 1) * capl];
-#pragma unroll
-          for (int j = 0; j < 4; j++) { hd[j] = head[ce[j] & 0xffff]; ord[j] = tOrd[ce[j] & 0xffff]; }
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            if (k + j >= nc) break;
-            const int e = ce[j] & 0xffff, dist = (int)(ce[j] >> 16);
-            const unsigned long long key = ((unsigned long long)dist << 32) | ord[j];
-            if (record && key < tk[MW_TOPK - 1]) {  // insertion into the sorted top entries (keys are unique: the order holds the index)
-              unsigned long long ck = key;
-              uint32_t cc = ce[j];
-#pragma unroll
-              for (int u = 0; u < MW_TOPK; u++) {
-                const bool sw = ck < tk[u];
-                const unsigned long long ok = tk[u];
-                const uint32_t oc = tce[u];
-                tk[u] = sw ? ck : ok; tce[u] = sw ? cc : oc;
-                ck = sw ? ok : ck; cc = sw ? oc : cc;
-              }
-            }
-            if (hiddenBelow(hd[j]) <= dist) continue;  // ORBmatcher.cpp:67
-            if (key < best) {
-              second = min(second, (int)(best >> 32));
-              best = key;
-              bt = e;
-            } else {
-              second = min(second, dist);
-            }
-          }
-        }
-        if (record) {
-#pragma unroll
-          for (int j = 0; j < MW_TOPK; j++)
-            if (j < nc) top[(size_t)j * capl + q] = tce[j];
-          topReady |= 1u << rr;
         }
       }
       int nOutcome, nBestT = -1, nBestD = 0;
-      const int bd = (int)(best >> 32);
-      if (best == MATCH_NONE || bd > TH_LOW) nOutcome = 1;
+      if (found == 0 || bd > TH_LOW) nOutcome = 1;
       else if ((float)bd > mp.nnratio * (float)second) nOutcome = 2;
       else { nOutcome = 3; nBestT = bt; nBestD = bd; }
       changed |= nOutcome != outcome[rr] || nBestT != bestT[rr] || nBestD != bestD[rr];
@@ -2975,6 +2978,7 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
   if (wideMode != 0) {
     hipLaunchKernelGGL(k_match_wide_lists, dim3((capl + 63) / 64, nPairs), dim3(256), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
                        nmatches, scratch, scratch, stride, capl);
+    hipLaunchKernelGGL(k_match_wide_sort, dim3((capl + 15) / 16, nPairs), dim3(256), 0, st, mp, nmatches, scratch, stride, capl);
     hipLaunchKernelGGL(k_match_wide_resolve, dim3(nPairs), dim3(MW_T), lds, st, dFirst, dSecond, kps, desc, nkp, mp, matches12,
                        nmatches, stats, scratch, stride, capl);
   }

@@ -12,6 +12,7 @@
 
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -94,7 +95,10 @@ struct orbx_multi {
   int n = 0;
   std::vector<int> dev;
   std::vector<orbx_ctx*> ctx;
-  std::vector<ncclComm_t> comm;       // n > 1 only
+  std::vector<ncclComm_t> comm;       // useRccl only
+  bool useRccl = false;               // n > 1, or ORBX_MULTI_FORCE_RCCL=1: a one-rank communicator on one device (the RCCL code
+                                      // paths -- dlopen, ncclCommInitAll, grouped ncclAllGather, destroy -- on a one-GPU box)
+  int32_t* hAll = nullptr;            // pinned [padCap * n]: device 0's copy of the gathered counts lands here
   std::vector<hipStream_t> st;        // one stream per device for the collective
   std::vector<int32_t*> dSend, dRecv; // per device: counts of its block (padded), counts of all blocks
   int padCap = 0;                     // entries per block in the gather buffers
@@ -172,7 +176,7 @@ int gatherCounts(orbx_multi* m, const Batch& B) {
     if (nb > 0 && hipMemcpyAsync(m->dSend[r], B.dN[r], sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToDevice, m->st[r]) != hipSuccess)
       return ORBX_E_HIP;
   }
-  if (n > 1) {
+  if (m->useRccl) {
     if (g_rccl.GroupStart() != 0) return ORBX_E_RCCL;
     for (int r = 0; r < n; r++) {
       const ncclResult_t q = g_rccl.AllGather(m->dSend[r], m->dRecv[r], (size_t)per, kNcclInt32, m->comm[r], m->st[r]);
@@ -187,15 +191,16 @@ int gatherCounts(orbx_multi* m, const Batch& B) {
     if (hipMemcpyAsync(m->dRecv[0], m->dSend[0], sizeof(int32_t) * (size_t)per, hipMemcpyDeviceToDevice, m->st[0]) != hipSuccess)
       return ORBX_E_HIP;
   }
-  std::vector<int32_t> all((size_t)per * n);
+  // device 0's copy comes back into page-locked memory (an asynchronous copy command: nothing above has been waited for yet);
+  // only then are the devices' collective streams synchronised, one after the other -- all of them have been running meanwhile
+  if (hipSetDevice(m->dev[0]) != hipSuccess) return ORBX_E_HIP;
+  if (hipMemcpyAsync(m->hAll, m->dRecv[0], sizeof(int32_t) * (size_t)per * n, hipMemcpyDeviceToHost, m->st[0]) != hipSuccess) return ORBX_E_HIP;
   for (int r = 0; r < n; r++) {
     if (hipSetDevice(m->dev[r]) != hipSuccess) return ORBX_E_HIP;
-    if (r == 0 && hipMemcpyAsync(all.data(), m->dRecv[0], sizeof(int32_t) * all.size(), hipMemcpyDeviceToHost, m->st[0]) != hipSuccess)
-      return ORBX_E_HIP;
     if (hipStreamSynchronize(m->st[r]) != hipSuccess) return ORBX_E_HIP;  // every device's copy of the counts is complete
   }
   for (int r = 0; r < n; r++)
-    for (int f = B.lo[r]; f < B.hi[r]; f++) B.countsAll[f] = all[(size_t)r * per + (f - B.lo[r])];
+    for (int f = B.lo[r]; f < B.hi[r]; f++) B.countsAll[f] = m->hAll[(size_t)r * per + (f - B.lo[r])];
   return ORBX_OK;
 }
 
@@ -236,6 +241,7 @@ void orbx_multi_destroy(orbx_multi* m) {
     if (r < (int)m->st.size() && m->st[r]) (void)hipStreamDestroy(m->st[r]);
     if (r < (int)m->ctx.size() && m->ctx[r]) orbx_destroy(m->ctx[r]);
   }
+  if (m->hAll) (void)hipHostFree(m->hAll);
   delete m;
 }
 
@@ -264,7 +270,15 @@ int orbx_multi_create(const orbx_params* params, int n_devices, const int* devic
       return ORBX_E_HIP;
     }
   }
-  if (n_devices > 1) {
+  if (hipHostMalloc((void**)&m->hAll, sizeof(int32_t) * (size_t)m->padCap * n_devices, hipHostMallocDefault) != hipSuccess) {
+    orbx_multi_destroy(m);
+    return ORBX_E_HIP;
+  }
+  {
+    const char* force = getenv("ORBX_MULTI_FORCE_RCCL");
+    m->useRccl = n_devices > 1 || (force && force[0] && force[0] != '0');
+  }
+  if (m->useRccl) {
     std::string e;
     if (!g_rccl.load(&e)) { orbx_multi_destroy(m); return ORBX_E_RCCL; }
     m->comm.assign(n_devices, nullptr);
@@ -334,15 +348,25 @@ int orbx_multi_extract_match_batch_device_async(orbx_multi* m, int n_frames, con
     push(*m->workers[r], c);
   }
   int rcAll = ORBX_OK;
+  std::string errIssue;
   for (int r = 0; r < n; r++) {
     std::string e;
     const int rc = B.hi[r] - B.lo[r] == 0 ? ORBX_OK : drain(*m->workers[r], &e);
-    if (rc != ORBX_OK && rcAll == ORBX_OK) { rcAll = rc; m->err = e; }
+    if (rc != ORBX_OK && rcAll == ORBX_OK) { rcAll = rc; errIssue = e; }
   }
-  if (rcAll != ORBX_OK) {  // some block was not issued: drain what the other devices have queued for this batch and forget it
+  if (rcAll != ORBX_OK) {
+    // Some block of THIS batch was not issued.  The batches issued before it are complete batches: they are finished as
+    // usual -- blocks waited for, counts gathered into their counts_all, their own errors reported (the first one wins over
+    // the issue error: it is older) -- and only what the other devices queued for this batch is drained and forgotten.
+    int older = ORBX_OK;
+    std::string errOlder;
+    while (!m->inflight.empty()) {
+      const int w = orbx_multi_wait_one(m);
+      if (w != ORBX_OK && older == ORBX_OK) { older = w; errOlder = m->err; }
+    }
     for (int r = 0; r < n; r++) (void)orbx_wait(m->ctx[r]);
-    m->inflight.clear();
-    return rcAll;
+    m->err = older != ORBX_OK ? errOlder : errIssue;
+    return older != ORBX_OK ? older : rcAll;
   }
   m->inflight.push_back(B);
   return ORBX_OK;

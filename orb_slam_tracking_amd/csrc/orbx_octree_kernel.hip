@@ -116,6 +116,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
                                                      const OctLaunch P, SelKp* __restrict__ selStage,
                                                      int* __restrict__ nselLevel, uint8_t* __restrict__ scratch,
                                                      int* __restrict__ maxN, int deferBig, int level0) {
+  ORBX_SETPRIO();
   constexpr int MCAP = 4 * QMAX, FCAP = 2 * QMAX;
   static_assert((NMAX & (NMAX - 1)) == 0 && (MCAP & (MCAP - 1)) == 0, "sort buffers must be powers of two");
   // LDS budget (QMAX 256): NMAX 2048: 16 + 8 + 4 + 6 + 2 + 3 KB = 39 KB -> FOUR workgroups per CU (it was 51 KB and three

@@ -297,6 +297,34 @@ def test_multi_c_abi_async_one_device(orbx, c4_oracle, depth):
     _multi_async_run(orbx, [0], c4_oracle, depth, nbatch=4, n_frames=64)
 
 
+def test_multi_c_abi_forced_rccl_one_device(orbx, c4_oracle, monkeypatch):
+    """ORBX_MULTI_FORCE_RCCL=1: a ONE-device orbx_multi context goes through RCCL -- dlopen(librccl.so), ncclCommInitAll(1), a
+    grouped ncclAllGather of the counts on the collective stream per batch, ncclCommDestroy -- so these code paths run on a
+    one-GPU box too (they used to see their first execution on the driver's 8-GPU node).  The synchronous form and the
+    stream-ordered form (three lanes, batches in flight) must both give the oracle's counts, blocks and pairs."""
+    import torch
+    torch.cuda.init()
+    monkeypatch.setenv("ORBX_MULTI_FORCE_RCCL", "1")
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    _multi_run(orbx, [0], 64, c4_oracle)
+    assert "librccl" in open("/proc/self/maps").read(), "RCCL was not loaded: the forced path did not run"
+    _multi_async_run(orbx, [0], c4_oracle, 3, nbatch=4, n_frames=64)
+    _multi_async_run(orbx, [0], c4_oracle, 0, nbatch=3, n_frames=64)
+
+
+def test_bench_force_collective_one_rank(orbx):
+    """`bench.py --gpus 1 --force-collective`: the nccl (RCCL) process group with ONE rank, the counts all-gathered every step as the
+    N > 1 runs do -- the line says backend nccl, one RCCL rank, gathered counts equal the rank's own."""
+    out = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-collective", "--steps", "5", "--warmup", "2",
+                "--prime", "4", "--regions", "1", "--no-cpu-baseline", "--no-single-frame", "--no-other-configs"],
+               env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    d = _bench_line(out)
+    c = d["config"]["collective"]
+    assert d["n_gpus"] == 1 and d["checked"] is True, d["check"]
+    assert c["backend"] == "nccl" and c["world_size"] == 1 and c["all_gathers"] >= 5 and c["gathered_counts_ok"] is True
+    assert d["config"]["rccl_ranks"] == 1
+
+
 def test_multi_c_abi_async_rccl(orbx, c4_oracle):
     import torch
     n = torch.cuda.device_count()

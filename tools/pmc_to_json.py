@@ -50,7 +50,8 @@ def main():
     import os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import kernel_sources_sha16
-    json.dump({"source": note, "frames_per_launch": frames, "kernel_sources_sha16": kernel_sources_sha16(),
+    from bench import PMC_WORKLOAD
+    json.dump({"source": note, "workload": PMC_WORKLOAD, "frames_per_launch": frames, "kernel_sources_sha16": kernel_sources_sha16(),
                "formula": "valu_issue_cycles = 4 x (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2); valu_frac = valu_issue_cycles x frames / "
                           "launch duration / (256 CUs x 4 SIMDs x 2.4 GHz); bytes = FETCH_SIZE / WRITE_SIZE x 1024 (raw)",
                "per_frame": per_frame}, open(dst, 'w'), indent=1)
