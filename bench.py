@@ -462,8 +462,26 @@ def main():
             t2 = time.perf_counter()
             out["single_frame"] = {"extract_ms_per_frame": (t1 - t0) / nrep * 1e3, "match_ms_per_pair": (t2 - t1) / nrep * 1e3,
                                    "frames_per_s_extract_only": nrep / (t1 - t0),
-                                   "note": "synchronous host-buffer calls, one 640x480 frame (orbx_extract) / one pair (orbx_match_init) per call"}
+                                   "note": "synchronous host-buffer calls, one 640x480 frame (orbx_extract) / one pair (orbx_match_init) per call, "
+                                           "through the ctypes binding; cpp_shim: the same two calls as the reference makes them "
+                                           "(Frame.cpp:58-60, demo_initialization.cpp:105-108) through include/orbx_shim.hpp from C++ "
+                                           "(tests/cpp/shim_latency.cpp, medians of 300 calls)"}
             e1.close()
+            try:  # the drop-in call from C++: g++ builds the small harness against liborbx.so
+                import subprocess
+                import tempfile
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from test_host import build_shim_latency
+                with tempfile.TemporaryDirectory() as td:
+                    exe = build_shim_latency(orbx.lib_path(), td)
+                    fa, fb = os.path.join(td, "a.raw"), os.path.join(td, "b.raw")
+                    frames[0].tofile(fa)
+                    frames[1].tofile(fb)
+                    r = subprocess.run([exe, str(W), str(H), fa, fb, "1000", "20", "7", "300"], stdout=subprocess.PIPE,
+                                       stderr=subprocess.PIPE, text=True, timeout=120)
+                    out["single_frame"]["cpp_shim"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-200:]}
+            except Exception as ex:
+                out["single_frame"]["cpp_shim"] = {"error": str(ex)[:200]}
         except Exception as ex:  # never let the second figure break the line
             out["single_frame"] = {"error": str(ex)[:200]}
         # BASELINE configurations 3 and 5 and config 5's 2000 x 2000 brute-force match: rates of the same

@@ -30,6 +30,11 @@ extern "C" {
 #define ORBX_E_EMPTY (-1)
 #define ORBX_E_BADARG (-2)
 #define ORBX_E_TOOSMALL (-3) /* a pyramid level is narrower than one FAST cell: UB upstream (cpp:1071-1074) */
+/* Documented deviation: a frame wider or taller than ORBX_MAX_FRAME_DIM pixels returns ORBX_E_BADARG (orbx_last_error says so).
+ * The reference has no such limit (Features/ORBextractor.cpp:1531-1545 takes any cv::Mat); here a FAST candidate is one 32-bit
+ * word -- x and y in 12 bits each, the score in 8 -- and the selection kernels' path-code tables are indexed by those
+ * coordinates.  4096 x 4096 covers every BASELINE configuration (the largest is 3840 x 2160). */
+#define ORBX_MAX_FRAME_DIM 4096
 #define ORBX_E_HIP (-4)
 #define ORBX_E_CAPACITY (-5)
 #define ORBX_E_RCCL (-6)     /* the multi-device context could not load / initialise RCCL, or a collective failed */
@@ -64,7 +69,8 @@ typedef struct orbx_ctx orbx_ctx;
 /* ---- lifetime ---------------------------------------------------------------------------- */
 /* Creates a context on `device_id` sized for batches of up to `max_batch` frames of up to
  * max_width x max_height pixels.  The sizes are an initial reservation, not a limit: like
- * ORBextractor::operator() (cpp:1531-1545), every extraction entry point takes any frame size, and a call
+ * ORBextractor::operator() (cpp:1531-1545), every extraction entry point takes any frame size up to ORBX_MAX_FRAME_DIM in either
+ * direction (see there), and a call
  * that brings a larger frame or batch drains what is in flight and re-allocates the context's buffers
  * (a one-off cost of milliseconds; results are unaffected).  `stream` is an optional hipStream_t (as
  * void*) the caller wants the work issued on (e.g. torch's current stream); NULL = the ctx creates its own.
@@ -106,6 +112,13 @@ int orbx_get_umax(const orbx_ctx* ctx, int32_t* umax16);
  * (keypoints 28 B, descriptors 32 B each). */
 int orbx_extract(orbx_ctx* ctx, const uint8_t* img, int width, int height, int stride, int lap0, int lap1,
                  orbx_keypoint* kps, uint8_t* desc32, int capacity, int* n_out);
+
+/* Optional, for a host that keeps its frames in buffers of its own (a camera ring, a decoder's pool): page-locks [ptr, ptr + bytes)
+ * so that orbx_extract / orbx_extract_batch copy a frame out of it with one asynchronous DMA instead of through the runtime's
+ * staging copy of pageable memory (640x480: ~25 us of the call's ~100).  Thin wrappers over hipHostRegister / hipHostUnregister
+ * (a C++ host need not link HIP); the buffer must be unregistered before it is freed.  Results are the same either way. */
+int orbx_host_register(orbx_ctx* ctx, void* ptr, size_t bytes);
+int orbx_host_unregister(orbx_ctx* ctx, void* ptr);
 
 /* `n_frames` same-sized frames from host memory (frame f at imgs + f*frame_stride_bytes).
  * Outputs: frame f's keypoints at kps + f*capacity, descriptors at desc32 + f*capacity*32,

@@ -124,8 +124,10 @@ class ORBextractor {
     if (_image.empty()) return -1;  // cpp:1536
     cv::Mat image = _image.getMat();
     CV_Assert(image.type() == CV_8UC1);
-    std::vector<orbx_keypoint> k(std::max(capacity_, 1));
-    std::vector<uint8_t> d((size_t)std::max(capacity_, 1) * 32);
+    std::vector<orbx_keypoint>& k = scratchK_;  // (kept across calls: no allocation per frame)
+    std::vector<uint8_t>& d = scratchD_;
+    if (k.size() < (size_t)std::max(capacity_, 1)) k.resize(std::max(capacity_, 1));
+    if (d.size() < (size_t)std::max(capacity_, 1) * 32) d.resize((size_t)std::max(capacity_, 1) * 32);
     int n = 0;
     const int r = orbx_extract(ctx_, image.data, image.cols, image.rows, (int)image.step, vLappingArea[0], vLappingArea[1],
                                k.data(), d.data(), capacity_, &n);
@@ -148,8 +150,9 @@ class ORBextractor {
   int operator()(const orbx::Image8& image, const orbx::Image8& /*mask*/, std::vector<orbx::KeyPoint>& keypoints,
                  std::vector<uint8_t>& descriptors, std::vector<int>& vLappingArea) {
     if (image.empty()) return -1;  // cpp:1536
-    keypoints.assign(std::max(capacity_, 1), orbx::KeyPoint());
-    descriptors.assign((size_t)std::max(capacity_, 1) * 32, 0);
+    // (no zero-fill per call: the library overwrites the first n entries, and the vectors are cut to n below)
+    if (keypoints.size() < (size_t)std::max(capacity_, 1)) keypoints.resize(std::max(capacity_, 1));
+    if (descriptors.size() < (size_t)std::max(capacity_, 1) * 32) descriptors.resize((size_t)std::max(capacity_, 1) * 32);
     int n = 0;
     const int r = orbx_extract(ctx_, image.data, image.cols, image.rows, image.step, vLappingArea[0], vLappingArea[1],
                                reinterpret_cast<orbx_keypoint*>(keypoints.data()), descriptors.data(), capacity_, &n);
@@ -182,6 +185,14 @@ class ORBextractor {
   std::vector<int> inline GetNumFeaturesPerLevel() { return mnFeaturesPerLevel; }
 
   orbx_ctx* context() { return ctx_; }
+
+  // Optional: page-lock a frame buffer the host reuses (orbx_host_register) -- operator() then takes the image with one DMA
+  // instead of the runtime's staging copy.  Unpin before freeing the buffer.
+  void PinHostBuffer(void* ptr, size_t bytes) {
+    const int r = orbx_host_register(ctx_, ptr, bytes);
+    if (r != ORBX_OK) throw orbx::Error(r, orbx_last_error(ctx_));
+  }
+  void UnpinHostBuffer(void* ptr) { (void)orbx_host_unregister(ctx_, ptr); }
 
   // Drop-ins for the bodies of Frame::UndistortKeyPoints / Frame::ComputeImageBounds (SlamTypes/Frame.cpp:101-161):
   //   void Frame::UndistortKeyPoints() { mpORBextractor->UndistortKeyPoints(mvKeys, cam, mvKeysUn); N = mvKeysUn.size(); }
@@ -271,6 +282,8 @@ class ORBextractor {
   }
 #endif
   orbx_ctx* ctx_ = nullptr;
+  std::vector<orbx_keypoint> scratchK_;
+  std::vector<uint8_t> scratchD_;
   int nfeatures_, nlevels_, capacity_ = 0;
   std::vector<int> mnFeaturesPerLevel;
   std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;

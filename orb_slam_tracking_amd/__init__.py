@@ -84,6 +84,8 @@ def lib() -> ctypes.CDLL:
     L.orbx_get_tables.argtypes = [vp, vp, vp, vp, vp, vp]
     L.orbx_get_umax.argtypes = [vp, vp]
     L.orbx_extract.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]
+    L.orbx_host_register.argtypes = [vp, vp, sz]
+    L.orbx_host_unregister.argtypes = [vp, vp]
     L.orbx_extract_batch.argtypes = [vp, i32, vp, i32, i32, i32, sz, i32, i32, vp, vp, i32, vp, vp]
     L.orbx_extract_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, sz, vp, vp, i32, vp]
     L.orbx_level_size.argtypes = [vp, i32, vp, vp]

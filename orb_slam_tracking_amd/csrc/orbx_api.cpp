@@ -351,7 +351,10 @@ int buildGeometry(orbx_ctx* c, int w, int h, int stride0, Geom* out, std::vector
   for (int l = 0; l < g.nlevels; l++) {
     LevelGeom& L = g.L[l];
     levelSize(c, w, h, l, &L.w, &L.h);
-    if (L.w > 4096 || L.h > 4096) return ORBX_E_BADARG;
+    if (L.w > ORBX_MAX_FRAME_DIM || L.h > ORBX_MAX_FRAME_DIM) {  // (documented deviation, orbx.h: 12-bit candidate coordinates)
+      c->err = "frame larger than ORBX_MAX_FRAME_DIM (4096) pixels in width or height";
+      return ORBX_E_BADARG;
+    }
     L.maxBX = L.w - ORBX_EDGE + 3;
     L.maxBY = L.h - ORBX_EDGE + 3;
     const float width = (float)(L.maxBX - ORBX_MIN_BORDER), height = (float)(L.maxBY - ORBX_MIN_BORDER);
@@ -1621,6 +1624,19 @@ int orbx_extract(orbx_ctx* ctx, const uint8_t* img, int width, int height, int s
   int r = orbx_extract_batch(ctx, 1, img, width, height, stride, 0, lap0, lap1, kps, desc32, capacity, &n, &mono);
   if (n_out) *n_out = r == ORBX_OK ? n : 0;
   return r == ORBX_OK ? mono : r;
+}
+
+int orbx_host_register(orbx_ctx* ctx, void* ptr, size_t bytes) {
+  if (!ctx || !ptr || bytes == 0) return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return ORBX_OK;
+}
+int orbx_host_unregister(orbx_ctx* ctx, void* ptr) {
+  if (!ctx || !ptr) return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  HIPCHK(hipHostUnregister(ptr));
+  return ORBX_OK;
 }
 
 int orbx_level_size(const orbx_ctx* ctx, int level, int* width, int* height) {

@@ -2,7 +2,8 @@
 // (reference: ORBextractor::DistributeOctTree, Features/ORBextractor.cpp:698-1011; DivideNode cpp:617-676;
 //  compareNodes cpp:684-696; truncation to the level quota cpp:1159-1161; coordinate fix-up cpp:1165-1179).
 //
-// One workgroup per (frame, pyramid level).  Same array formulation as the host prototype in orbx_octree.cpp:
+// One workgroup per (frame, pyramid level) -- large units: a wave per bucket of keys, then one workgroup per unit (below).  The
+// array formulation (its host prototype lives under tests/cpp/host_quadtree.cpp, test infrastructure):
 // every candidate gets a path code (root index + one quadrant digit per depth); with the codes sorted, every tree
 // node is a contiguous range and the reference's std::list bookkeeping becomes arithmetic on common-prefix lengths.
 //

@@ -138,6 +138,28 @@ def test_edge_cases(orbx, ext640):
         orbx.ORBextractor(1000, 1.0, 8, 20, 7)  # exit(1) upstream (cpp:502-505)
 
 
+def test_frame_size_limit(orbx, oracle):
+    """ORBX_MAX_FRAME_DIM (documented deviation, include/orbx.h): a 4096-pixel-wide frame is taken and equals the oracle (nine
+    quadtree roots, 12-bit candidate coordinates used to the last column); 4100 pixels in either direction return ORBX_E_BADARG with a
+    message that names the limit -- not a crash, not a silent truncation."""
+    from orb_slam_tracking_amd import synth
+    params = (600, 1.2, 4, 20, 7)
+    e = orbx.ORBextractor(*params, max_width=640, max_height=480, max_batch=1)
+    oe = oracle.Extractor(*params)
+    f = synth.synth(4096, 300, 41)
+    (r, k, d), = e.extract_batch(f[None])
+    ro, ko, do = oe(f)
+    assert r == ro and len(k) > 300
+    _same(k, d, ko, do)
+    for (w, h) in ((4100, 300), (300, 4100)):
+        with pytest.raises(orbx.OrbxError) as ex:
+            e.extract_batch(synth.synth(w, h, 42)[None])
+        assert ex.value.code == orbx.E_BADARG and "4096" in str(ex.value)
+    (r, k, d), = e.extract_batch(f[None])  # the context is still usable
+    _same(k, d, ko, do)
+    e.close()
+
+
 def test_odd_sizes_and_fallback_cells(orbx, oracle):
     """Ragged geometry: odd widths, nIni == 2, dark low-contrast cells that need the minThFAST retry."""
     from orb_slam_tracking_amd import synth

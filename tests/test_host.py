@@ -179,6 +179,19 @@ def build_shim_demo(orbx, out_dir):
     return exe
 
 
+def build_shim_latency(lib_path, out_dir):
+    """Compiles tests/cpp/shim_latency.cpp: the reference's one-frame-per-call use of the C++ drop-in classes, timed (bench.py's
+    single_frame.cpp_shim)."""
+    import subprocess
+    exe = os.path.join(out_dir, "shim_latency")
+    libdir = os.path.dirname(lib_path)
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "shim_latency.cpp"),
+           "-L", libdir, "-lorbx", "-Wl,-rpath," + libdir, "-o", exe]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout
+    return exe
+
+
 def build_shim_opencv_frame(orbx, out_dir):
     """Compiles tests/cpp/shim_opencv_frame.cpp: the -DORBX_WITH_OPENCV branch of the shim (the reference's real cv::
     signatures) against the compile-check mock of six cv:: types in tests/cpp/mock_opencv (which pins nothing)."""
