@@ -23,7 +23,7 @@ namespace orbx {
 
 hipError_t launch_resize(hipStream_t st, int nFrames, const uint8_t* src, long long srcFrameStride, int sw, int sh, int sstride,
                          uint8_t* dst, long long dstFrameStride, int dw, int dh, int dstride, const ResizeTab* xtab,
-                         const ResizeTab* ytab, int dwordPath);
+                         const ResizeTab* ytab, int dwordPath, int wideFrames);
 hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, int img0Aligned,
                        const uint8_t* pyr, const Geom& g, uint32_t* cand, int* cellCount, const FastCell* cells, int waveOk,
                        int* usedWave);
@@ -1087,7 +1087,9 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
       const long long sfs = l == 1 ? a.frameStride0 : S.frameStride;
       HIPCHK(launch_resize(st, n, src + (long long)f0 * sfs, sfs, S.w, S.h, S.stride, ctx->dPyr + D.imgOff + (long long)f0 * D.frameStride,
                            D.frameStride, D.w, D.h, D.stride, ctx->dTab + D.xtabOff, ctx->dTab + D.ytabOff,
-                           D.resizeSpanOk && (l > 1 || a.aligned0)));
+                           D.resizeSpanOk && (l > 1 || a.aligned0),
+                           // (behind the pyramid buffer's levels there is slack; behind the caller's last frame nothing is known)
+                           l > 1 ? n : std::min(std::max(a.safeFrom - f0, 0), n)));
     }
     if (nl > 1) tm.stop(nl - 1);
     ctx->lastLaunch[0] = 0;

@@ -64,13 +64,14 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 }
 
 #define RESIZE_DW_ROWS 4  // output rows per thread of k_resize_dw
+struct __attribute__((aligned(4))) PyrU3 { uint32_t a, b, c; };  // 12 bytes from a 4-aligned address: one global_load_dwordx3
 // Same arithmetic, but the source taps of the 4 outputs are fetched as 3 aligned dwords per source row (the taps of
 // 4 consecutive outputs span at most 11 bytes from the aligned start when the scale is <= 2) instead of 8 byte loads,
 // and extracted with v_alignbyte.  Needs 4-byte aligned source rows; the launcher falls back to k_resize otherwise.
 __global__ __launch_bounds__(256) void k_resize_dw(const uint8_t* __restrict__ src, long long srcFrameStride, int sw, int sh,
                                                    int sstride, uint8_t* __restrict__ dst, long long dstFrameStride, int dw,
                                                    int dh, int dstride, const ResizeTab* __restrict__ xtab,
-                                                   const ResizeTab* __restrict__ ytab) {
+                                                   const ResizeTab* __restrict__ ytab, int wideFrames) {
   // RESIZE_DW_ROWS output rows per thread (rows dy, dy + 4, ...: a wave still covers whole row segments): the column taps -- 32
   // bytes of table per thread, eight times the bytes it stores per row -- are loaded once, and the rows' source dwords are all
   // in flight together
@@ -96,10 +97,21 @@ __global__ __launch_bounds__(256) void k_resize_dw(const uint8_t* __restrict__ s
     b0[k] = ty.coef & 0xffff; b1[k] = ty.coef >> 16;
     const uint8_t* S0 = S + (long long)sy0 * sstride;
     const uint8_t* S1 = S + (long long)sy1 * sstride;
-    r0a[k] = *reinterpret_cast<const uint32_t*>(S0 + o0); r0b[k] = *reinterpret_cast<const uint32_t*>(S0 + o1);
-    r0c[k] = *reinterpret_cast<const uint32_t*>(S0 + o2);
-    r1a[k] = *reinterpret_cast<const uint32_t*>(S1 + o0); r1b[k] = *reinterpret_cast<const uint32_t*>(S1 + o1);
-    r1c[k] = *reinterpret_cast<const uint32_t*>(S1 + o2);
+    // The group's taps lie in 12 bytes from the aligned start: ONE 12-byte load per source row (the texture addresser charges per
+    // instruction and lane -- 18 cycles for this load, 3 x 12 for three dwords at this pitch, tools/microbench/mem_rate.hip --
+    // and at 4K the launch was bound by it: 24 us per level, 0.9 TB/s).  It may read up to 11 bytes beyond the row's last pixel:
+    // the next row, the next frame, or the slack the buffers end with -- only behind the LAST row of the caller's last frame
+    // nothing is known to follow, so frames >= wideFrames take that row (a uniform branch per row) through clamped dwords.
+    if (f < wideFrames || sy1 < sh - 1) {
+      const PyrU3 u0 = *reinterpret_cast<const PyrU3*>(S0 + o0), u1 = *reinterpret_cast<const PyrU3*>(S1 + o0);
+      r0a[k] = u0.a; r0b[k] = u0.b; r0c[k] = u0.c;
+      r1a[k] = u1.a; r1b[k] = u1.b; r1c[k] = u1.c;
+    } else {
+      r0a[k] = *reinterpret_cast<const uint32_t*>(S0 + o0); r0b[k] = *reinterpret_cast<const uint32_t*>(S0 + o1);
+      r0c[k] = *reinterpret_cast<const uint32_t*>(S0 + o2);
+      r1a[k] = *reinterpret_cast<const uint32_t*>(S1 + o0); r1b[k] = *reinterpret_cast<const uint32_t*>(S1 + o1);
+      r1c[k] = *reinterpret_cast<const uint32_t*>(S1 + o2);
+    }
   }
 #pragma unroll
   for (int k = 0; k < RESIZE_DW_ROWS; k++) {
@@ -283,7 +295,6 @@ extern "C" int orbx_diag_pyr_stamps(uint32_t* out, int nWgs) {  // out: nWgs x 4
                     // against 201 of 256) and take three fat bands per frame (3.5 % shared rows instead of 11 % with seven)
 #endif
 #define PYR_R 2   // output rows in flight per thread and step
-struct __attribute__((aligned(4))) PyrU3 { uint32_t a, b, c; };  // 12 bytes from a 4-aligned address: one global_load_dwordx3
 template <int DUAL2>
 __global__ __launch_bounds__(PYR_T) void k_pyramid_bands(const uint8_t* __restrict__ img0, long long img0FrameStride,
                                                        uint8_t* __restrict__ pyr, const Geom g,
@@ -2857,11 +2868,12 @@ hipError_t launch_pyramid_tiles(hipStream_t st, int nFrames, const uint8_t* img0
 
 hipError_t launch_resize(hipStream_t st, int nFrames, const uint8_t* src, long long srcFrameStride, int sw, int sh, int sstride,
                          uint8_t* dst, long long dstFrameStride, int dw, int dh, int dstride, const ResizeTab* xtab,
-                         const ResizeTab* ytab, int dwordPath) {
+                         const ResizeTab* ytab, int dwordPath, int wideFrames) {
+  // wideFrames: frames of this launch behind whose last source row more memory is known to follow (k_resize_dw's 12-byte loads)
   dim3 block(64, 4, 1), grid((dw + 255) / 256, (dh + 3) / 4, nFrames);
   if (dwordPath)
     hipLaunchKernelGGL(k_resize_dw, dim3(grid.x, (dh + 4 * RESIZE_DW_ROWS - 1) / (4 * RESIZE_DW_ROWS), nFrames), block, 0, st, src, srcFrameStride, sw, sh, sstride, dst, dstFrameStride, dw, dh,
-                       dstride, xtab, ytab);
+                       dstride, xtab, ytab, wideFrames);
   else
     hipLaunchKernelGGL(k_resize, grid, block, 0, st, src, srcFrameStride, sw, sh, sstride, dst, dstFrameStride, dw, dh, dstride,
                        xtab, ytab);

@@ -79,3 +79,21 @@ typedef const _InputArray& InputArray;
 typedef const _OutputArray& OutputArray;
 
 }  // namespace cv
+
+// ---- additions for tools/pin_opencv/pin_opencv.cpp (compile check only; declarations, no definitions) ----
+#define CV_32F 5
+#define CV_64F 6
+#define CV_32FC2 13
+namespace cv {
+struct Size {
+  int width = 0, height = 0;
+  Size() {}
+  Size(int w, int h) : width(w), height(h) {}
+};
+enum { INTER_LINEAR = 1, BORDER_REFLECT_101 = 4, COLOR_BGR2GRAY = 6, COLOR_RGB2GRAY = 7 };
+float fastAtan2(float y, float x);
+const char* getVersionString_();
+}  // namespace cv
+int cvRound(double v);
+int cvRound(float v);
+#define CV_VERSION "mock"

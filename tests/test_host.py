@@ -248,3 +248,15 @@ def test_bench_gpus_n_launches_its_ranks():
                        stderr=subprocess.STDOUT, text=True, timeout=300, env=env, cwd=ROOT)
     assert p.returncode != 0
     assert "bench.py needs a GPU" in p.stdout and "launch with torch.distributed.run" not in p.stdout, p.stdout[-2000:]
+
+
+def test_pin_kit_compiles():
+    """tools/pin_opencv (the one-command diff of the oracle against a real OpenCV, for whoever has one) at least compiles: its only
+    possible check in this image is the compile-check mock of the cv:: declarations it uses (tests/cpp/mock_opencv pins nothing)."""
+    import subprocess
+    p = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "tests", "cpp", "mock_opencv"),
+                        os.path.join(ROOT, "tools", "pin_opencv", "pin_opencv.cpp")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout
+    p = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "pin_opencv", "export_fixtures.py"), "/tmp/orbx_pin_fixtures"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0 and os.path.exists("/tmp/orbx_pin_fixtures/manifest.txt"), p.stdout
