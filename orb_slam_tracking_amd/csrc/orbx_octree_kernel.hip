@@ -53,6 +53,22 @@ __device__ unsigned long long g_octStamps[4096 * OCT_NSTAMP];
       (t0) = now_;                                                                                           \
     }                                                                                                        \
   } while (0)
+// ... the std::sort replay's phases, summed over its recursion levels (slot 7 = levels), per workgroup
+__device__ unsigned long long g_octReplay[4096 * 8];
+#define OCT_REPLAY_INIT() unsigned long long tRep_ = __builtin_amdgcn_s_memtime(); \
+  if (threadIdx.x == 0) for (int k_ = 0; k_ < 8; k_++) g_octReplay[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + k_] = 0
+#define OCT_REPLAY_ACC(k)                                                                                   \
+  do {                                                                                                      \
+    if (threadIdx.x == 0) {                                                                                 \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                         \
+      g_octReplay[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (k)] += now_ - tRep_;                \
+      tRep_ = now_;                                                                                         \
+    }                                                                                                       \
+  } while (0)
+#define OCT_REPLAY_COUNT(k) do { if (threadIdx.x == 0) g_octReplay[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (k)] += 1; } while (0)
+extern "C" int orbx_diag_oct_replay(unsigned long long* out, int nBlocks) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_octReplay), sizeof(unsigned long long) * 8 * nBlocks);
+}
 // ... and which XCD the bucket waves / the unit's workgroup of the many-workgroup selection ran on (placement check)
 __device__ unsigned int g_octXcc[4096 * 9];
 #define OCT_XCC_B1(u) atomicAdd(&g_octXcc[((u) & 4095) * 9 + (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 7)], 1u)
@@ -66,6 +82,9 @@ extern "C" int orbx_diag_octb_stamps(unsigned long long* out, int nWaves) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_octbStamps), sizeof(unsigned long long) * 8 * (size_t)nWaves);
 }
 #else
+#define OCT_REPLAY_INIT() do {} while (0)
+#define OCT_REPLAY_ACC(k) do {} while (0)
+#define OCT_REPLAY_COUNT(k) do {} while (0)
 #define OCTB_STAMP(k) do {} while (0)
 #define OCTB_STAMP_V(k, v) do {} while (0)
 #define OCT_XCC_B1(u) do {} while (0)
@@ -140,7 +159,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   constexpr int PARCAP = 256;
   static_assert(QMAX <= PARCAP, "parallel-replay capacity");
   constexpr int HI_DWORDS = (NMAX / 2 > OCT_PAR_SCR_FOR(PARCAP)) ? NMAX / 2 : OCT_PAR_SCR_FOR(PARCAP);
-  __shared__ uint32_t hiPar[HI_DWORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t hiPar[HI_DWORDS];
   uint16_t* hiOf = reinterpret_cast<uint16_t*>(hiPar);
   static_assert(NMAX <= 65535, "16-bit sorted positions");
   __shared__ uint16_t nodeLo[MCAP + FCAP], nodeHi[MCAP + FCAP];
@@ -206,7 +225,7 @@ __global__ __launch_bounds__(1024) void k_octree_global(const uint32_t* __restri
   __shared__ u64 xchg[OCT_GLOBAL_XCHG];
   // scratch of the workgroup-parallel std::sort replay for up to 2048 pending nodes (the level-0 quota of 1080p / 4000 features is
   // 869, of 4K / 8000 features 1737: the one-lane replay took 96 k cycles of such a unit)
-  __shared__ uint32_t parScr[OCT_PAR_SCR_FOR(OCT_PAR_BIG)];
+  __shared__ __attribute__((aligned(16))) uint32_t parScr[OCT_PAR_SCR_FOR(OCT_PAR_BIG)];
   // a second set of the radix sort's 512 x 16 digit counters: a pass's scatter sweep counts the next pass's digits
   __shared__ uint32_t radixCnt2[512 * (1024 / 64)];
   static_assert(sizeof(radixCnt2) == OCT_GLOBAL_XCHG * sizeof(u64), "as many counters as the exchange buffer holds");
@@ -504,7 +523,7 @@ __global__ __launch_bounds__(1024) void k_octree_big(const uint32_t* __restrict_
                                                     SelKp* __restrict__ selStage, int* __restrict__ nselLevel,
                                                     uint8_t* __restrict__ scratch, int* __restrict__ maxN, int level0, int fallback) {
   __shared__ __attribute__((aligned(16))) u64 xchg[OCTBIG_XCHG];
-  __shared__ uint32_t parScr[OCT_PAR_SCR_FOR(OCT_PAR_BIG)];
+  __shared__ __attribute__((aligned(16))) uint32_t parScr[OCT_PAR_SCR_FOR(OCT_PAR_BIG)];
   __shared__ __attribute__((aligned(16))) uint32_t nodeLH[OCTBIG_NODES];
   __shared__ uint16_t nodeUlx[OCTBIG_NODES];
   __shared__ int pNd[OCTBIG_PEND], pLo[OCTBIG_PEND], pHiD[OCTBIG_PEND];
@@ -818,7 +837,7 @@ __global__ __launch_bounds__(OCT_T) void k_debug_sort(int* triples, int n, u64* 
     a[j] = ((u64)(uint32_t)triples[3 * j] << 40) | ((u64)((uint32_t)triples[3 * j + 1] & 0xfffff) << 20) |
            (u64)((uint32_t)triples[3 * j + 2] & 0xfffff);
   __syncthreads();
-  __shared__ uint32_t parScr[OCT_PAR_SCR];
+  __shared__ __attribute__((aligned(16))) uint32_t parScr[OCT_PAR_SCR];
   __shared__ u64 parKeys[OCT_PAR_MAX];
   __shared__ int parWs[4];
   if (n <= OCT_PAR_MAX) {  // the workgroup-parallel replay works on LDS keys, as in the selection kernels

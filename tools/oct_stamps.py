@@ -53,3 +53,10 @@ if big:  # where the buckets' waves of a unit ran (counts per XCD) and where its
     assert L.orbx_diag_oct_xcc(xc.ctypes.data, nb) == 0
     same = sum(int(r[:8].argmax() == r[8]) for r in xc)
     print("XCD placement: %d of %d units have their bucket waves on the XCD of their k_octree_big workgroup; first units: %s" % (same, nb, xc[:6].tolist()))
+if big:  # the std::sort replay's phases (summed over its recursion levels), level-0 units
+    rp = np.zeros((nb, 8), np.uint64)
+    L.orbx_diag_oct_replay.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    assert L.orbx_diag_oct_replay(rp.ctypes.data, nb) == 0
+    rp = rp.astype(np.int64)[:B]
+    print("std::sort replay, level-0 units: %d recursion levels; cycles per unit: median of three %.0f, stop flags + scan %.0f, prefix arrays %.0f, scatter %.0f, swaps + cut %.0f, tail %.0f, in-range ranks %.0f" % (
+        rp[:, 7].mean(), rp[:, 0].mean(), rp[:, 1].mean(), rp[:, 2].mean(), rp[:, 3].mean(), rp[:, 4].mean(), rp[:, 5].mean(), rp[:, 6].mean()))
