@@ -1058,6 +1058,34 @@ __device__ __forceinline__ void sincosSmall(double x, double* sn, double* cs) {
   *cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
+// The same values from a 256-entry table (round 4): x = k pi / 128 + r with |r| <= pi / 256, sin / cos of k pi / 128 as correctly
+// rounded doubles (orbx_sincos_tab.inc), three-term Taylor polynomials for sin r and cos r - 1 (next terms r^9 / 9! and
+// r^8 / 8!: below 2^-80) and the addition theorems -- ~17 f64 instructions instead of ~33 (no 6-term kernels, no quadrant
+// selects).  In k_describe_patch the angle is the same in all 64 lanes (one keypoint per wave), so the table entry comes through
+// one scalar load (UNIFORM).  What matters is the value ROUNDED TO F32: tools/sincos_exhaustive.py compares it with the
+// oracle's (float)cos((double)a) / (float)sin((double)a) for EVERY f32 angle in [0, 360] (1.13e9 values).
+#include "orbx_sincos_tab.inc"
+template <bool UNIFORM>
+__device__ __forceinline__ void sincosTable(double x, double* sn, double* cs) {
+  const double k = rint(x * ORBX_128OPI);                  // nearest multiple of pi / 128: 0 .. 256
+  double r = fma(-k, ORBX_PIO128_HI, x);                   // exact (cancellation: the difference has at most 52 significant bits)
+  r = fma(-k, ORBX_PIO128_LO, r);
+  int ki = (int)k & 255;
+  if (UNIFORM) ki = __builtin_amdgcn_readfirstlane(ki);
+  const double sk = d_sincosTab[ki][0], ck = d_sincosTab[ki][1];
+  const double z = r * r;
+  const double ps = fma(z, fma(z, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0);   // (sin r - r) / r^3
+  const double pc = fma(z, fma(z, -1.0 / 720.0, 1.0 / 24.0), -0.5);           // (cos r - 1) / r^2
+  const double sr = fma(z * r, ps, r), cm1 = z * pc;
+  *sn = fma(ck, sr, fma(sk, cm1, sk));
+  *cs = fma(-sk, sr, fma(ck, cm1, ck));
+}
+#ifdef ORBX_SINCOS_POLY  // (build flag: the round-2 / 3 evaluation, for comparison)
+#define ORBX_SINCOS(x, sn, cs, uniform) sincosSmall(x, sn, cs)
+#else
+#define ORBX_SINCOS(x, sn, cs, uniform) sincosTable<uniform>(x, sn, cs)
+#endif
+
 // cv::fastAtan2: plain f32 mul/add/div, no contraction
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
@@ -1410,7 +1438,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   const uint8_t* bl = reinterpret_cast<const uint8_t*>(bl32);
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   double sd, cd;
-  sincosSmall((double)(angle * factorPI), &sd, &cd);
+  ORBX_SINCOS((double)(angle * factorPI), &sd, &cd, true);
   const float cs = (float)cd, sn = (float)sd;
   unsigned long long words[4];
 #pragma unroll
@@ -2833,7 +2861,7 @@ __global__ __launch_bounds__(256) void k_debug_sincos(const float* __restrict__ 
   if (i >= n) return;
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   double sd, cd;
-  sincosSmall((double)(angle[i] * factorPI), &sd, &cd);
+  ORBX_SINCOS((double)(angle[i] * factorPI), &sd, &cd, false);
   c[i] = (float)cd;
   s[i] = (float)sd;
 }
