@@ -2244,6 +2244,7 @@ __global__ __launch_bounds__(MW_T) void k_match_wide_prep(const int* __restrict_
                                                          const MatchParams mp, int* __restrict__ matches12,
                                                          const int* __restrict__ nmatchesOut, int* __restrict__ scratch,
                                                          long long scratchStride, int capl) {
+  ORBX_SETPRIO();
   const int pair = blockIdx.x + mp.pair0;
   if (nmatchesOut[pair] != MATCH_PENDING) return;
   matchWidePrep<MW_T>(pair, pairFirst, pairSecond, kps, nkp, mp, matches12, scratch, scratchStride, capl);
@@ -2432,6 +2433,7 @@ __global__ __launch_bounds__(256) void k_match_wide_lists(const int* __restrict_
 static_assert(MW_CP == 128, "k_match_wide_sort: two list entries per lane");
 __global__ __launch_bounds__(256) void k_match_wide_sort(const MatchParams mp, const int* __restrict__ nmatchesOut, int* __restrict__ scratch,
                                                         long long scratchStride, int capl) {
+  ORBX_SETPRIO();
   const int lane = threadIdx.x & 63;
   const int pair = blockIdx.y + mp.pair0;
   if (nmatchesOut[pair] != MATCH_PENDING) return;
@@ -2489,6 +2491,7 @@ __global__ __launch_bounds__(MW_T) void k_match_wide_resolve(const int* __restri
                                                             const MatchParams mp, int* __restrict__ matches12,
                                                             int* __restrict__ nmatchesOut, int* __restrict__ statsOut,
                                                             int* scratch, long long scratchStride, int capl) {
+  ORBX_SETPRIO();
   extern __shared__ __align__(16) unsigned char mwLds[];
   // claims of a sweep = one linked list per train through its claimant queries (any number of claimants)
   int* head = reinterpret_cast<int*>(mwLds);                              // [capl] a claimant of the train, -1 = none; lastQ at the end

@@ -221,6 +221,7 @@ static_assert(OCT_SORT_LDS >= 1024, "the register sort of the 1024-thread instan
 __global__ __launch_bounds__(1024) void k_octree_global(const uint32_t* __restrict__ cand, const int* __restrict__ cellCount,
                                                        const OctLaunch P, SelKp* __restrict__ selStage,
                                                        int* __restrict__ nselLevel, uint8_t* __restrict__ scratch, int all, int level0) {
+  ORBX_SETPRIO();
   // exchange buffer: 2048 keys for the register sorts, and 512 x 16 digit counters (9-bit digits) for the radix sort
   __shared__ u64 xchg[OCT_GLOBAL_XCHG];
   // scratch of the workgroup-parallel std::sort replay for up to 2048 pending nodes (the level-0 quota of 1080p / 4000 features is
@@ -379,14 +380,9 @@ __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __res
       const int cell = (cy0 + c / cw) * L.nCols + cx0 + c % cw;
       const int v = c < nc ? cellCnt[cell] : 0;
       if (c < nc) cidx[c] = (uint16_t)cell;
-      int inc = v;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-      }
+      const int inc = t64::waveScanIncl(v);
       if (c < nc) cpre[c] = nRaw + inc - v;
-      nRaw += __shfl(inc, 63);
+      nRaw += __builtin_amdgcn_readlane(inc, 63);
     }
     if (lane == 0) cpre[nc] = nRaw;
   }
@@ -522,6 +518,7 @@ static_assert(ORBX_OCTB_INFO >= 4 + 2 * (OCT_DEPTH + 2), "a bucket's record hold
 __global__ __launch_bounds__(1024) void k_octree_big(const uint32_t* __restrict__ cand, const int* __restrict__ cellCount, const OctLaunch P,
                                                     SelKp* __restrict__ selStage, int* __restrict__ nselLevel,
                                                     uint8_t* __restrict__ scratch, int* __restrict__ maxN, int level0, int fallback) {
+  ORBX_SETPRIO();
   __shared__ __attribute__((aligned(16))) u64 xchg[OCTBIG_XCHG];
   __shared__ __attribute__((aligned(16))) uint32_t parScr[OCT_PAR_SCR_FOR(OCT_PAR_BIG)];
   __shared__ __attribute__((aligned(16))) uint32_t nodeLH[OCTBIG_NODES];
@@ -567,6 +564,7 @@ __global__ __launch_bounds__(1024) void k_octree_big(const uint32_t* __restrict_
 // every range's scores in flight sixteen at a time.
 __global__ __launch_bounds__(256) void k_octree_emit(const OctLaunch P, SelKp* __restrict__ selStage, const int* __restrict__ nselLevel,
                                                     uint8_t* __restrict__ scratch, int level0) {
+  ORBX_SETPRIO();
   const int level = blockIdx.y + level0, f = blockIdx.x + P.frame0;
   const int nOutNodes = nselLevel[f * P.nlevels + level];
   const int p = blockIdx.z * 256 + threadIdx.x;
@@ -617,6 +615,7 @@ __global__ __launch_bounds__(256) void k_sel_compact(const SelKp* __restrict__ s
                                                      int* __restrict__ nselUser, int* __restrict__ hostNsel, int selCap,
                                                      int* __restrict__ hostErr, int* __restrict__ maxN,
                                                      int* __restrict__ hostMaxN) {
+  ORBX_SETPRIO();
   const int f = blockIdx.x + P.frame0;
   // per-level maxima of the units' candidate counts (k_octree_lds: maxN[frame * nlevels + level]) of this launch go to pinned
   // host memory; the counts are reset for the next launch (levels no LDS unit ran on report 0)
