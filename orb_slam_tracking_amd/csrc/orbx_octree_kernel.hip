@@ -264,17 +264,7 @@ __device__ __forceinline__ void waveSort32(uint32_t* a, int lane) {
 #pragma unroll
   for (int e = 0; e < E; e++) v[e] = a[lane * E + e];
   for (int k = 2; k <= NTOT; k <<= 1) {
-    for (int j = k >> 1; j >= E; j >>= 1) {
-      const int lm = j / E;
-#pragma unroll
-      for (int e = 0; e < E; e++) {
-        const int i = lane * E + e;
-        const uint32_t o = __shfl_xor(v[e], lm);
-        const bool lower = (i & j) == 0, asc = (i & k) == 0;
-        const bool keepMin = lower == asc;
-        v[e] = keepMin ? min(o, v[e]) : max(o, v[e]);
-      }
-    }
+    t64::bitonicLaneStages<E>(v, lane, k);
 #pragma unroll
     for (int jj = E / 2; jj > 0; jj >>= 1) {
       if (jj < k) {
