@@ -104,6 +104,10 @@ typedef unsigned long long u64;
 #define OCT_PAR_RANGES_FOR(capN) ((capN) / 16 < 64 ? 64 : (capN) / 16)  // ranges of more than 16 keys alive at a time: < capN / 16
 #define OCT_PAR_SCR_FOR(capN) (4 * (((capN) + 8) / 2) + 5 * OCT_PAR_RANGES_FOR(capN) + 4)
 #define OCT_PAR_SCR OCT_PAR_SCR_FOR(OCT_PAR_MAX)
+// what stdSortPartitionPhasePar lays out in it: LR[capN + 8], SLR[capN + 2] / the wave tasks' 130 dwords each, the task list
+#define OCT_PAR_NEED(capN) (((capN) + 8) + ((capN) + 2 > 130 * ((capN) / 128 < 4 ? 4 : (capN) / 128) ? (capN) + 2 : 130 * ((capN) / 128 < 4 ? 4 : (capN) / 128)) + (capN) / 16 + 2)
+static_assert(OCT_PAR_NEED(256) <= OCT_PAR_SCR_FOR(256) && OCT_PAR_NEED(512) <= OCT_PAR_SCR_FOR(512) && OCT_PAR_NEED(2048) <= OCT_PAR_SCR_FOR(2048),
+              "scratch of the parallel std::sort replay");
 #define ORBX_OCT_REDONE 0x40000000  // bit of a (frame, level) count: k_octree_emit redid the unit with the one-workgroup code
 #define OCTBIG_NODES 8192   // k_octree_big: list nodes of a unit (LDS tables; M < 4 N)
 #define OCTBIG_PEND 2048    // ... pending nodes of a partial-pass round (< N)
