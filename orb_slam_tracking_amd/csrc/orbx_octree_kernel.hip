@@ -167,7 +167,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_lds(const uint32_t* __restrict
   uint16_t* hiOf = reinterpret_cast<uint16_t*>(hiPar);
   static_assert(NMAX <= 65535, "16-bit sorted positions");
   __shared__ uint16_t nodeLo[MCAP + FCAP], nodeHi[MCAP + FCAP];
-  __shared__ uint8_t div[NMAX + 4];
+  __shared__ __attribute__((aligned(16))) uint8_t div[NMAX + 16];  // (octChildBounds reads whole 16-byte chunks)
   __shared__ uint8_t nodeDepth[MCAP + FCAP];
   static_assert(2 * QMAX * 8 + 2 * QMAX * 4 + QMAX * 4 <= MCAP * 8, "partial-pass buffers must fit in nodes[]");
   u64* sized = nodes;                                             // [2 * QMAX]
