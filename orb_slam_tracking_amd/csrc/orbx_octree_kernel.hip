@@ -556,12 +556,15 @@ __global__ __launch_bounds__(1024) void k_octree_big(const uint32_t* __restrict_
 // range's first key with the highest response (cpp:984-1007) is the key with the largest score.  One thread per range, 256 per
 // workgroup (many workgroups: one CU's L1 takes ~4 cycles per scattered line, 45 k cycles for the 1737 ranges of a 4K level 0),
 // every range's scores in flight sixteen at a time.
-__global__ __launch_bounds__(256) void k_octree_emit(const OctLaunch P, SelKp* __restrict__ selStage, const int* __restrict__ nselLevel,
+#ifndef ORBX_TAIL_T
+#define ORBX_TAIL_T 64  // threads per workgroup of k_octree_emit / k_sel_compact: ONE wave (see k_sel_compact)
+#endif
+__global__ __launch_bounds__(ORBX_TAIL_T) void k_octree_emit(const OctLaunch P, SelKp* __restrict__ selStage, const int* __restrict__ nselLevel,
                                                     uint8_t* __restrict__ scratch, int level0) {
   ORBX_SETPRIO();
   const int level = blockIdx.y + level0, f = blockIdx.x + P.frame0;
   const int nOutNodes = nselLevel[f * P.nlevels + level];
-  const int p = blockIdx.z * 256 + threadIdx.x;
+  const int p = blockIdx.z * ORBX_TAIL_T + threadIdx.x;
   if (nOutNodes < 0 || (nOutNodes & ORBX_OCT_REDONE) || p >= nOutNodes) return;  // (a redone unit's records are in place already)
   uint32_t* candBuf;
   int mCap, fCap, qMax;
@@ -604,34 +607,36 @@ size_t octScratchBytes(int nMax, int qMax) {
 // context's array (k_describe_patch reads it), to the caller's array if there is one, and to the host (mapped pinned
 // memory), so that no copy command follows on the stream.  A unit the selection could not handle raises the host's error
 // flag the same way.
-__global__ __launch_bounds__(256) void k_sel_compact(const SelKp* __restrict__ selStage, const int* __restrict__ nselLevel,
+__global__ __launch_bounds__(ORBX_TAIL_T) void k_sel_compact(const SelKp* __restrict__ selStage, const int* __restrict__ nselLevel,
                                                      const OctLaunch P, SelKp* __restrict__ sel, int* __restrict__ nsel,
                                                      int* __restrict__ nselUser, int* __restrict__ hostNsel, int selCap,
                                                      int* __restrict__ hostErr, int* __restrict__ maxN,
                                                      int* __restrict__ hostMaxN) {
   ORBX_SETPRIO();
-  const int f = blockIdx.x + P.frame0;
+  // grid (frames, parts): the workgroups (frame, 0 .. parts - 1) share the frame's copy; (frame, 0) writes its totals
+  constexpr int T = ORBX_TAIL_T;
+  const int f = blockIdx.x + P.frame0, part = blockIdx.y, parts = gridDim.y;
   // per-level maxima of the units' candidate counts (k_octree_lds: maxN[frame * nlevels + level]) of this launch go to pinned
   // host memory; the counts are reset for the next launch (levels no LDS unit ran on report 0)
-  // (small launches: the first workgroup, one count per thread; else workgroup l takes level l, one count per thread at 256 frames)
+  // (small launches: the first workgroup, one count per thread; else workgroup l takes level l)
   const int nUnits = (int)gridDim.x * P.nlevels;
-  if (maxN && (nUnits <= 256 ? blockIdx.x == 0 : (int)blockIdx.x < P.nlevels)) {
+  if (maxN && part == 0 && (nUnits <= 256 ? blockIdx.x == 0 : (int)blockIdx.x < P.nlevels)) {
     __shared__ int red[ORBX_MAX_LEVELS];
     if (threadIdx.x < P.nlevels) red[threadIdx.x] = 0;
     __syncthreads();
     if (nUnits <= 256) {
-      if ((int)threadIdx.x < nUnits) {
-        const int idx = P.frame0 * P.nlevels + threadIdx.x;
+      for (int u = threadIdx.x; u < nUnits; u += T) {
+        const int idx = P.frame0 * P.nlevels + u;
         const int v = maxN[idx];
         maxN[idx] = 0;
-        if (v > 0) atomicMax(&red[threadIdx.x % P.nlevels], v);
+        if (v > 0) atomicMax(&red[u % P.nlevels], v);
       }
       __syncthreads();
       if (threadIdx.x < P.nlevels) hostMaxN[threadIdx.x] = red[threadIdx.x];
     } else {
       const int l = blockIdx.x;
       int m = 0;
-      for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
+      for (int i = threadIdx.x; i < (int)gridDim.x; i += T) {
         const int idx = (P.frame0 + i) * P.nlevels + l;
         m = max(m, maxN[idx]);
         maxN[idx] = 0;
@@ -655,17 +660,19 @@ __global__ __launch_bounds__(256) void k_sel_compact(const SelKp* __restrict__ s
       acc += max(c, 0);
     }
     off[P.nlevels] = acc;
-    nsel[f] = acc;
-    if (nselUser) nselUser[f] = acc;
-    if (hostNsel) hostNsel[f] = acc;
-    if (bad) *hostErr = 1;
+    if (part == 0) {
+      nsel[f] = acc;
+      if (nselUser) nselUser[f] = acc;
+      if (hostNsel) hostNsel[f] = acc;
+      if (bad) *hostErr = 1;
+    }
   }
   __syncthreads();
   for (int l = 0; l < P.nlevels; l++) {
     const int c = off[l + 1] - off[l];
     const SelKp* src = selStage + (int64_t)f * P.selStride + P.selOff[l];
     SelKp* dst = sel + (int64_t)f * selCap + off[l];
-    for (int i = threadIdx.x; i < c; i += 256) dst[i] = src[i];
+    for (int i = part * T + threadIdx.x; i < c; i += parts * T) dst[i] = src[i];
   }
 }
 
@@ -721,7 +728,7 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
                          fallback ? 1 : 0);
       int qMost = 1;
       for (int l = l0; l < l1; l++) qMost = std::max(qMost, Q.lev[l].quota);
-      hipLaunchKernelGGL(k_octree_emit, dim3(nFrames, l1 - l0, (qMost + 255) / 256), dim3(256), 0, st, Q, selStage, nselLevel, scratch, l0);
+      hipLaunchKernelGGL(k_octree_emit, dim3(nFrames, l1 - l0, (qMost + ORBX_TAIL_T - 1) / ORBX_TAIL_T), dim3(ORBX_TAIL_T), 0, st, Q, selStage, nselLevel, scratch, l0);
     } else {
       hipLaunchKernelGGL(k_octree_global, dim3(nFrames, l1 - l0, 1), dim3(1024), 0, st, cand, cellCount, P, selStage, nselLevel, scratch, 1, l0);
     }
@@ -809,7 +816,7 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
 hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage, const int* nselLevel, const OctLaunch& P,
                               SelKp* sel, int* nsel, int* nselUser, int* hostNsel, int selCap, int* hostErr, int* maxN,
                               int* hostMaxN) {
-  hipLaunchKernelGGL(k_sel_compact, dim3(nFrames), dim3(256), 0, st, selStage, nselLevel, P, sel, nsel, nselUser, hostNsel, selCap,
+  hipLaunchKernelGGL(k_sel_compact, dim3(nFrames, 256 / ORBX_TAIL_T), dim3(ORBX_TAIL_T), 0, st, selStage, nselLevel, P, sel, nsel, nselUser, hostNsel, selCap,
                      hostErr, maxN, hostMaxN);
   return hipGetLastError();
 }
