@@ -34,7 +34,7 @@ hipError_t launch_pyramid_bands(hipStream_t st, int nFrames, const uint8_t* img0
                                 const Geom& g, const ResizeTab* tab, const PyrBands& pb);
 hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const uint8_t* img0, long long img0FrameStride,
                                  int img0Aligned, const uint8_t* pyr, const Geom& g, const SelKp* sel, const int* nsel,
-                                 orbx_keypoint* kps, uint8_t* desc, int capacity, int gaussVariant);
+                                 orbx_keypoint* kps, uint8_t* desc, int capacity, int gaussVariant, const DescStage* staged);
 hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int* dSecond, const orbx_keypoint* kps,
                         const uint8_t* desc, const int* nkp, int capacity, orbx_bounds b, int window, float nnratio, int checkOri,
                         int* matches12, int* nmatches, int* stats, int* scratch, int pair0, int wideMode, int* hostWide);
@@ -1104,21 +1104,32 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   }
   return ORBX_OK;
   }  // part 0
+  bool staged = false;
   {  // selection stage: quadtree per (frame, level), then level-major compaction
     StageTimer tm(ctx, ORBX_STAGE_SELECT, si, st);
     // per-level candidate maxima of this stream slot: device accumulators + their pinned host mirror (read after the sync)
     int* dMax = ctx->dMaxN;  // (indexed by frame: the two half batches do not meet)
     HIPCHK(launch_octree(st, n, ctx->dCand, ctx->dCellCount, oct, ctx->dSelStage, ctx->dNselLevel, ctx->dOctScratch, dMax,
                          ctx->candHintL, 0, &ctx->lastLaunch[3]));
-    HIPCHK(launch_sel_compact(st, n, ctx->dSelStage, ctx->dNselLevel, oct, ctx->dSel, ctx->dNsel, a.dNuser, ctx->hNselDev, g.selCap,
-                              ctx->hFlagsDev + ctx->parity, dMax, ctx->hMaxNDev + si * ORBX_MAX_LEVELS));
+    // small launches (the one-frame call): the descriptor kernel indexes the staging lists itself and does the bookkeeping
+    // (DescStage) -- one kernel less on the call's critical path
+    static const bool noStaged = getenv("ORBX_DESC_NO_STAGED") != nullptr;  // diagnostics
+    staged = !noStaged && n * g.nlevels <= ORBX_DESC_STAGED_MAX_UNITS;
+    if (!staged)
+      HIPCHK(launch_sel_compact(st, n, ctx->dSelStage, ctx->dNselLevel, oct, ctx->dSel, ctx->dNsel, a.dNuser, ctx->hNselDev, g.selCap,
+                                ctx->hFlagsDev + ctx->parity, dMax, ctx->hMaxNDev + si * ORBX_MAX_LEVELS));
     ctx->maxSlotsUsed |= 1 << si;
-    tm.stop(2);
+    tm.stop(staged ? 1 : 2);
   }
   {
     StageTimer tm(ctx, ORBX_STAGE_DESCRIBE, si, st);
+    DescStage ds;
+    ds.selStage = ctx->dSelStage; ds.nselLevel = ctx->dNselLevel; ds.nsel = ctx->dNsel; ds.nselUser = a.dNuser; ds.hostNsel = ctx->hNselDev;
+    ds.hostErr = ctx->hFlagsDev + ctx->parity; ds.maxN = ctx->dMaxN; ds.hostMaxN = ctx->hMaxNDev + si * ORBX_MAX_LEVELS;
+    ds.selStride = oct.selStride;
+    for (int l = 0; l < ORBX_MAX_LEVELS; l++) ds.selOff[l] = oct.selOff[l];
     HIPCHK(launch_describe_patch(st, n, g.selCap, a.dImg0, a.frameStride0, a.aligned0, ctx->dPyr, g, ctx->dSel, ctx->dNsel,
-                                 a.dKps, a.dDesc, a.capacity, ctx->gaussVariant));
+                                 a.dKps, a.dDesc, a.capacity, ctx->gaussVariant, staged ? &ds : nullptr));
     tm.stop(1);
   }
   return ORBX_OK;

@@ -107,6 +107,22 @@ struct OctLevel {
 #define ORBX_OCTB_MAX_BUCKETS 1024
 #define ORBX_OCTB_INFO 40         // ints of a bucket's record: count, first / last inner divergence, overflow, 18 + 18 histogram bins
 
+// Small launches (the one-frame call): k_describe_patch reads the selection's per-level staging lists directly and does
+// k_sel_compact's bookkeeping in one designated wave per frame, so that no compaction kernel sits on the call's critical path.
+struct DescStage {
+  const SelKp* selStage;
+  const int* nselLevel;
+  int* nsel;
+  int* nselUser;
+  int* hostNsel;
+  int* hostErr;
+  int* maxN;
+  int* hostMaxN;
+  int32_t selStride;
+  int32_t selOff[ORBX_MAX_LEVELS];
+};
+#define ORBX_DESC_STAGED_MAX_UNITS 64  // units (frames x levels) up to which the descriptor kernel takes the staged lists
+
 struct OctLaunch {
   OctLevel lev[ORBX_MAX_LEVELS];
   int64_t candOff[ORBX_MAX_LEVELS];

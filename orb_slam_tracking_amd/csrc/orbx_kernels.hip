@@ -1224,12 +1224,12 @@ __host__ __device__ constexpr uint32_t descHTap(int t, int m) {
   }
   return k;
 }
-template <int GV>
+template <int GV, bool STAGED = false>
 __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_t* __restrict__ img0, long long img0FrameStride,
                                                        int img0Aligned, const uint8_t* __restrict__ pyr, const Geom g,
                                                        const SelKp* __restrict__ sel, const int* __restrict__ nsel,
                                                        orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                       int capacity) {
+                                                       int capacity, const DescStage ds) {
   __shared__ __attribute__((aligned(16))) uint32_t ldsAll[DESC_WAVES][PW_WAVE_WORDS];
   static_assert(PW_WAVE_WORDS % 4 == 0, "every wave's LDS slice must stay 16-byte aligned");
   const int f = blockIdx.y + g.frame0, lane = threadIdx.x & 63;
@@ -1242,8 +1242,41 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   const int i = grp * DESC_WAVES + (threadIdx.x >> 6);
   // (the keypoint record is fetched together with the frame's count, not behind it: count, record and window were three
   // dependent global loads and, by tools/desc_stamps.py, 63 % of a wave's lifetime)
-  const SelKp k = sel[(long long)f * g.selCap + min(i, g.selCap - 1)];
-  if (i >= nsel[f]) return;  // wave-uniform; the waves of a workgroup never synchronise with each other
+  SelKp k;
+  if constexpr (STAGED) {
+    // keypoint i of the level-major order = entry i - (keypoints of the levels below) of its level's staging list; the counts of
+    // the frame's levels come through scalar loads (a unit the selection redid carries a tag bit, a failed one a negative count)
+    int off = 0, total = 0, kl = 0, bad = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+      int c = ds.nselLevel[f * g.nlevels + l];
+      bad |= c < 0;
+      c = c < 0 ? 0 : (c & ~0x40000000);
+      if (i >= total) { off = total; kl = l; }
+      total += c;
+    }
+    if (i == 0) {  // the frame's designated wave: k_sel_compact's bookkeeping
+      if (lane == 0) {
+        ds.nsel[f] = total;
+        if (ds.nselUser) ds.nselUser[f] = total;
+        if (ds.hostNsel) ds.hostNsel[f] = total;
+        if (bad) *ds.hostErr = 1;
+      }
+      if (blockIdx.y == 0 && ds.maxN && lane < g.nlevels) {  // per-level maxima of the units' candidate counts, counts reset
+        int m = 0;
+        for (int fr = 0; fr < (int)gridDim.y; fr++) {
+          const int idx = (g.frame0 + fr) * g.nlevels + lane;
+          m = max(m, ds.maxN[idx]);
+          ds.maxN[idx] = 0;
+        }
+        ds.hostMaxN[lane] = m;
+      }
+    }
+    if (i >= total) return;  // wave-uniform
+    k = ds.selStage[(long long)f * ds.selStride + ds.selOff[kl] + (i - off)];
+  } else {
+    k = sel[(long long)f * g.selCap + min(i, g.selCap - 1)];
+    if (i >= nsel[f]) return;  // wave-uniform; the waves of a workgroup never synchronise with each other
+  }
 #ifdef ORBX_DESC_STAMPS
   const unsigned dsWave_ = (unsigned)((blockIdx.y * gridDim.x + blockIdx.x) * DESC_WAVES + (threadIdx.x >> 6));
 #endif
@@ -2977,16 +3010,26 @@ hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long lo
 
 hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const uint8_t* img0, long long img0FrameStride,
                                  int img0Aligned, const uint8_t* pyr, const Geom& g, const SelKp* sel, const int* nsel,
-                                 orbx_keypoint* kps, uint8_t* desc, int capacity, int gaussVariant) {
-  if (maxSel <= 0) return hipSuccess;
+                                 orbx_keypoint* kps, uint8_t* desc, int capacity, int gaussVariant, const DescStage* staged) {
+  // staged (optional): the selection's staging lists -- the kernel indexes them itself and writes the frames' totals (the caller
+  // launched no k_sel_compact; see DescStage)
+  if (maxSel <= 0 && !staged) return hipSuccess;
   dim3 block(64 * DESC_WAVES, 1, 1), grid(((maxSel + DESC_WAVES - 1) / DESC_WAVES + 7) / 8 * 8, nFrames, 1);  // x: multiple of 8
   static const int descPad = getenv("ORBX_DESC_LDS_PAD") ? atoi(getenv("ORBX_DESC_LDS_PAD")) : 0;  // diagnostics: fewer waves per CU
-  if (gaussVariant)
-    hipLaunchKernelGGL(k_describe_patch<1>, grid, block, descPad, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps, desc,
-                       capacity);
+  const DescStage none = {};
+  if (staged) {
+    if (gaussVariant)
+      hipLaunchKernelGGL((k_describe_patch<1, true>), grid, block, descPad, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps,
+                         desc, capacity, *staged);
+    else
+      hipLaunchKernelGGL((k_describe_patch<0, true>), grid, block, descPad, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps,
+                         desc, capacity, *staged);
+  } else if (gaussVariant)
+    hipLaunchKernelGGL((k_describe_patch<1, false>), grid, block, descPad, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps,
+                       desc, capacity, none);
   else
-    hipLaunchKernelGGL(k_describe_patch<0>, grid, block, descPad, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps, desc,
-                       capacity);
+    hipLaunchKernelGGL((k_describe_patch<0, false>), grid, block, descPad, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps,
+                       desc, capacity, none);
   return hipGetLastError();
 }
 
