@@ -1114,7 +1114,8 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
     // small launches (the one-frame call): the descriptor kernel indexes the staging lists itself and does the bookkeeping
     // (DescStage) -- one kernel less on the call's critical path
     static const bool noStaged = getenv("ORBX_DESC_NO_STAGED") != nullptr;  // diagnostics
-    staged = !noStaged && n * g.nlevels <= ORBX_DESC_STAGED_MAX_UNITS;
+    static const int stagedMax = getenv("ORBX_DESC_STAGED_MAX") ? atoi(getenv("ORBX_DESC_STAGED_MAX")) : ORBX_DESC_STAGED_MAX_UNITS;  // (experiments)
+    staged = !noStaged && n * g.nlevels <= stagedMax;
     if (!staged)
       HIPCHK(launch_sel_compact(st, n, ctx->dSelStage, ctx->dNselLevel, oct, ctx->dSel, ctx->dNsel, a.dNuser, ctx->hNselDev, g.selCap,
                                 ctx->hFlagsDev + ctx->parity, dMax, ctx->hMaxNDev + si * ORBX_MAX_LEVELS));

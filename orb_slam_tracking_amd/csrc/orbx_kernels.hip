@@ -1261,14 +1261,17 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
         if (ds.hostNsel) ds.hostNsel[f] = total;
         if (bad) *ds.hostErr = 1;
       }
-      if (blockIdx.y == 0 && ds.maxN && lane < g.nlevels) {  // per-level maxima of the units' candidate counts, counts reset
+      if (blockIdx.y == 0 && ds.maxN) {  // per-level maxima of the units' candidate counts, counts reset (lane = frame % 4, level)
+        static_assert(ORBX_MAX_LEVELS <= 16, "sixteen lanes per frame");
         int m = 0;
-        for (int fr = 0; fr < (int)gridDim.y; fr++) {
-          const int idx = (g.frame0 + fr) * g.nlevels + lane;
-          m = max(m, ds.maxN[idx]);
-          ds.maxN[idx] = 0;
-        }
-        ds.hostMaxN[lane] = m;
+        if ((lane & 15) < g.nlevels)
+          for (int fr = lane >> 4; fr < (int)gridDim.y; fr += 4) {
+            const int idx = (g.frame0 + fr) * g.nlevels + (lane & 15);
+            m = max(m, ds.maxN[idx]);
+            ds.maxN[idx] = 0;
+          }
+        m = max(m, __shfl_xor(m, 16)); m = max(m, __shfl_xor(m, 32));
+        if (lane < g.nlevels) ds.hostMaxN[lane] = m;
       }
     }
     if (i >= total) return;  // wave-uniform
