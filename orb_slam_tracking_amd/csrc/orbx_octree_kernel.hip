@@ -843,6 +843,17 @@ __global__ __launch_bounds__(OCT_T) void k_debug_sort(int* triples, int n, u64* 
   if (n <= OCT_PAR_MAX) {  // the workgroup-parallel replay works on LDS keys, as in the selection kernels
     for (int j = tid; j < n; j += OCT_T) parKeys[j] = a[j];
     __syncthreads();
+    if (n & 2) {  // ... with the whole sort from the partition phase's own ranges (k_octree_big's form): in-range ranks, no rank pass
+      __shared__ u64 parRanked[OCT_PAR_MAX];
+      stdSortPartitionPhasePar(parKeys, n, tid, parScr, parWs, n <= 256 && (n & 1) ? 256 : OCT_PAR_MAX, parRanked);
+      __syncthreads();
+      for (int j = tid; j < n; j += OCT_T) {
+        triples[3 * j] = (int)(parRanked[j] >> 40);
+        triples[3 * j + 1] = (int)((parRanked[j] >> 20) & 0xfffff);
+        triples[3 * j + 2] = (int)(parRanked[j] & 0xfffff);
+      }
+      return;
+    }
     stdSortPartitionPhasePar(parKeys, n, tid, parScr, parWs, n <= 256 && (n & 1) ? 256 : OCT_PAR_MAX);  // both layouts get exercised
     __syncthreads();
     for (int j = tid; j < n; j += OCT_T) a[j] = parKeys[j];

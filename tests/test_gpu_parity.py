@@ -392,13 +392,14 @@ def test_device_std_sort_replay(orbx, ext640, oracle):
     cases.append(np.stack([killer, np.zeros(n, int), np.arange(n)], 1))
     # n <= 512 runs the workgroup-parallel replay (closed-form partitions, breadth first): sizes around its limits, sorted /
     # reversed / constant inputs, few distinct keys, and the median-of-3 killer (depth budget -> per-range heapsort)
-    for n in (19, 20, 31, 34, 64, 66, 128, 130, 200, 254, 255, 256, 300, 400, 449, 511, 512):
+    # (sizes with bit 1 set take the form k_octree_big uses: the whole sort from the partition phase's own ranges, wave tasks included)
+    for n in (19, 20, 31, 34, 64, 66, 128, 130, 131, 200, 202, 254, 255, 256, 300, 303, 400, 449, 450, 510, 511, 512):
         for hi in (1, 2, 3, 9, 1000):
             cases.append(np.stack([rng.integers(2, 2 + hi, n), rng.integers(0, 6, n) * 16, np.arange(n)], 1))
         cases.append(np.stack([np.arange(n), np.zeros(n, int), np.arange(n)], 1))
         cases.append(np.stack([np.arange(n)[::-1], np.zeros(n, int), np.arange(n)], 1))
         cases.append(np.stack([np.full(n, 7), np.full(n, 3), np.arange(n)], 1))
-    for n in (64, 254, 256, 512):
+    for n in (64, 130, 254, 256, 510, 512):
         k = n // 2
         killer = np.zeros(n, int)
         for i in range(1, k + 1):
