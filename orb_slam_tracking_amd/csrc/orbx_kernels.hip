@@ -1239,7 +1239,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   // (mostly one pyramid level) and its L2 holds that part of the pyramid only.  Every keypoint costs the same, so the
   // XCDs stay balanced.
   const int grp = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int i = grp * DESC_WAVES + (threadIdx.x >> 6);
+  // (the wave's index as a scalar: the keypoint record then comes through a scalar load, beside the count's)
+  const int i = grp * DESC_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // (the keypoint record is fetched together with the frame's count, not behind it: count, record and window were three
   // dependent global loads and, by tools/desc_stamps.py, 63 % of a wave's lifetime)
   SelKp k;
@@ -1277,8 +1278,15 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
     if (i >= total) return;  // wave-uniform
     k = ds.selStage[(long long)f * ds.selStride + ds.selOff[kl] + (i - off)];
   } else {
-    k = sel[(long long)f * g.selCap + min(i, g.selCap - 1)];
-    if (i >= nsel[f]) return;  // wave-uniform; the waves of a workgroup never synchronise with each other
+    // (both loads are issued before either is waited for: the compiler sinks the record's load behind the count's branch otherwise,
+    // and the wave's chain of dependent loads is what its lifetime is made of -- tools/desc_stamps.py)
+    const unsigned long long kraw = *reinterpret_cast<const unsigned long long*>(&sel[(long long)f * g.selCap + min(i, g.selCap - 1)]);
+    const int cnt = nsel[f];
+    unsigned long long kuse = kraw;
+    asm volatile("" : "+s"(kuse));  // (the record is a value here, not a load to be moved)
+    if (i >= cnt) return;  // wave-uniform; the waves of a workgroup never synchronise with each other
+    k.x = (uint16_t)(kuse & 0xffff); k.y = (uint16_t)((kuse >> 16) & 0xffff); k.level = (uint8_t)((kuse >> 32) & 0xff);
+    k.response = (uint8_t)((kuse >> 40) & 0xff); k.pad = 0;
   }
 #ifdef ORBX_DESC_STAMPS
   const unsigned dsWave_ = (unsigned)((blockIdx.y * gridDim.x + blockIdx.x) * DESC_WAVES + (threadIdx.x >> 6));
