@@ -366,8 +366,8 @@ int orbx_debug_sincos(orbx_ctx* ctx, const float* angle_deg, int n, float* cos_o
  * alignment and the previous batch's statistics): info8 = { [0] pyramid: 1 = k_pyramid_bands (one launch, large batches), 2 = k_pyramid_tiles
  * (one launch, small batches), 0 = one resize launch per level; [1] row bands (tiles) per frame of that kernel; [2] FAST: 1 = k_fast_wave, 0 = k_fast; [3] selection: candidate
  * capacity of the smallest LDS instance a pyramid level of the batch ran on (2048 / 1024 / 512; 0 = a level expected units beyond
- * the LDS layout and went to the global-scratch kernel); [4] 1 = the batch was cut into two
- * halves on two streams; [5] frames per kernel launch; [6] 1 = the wide matcher kernels went with the batch; [7] lane the batch
+ * the LDS layout and went to the global-scratch kernel); [4] bit 0: the batch was cut into two
+ * halves on two streams, bit 1: the descriptor kernel took the selection's staging lists itself (small launches: no k_sel_compact); [5] frames per kernel launch; [6] 1 = the wide matcher kernels went with the batch; [7] lane the batch
  * went to (1-based; 0 = the context itself) }. */
 int orbx_debug_last_launch(const orbx_ctx* ctx, int32_t* info8);
 /* Host only, no device needed: the quadtree path codes (root << 32 | 16 quadrant digits of ExtractorNode::DivideNode,

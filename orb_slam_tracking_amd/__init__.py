@@ -520,7 +520,8 @@ class ORBextractor:
         v = np.zeros(8, np.int32)
         self._check(self._L.orbx_debug_last_launch(self._h, _ptr(v)), "orbx_debug_last_launch")
         return dict(pyramid_banded=int(v[0]), pyramid_bands=int(v[1]), fast_wave=int(v[2]), octree_instance=int(v[3]),
-                    split=int(v[4]), frames_per_launch=int(v[5]), wide_with_batch=int(v[6]), lane=int(v[7]))
+                    split=int(v[4]) & 1, staged_lists=(int(v[4]) >> 1) & 1, frames_per_launch=int(v[5]), wide_with_batch=int(v[6]),
+                    lane=int(v[7]))
 
     def debug_candidates(self, frame: int, level: int) -> np.ndarray:
         n = self._check(self._L.orbx_debug_candidates(self._h, frame, level, None, 0))

@@ -1121,6 +1121,7 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
                                 ctx->hFlagsDev + ctx->parity, dMax, ctx->hMaxNDev + si * ORBX_MAX_LEVELS));
     ctx->maxSlotsUsed |= 1 << si;
     tm.stop(staged ? 1 : 2);
+    ctx->lastLaunch[4] = (ctx->lastLaunch[4] & 1) | (staged ? 2 : 0);
   }
   {
     StageTimer tm(ctx, ORBX_STAGE_DESCRIBE, si, st);

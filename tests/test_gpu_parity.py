@@ -1224,6 +1224,8 @@ def test_tiled_pyramid_small_batches(orbx, oracle, params):
         e.extract_batch_device(d_img, B, w, h, stride, stride * h, d_k, d_d, d_n, cap)
         info = e.debug_last_launch()
         assert info["pyramid_banded"] == (2 if B <= 8 else 0), (w, h, B, info)
+        # launches of up to 64 (frame, level) units: k_describe_patch indexes the selection's staging lists itself (no k_sel_compact)
+        assert info["staged_lists"] == (1 if B * nlev <= 64 else 0), (w, h, B, info)
         n = d_n.cpu().numpy()
         kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, cap)
         dd = d_d.cpu().numpy().reshape(B, cap, 32)
