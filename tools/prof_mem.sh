@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export ORBX_NO_SPLIT=1
 cd $R
-P="python3 bench.py --depth 0 --steps 3 --warmup 1 --regions 1 --no-cpu-baseline --no-single-frame"
+P="python3 bench.py --depth 0 --steps 3 --warmup 1 --regions 1 --no-cpu-baseline --no-single-frame --no-other-configs"
 pass() { n=$1; shift; timeout -k 10 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -- $P > $OUT/$n.log 2>&1; echo "pass $n rc=$?" | tee -a $OUT/progress.txt; }
 pass ta1 TA_TA_BUSY TA_FLAT_READ_WAVEFRONTS TD_TD_BUSY TD_TC_STALL TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ
 pass ta2 TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES TCP_PENDING_STALL_CYCLES TCP_TCP_TA_DATA_STALL_CYCLES
