@@ -1240,7 +1240,7 @@ int waitOldest(orbx_ctx* ctx) {
     for (int l = 0; l < ctx->p.nlevels; l++) {
       int m = 0;
       for (int q = 0; q < 2; q++)
-        if (ctx->maxSlotsUsed & (1 << q)) m = std::max(m, ctx->hMaxN[q * ORBX_MAX_LEVELS + l]);
+        if (ctx->maxSlotsUsed & (1 << q)) { const int v = ctx->hMaxN[q * ORBX_MAX_LEVELS + l]; m = ORBX_OCT_FB_MAX(m, v); }
       ctx->candHintL[l] = m;
     }
     if (ctx->pending == 0) ctx->maxSlotsUsed = 0;

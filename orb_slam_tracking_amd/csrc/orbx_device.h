@@ -137,6 +137,12 @@ struct OctLaunch {
 };
 
 #define ORBX_OCT_MAX_CAND ((1 << 19) - 1)  // candidates per (frame, level) the selection stage can index
+// what a unit reports for the next batch's launch choices (maxN[], hostMaxN[], the host's candHintL[]): its candidate count and, from
+// k_octree_big, the fill of its fullest bucket; the reducers take the maximum of each field
+#define ORBX_OCT_FEEDBACK(n, fill) ((int)(n) | ((int)(fill) << 20))
+#define ORBX_OCT_FB_COUNT(v) ((int)(v) & 0xfffff)
+#define ORBX_OCT_FB_FILL(v) ((int)(v) >> 20)
+#define ORBX_OCT_FB_MAX(a, b) ORBX_OCT_FEEDBACK(ORBX_OCT_FB_COUNT(a) > ORBX_OCT_FB_COUNT(b) ? ORBX_OCT_FB_COUNT(a) : ORBX_OCT_FB_COUNT(b), ORBX_OCT_FB_FILL(a) > ORBX_OCT_FB_FILL(b) ? ORBX_OCT_FB_FILL(a) : ORBX_OCT_FB_FILL(b))
 
 // Bucket depth of a level for one launch of the many-workgroup selection (k_octree_buckets / k_octree_big): the coarsest depth
 // that leaves a bucket at most 256 keys on average of the `hint` candidates a unit of that level had in the previous batch (a

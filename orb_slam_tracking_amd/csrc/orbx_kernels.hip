@@ -1268,10 +1268,12 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
         if ((lane & 15) < g.nlevels)
           for (int fr = lane >> 4; fr < (int)gridDim.y; fr += 4) {
             const int idx = (g.frame0 + fr) * g.nlevels + (lane & 15);
-            m = max(m, ds.maxN[idx]);
+            const int v = ds.maxN[idx];
+            m = ORBX_OCT_FB_MAX(m, v);  // (count and bucket fill: the maximum of each field)
             ds.maxN[idx] = 0;
           }
-        m = max(m, __shfl_xor(m, 16)); m = max(m, __shfl_xor(m, 32));
+        { const int t = __shfl_xor(m, 16); m = ORBX_OCT_FB_MAX(m, t); }
+        { const int t = __shfl_xor(m, 32); m = ORBX_OCT_FB_MAX(m, t); }
         if (lane < g.nlevels) ds.hostMaxN[lane] = m;
       }
     }

@@ -297,6 +297,7 @@ __device__ __forceinline__ void waveSort32(uint32_t* a, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      \
   } while (0)
 
+template <int CAP>  // LDS slots per wave (512 / 1024): chosen from the previous batch's fullest bucket -- 22 / 38 KB per workgroup
 __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __restrict__ cand, const int* __restrict__ cellCount,
                                                           const OctLaunch P, uint8_t* __restrict__ scratch, int level0, int level1,
                                                           int nFrames) {
@@ -324,8 +325,9 @@ __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __res
     if (lane == 0) OCT_XCC_B1(u);
   }
   const OctLevel& L = P.lev[level];
-  __shared__ uint32_t keysAll[OCTB_WAVES][ORBX_OCTB_CAP];
-  __shared__ uint32_t ceAll[OCTB_WAVES][ORBX_OCTB_CAP];
+  static_assert(CAP <= ORBX_OCTB_CAP && CAP >= 64, "bucket slots in LDS");
+  __shared__ uint32_t keysAll[OCTB_WAVES][CAP];
+  __shared__ uint32_t ceAll[OCTB_WAVES][CAP];
   __shared__ int cpreAll[OCTB_WAVES][OCTB_MAXCELLS + 1];
   __shared__ uint16_t cidxAll[OCTB_WAVES][OCTB_MAXCELLS + 1];
   uint32_t* keysL = keysAll[wv];
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __res
         const unsigned long long m = __ballot(in);
         if (in) {
           const int slot = n + __popcll(m & ((1ull << lane) - 1ull));
-          if (slot < ORBX_OCTB_CAP) {
+          if (slot < CAP) {
             keysL[slot] = (((digits[j] >> rshift) & remMask) << 10) | (uint32_t)slot;
             ceL[slot] = ce[j];
           }
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(OCTB_T) void k_octree_buckets(const uint32_t* __res
       }
     }
   }
-  if (over || n >= capB || n > ORBX_OCTB_CAP) {  // (n == capB: the slot's last entry holds the divergence to the next bucket)
+  if (over || n >= capB || n > CAP) {  // (n == capB: the slot's last entry holds the divergence to the next bucket)
     if (lane == 0) { info[0] = 0; info[3] = 1; }
     return;
   }
@@ -621,31 +623,35 @@ __global__ __launch_bounds__(ORBX_TAIL_T) void k_sel_compact(const SelKp* __rest
   // (small launches: the first workgroup, one count per thread; else workgroup l takes level l)
   const int nUnits = (int)gridDim.x * P.nlevels;
   if (maxN && part == 0 && (nUnits <= 256 ? blockIdx.x == 0 : (int)blockIdx.x < P.nlevels)) {
-    __shared__ int red[ORBX_MAX_LEVELS];
-    if (threadIdx.x < P.nlevels) red[threadIdx.x] = 0;
+    __shared__ int red[ORBX_MAX_LEVELS], redFill[ORBX_MAX_LEVELS];  // (ORBX_OCT_FEEDBACK: count and bucket fill, the maximum of each)
+    if (threadIdx.x < P.nlevels) { red[threadIdx.x] = 0; redFill[threadIdx.x] = 0; }
     __syncthreads();
     if (nUnits <= 256) {
       for (int u = threadIdx.x; u < nUnits; u += T) {
         const int idx = P.frame0 * P.nlevels + u;
         const int v = maxN[idx];
         maxN[idx] = 0;
-        if (v > 0) atomicMax(&red[u % P.nlevels], v);
+        if (v > 0) {
+          atomicMax(&red[u % P.nlevels], ORBX_OCT_FB_COUNT(v));
+          atomicMax(&redFill[u % P.nlevels], ORBX_OCT_FB_FILL(v));
+        }
       }
       __syncthreads();
-      if (threadIdx.x < P.nlevels) hostMaxN[threadIdx.x] = red[threadIdx.x];
+      if (threadIdx.x < P.nlevels) hostMaxN[threadIdx.x] = ORBX_OCT_FEEDBACK(red[threadIdx.x], redFill[threadIdx.x]);
     } else {
       const int l = blockIdx.x;
       int m = 0;
       for (int i = threadIdx.x; i < (int)gridDim.x; i += T) {
         const int idx = (P.frame0 + i) * P.nlevels + l;
-        m = max(m, maxN[idx]);
+        const int v = maxN[idx];
+        m = ORBX_OCT_FB_MAX(m, v);
         maxN[idx] = 0;
       }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-      if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&red[l], m);
+      for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(m, o); m = ORBX_OCT_FB_MAX(m, t); }
+      if ((threadIdx.x & 63) == 0 && m > 0) { atomicMax(&red[l], ORBX_OCT_FB_COUNT(m)); atomicMax(&redFill[l], ORBX_OCT_FB_FILL(m)); }
       __syncthreads();
-      if (threadIdx.x == 0) hostMaxN[l] = red[l];
+      if (threadIdx.x == 0) hostMaxN[l] = ORBX_OCT_FEEDBACK(red[l], redFill[l]);
     }
   }
   __shared__ int off[ORBX_MAX_LEVELS + 1];
@@ -713,7 +719,9 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
   // code of k_octree_global, the round-1..3 path), k_octree_emit picks the keypoints.  ORBX_OCT_NO_BIG (diagnostics): the old path.
   static const bool noBig = getenv("ORBX_OCT_NO_BIG") != nullptr;
   OctLaunch Q = P;  // the launch's bucket depths: from the candidate counts of the previous batch (octBigChoose)
-  for (int l = 0; l < Q.nlevels; l++) octBigChoose(&Q.lev[l], Q.scrNMax[l], hintL ? hintL[l] : 0);
+  // (hintL: ORBX_OCT_FEEDBACK values -- the previous batch's largest candidate count and fullest bucket per level)
+  auto hintOf = [&](int l) { return hintL ? ORBX_OCT_FB_COUNT(hintL[l]) : 0; };
+  for (int l = 0; l < Q.nlevels; l++) octBigChoose(&Q.lev[l], Q.scrNMax[l], hintOf(l));
   auto launchBig = [&](int l0, int l1, bool fallback) {
     int nBuckets = 0;
     for (int l = l0; l < l1; l++) nBuckets += Q.lev[l].bigBuckets;
@@ -722,8 +730,23 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
       long long perXcd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, most = 0;
       for (int u = 0; u < (l1 - l0) * nFrames; u++) perXcd[u & 7] += Q.lev[l0 + u / nFrames].bigBuckets;
       for (int x = 0; x < 8; x++) most = std::max(most, perXcd[x]);
-      hipLaunchKernelGGL(k_octree_buckets, dim3((unsigned)(8 * ((most + OCTB_WAVES - 1) / OCTB_WAVES)), 1, 1), dim3(OCTB_T), 0, st, cand,
-                         cellCount, Q, scratch, l0, l1, nFrames);
+      // the waves' LDS slots: 512 per bucket when the previous batch's fullest bucket of these levels leaves a quarter of that free
+      // (five workgroups per CU instead of four: 41 -> 36 us per half batch at 1080p / 4K); a fuller bucket overflows into the
+      // in-place redo of its unit and reports ORBX_OCTB_CAP, which brings the 1024-slot instance back for the next batch
+      int fillMost = 0;
+      bool known = hintL != nullptr;
+      for (int l = l0; l < l1; l++)
+        if (Q.lev[l].bigBuckets > 0) {
+          const int fl = hintL ? ORBX_OCT_FB_FILL(hintL[l]) : 0;
+          known = known && fl > 0;
+          fillMost = std::max(fillMost, fl);
+        }
+      static const bool noSmallSlots = getenv("ORBX_OCTB_NO_512") != nullptr;  // diagnostics
+      const dim3 bgrid((unsigned)(8 * ((most + OCTB_WAVES - 1) / OCTB_WAVES)), 1, 1);
+      if (known && !noSmallSlots && fillMost * 4 <= 512 * 3)
+        hipLaunchKernelGGL(k_octree_buckets<512>, bgrid, dim3(OCTB_T), 0, st, cand, cellCount, Q, scratch, l0, l1, nFrames);
+      else
+        hipLaunchKernelGGL(k_octree_buckets<ORBX_OCTB_CAP>, bgrid, dim3(OCTB_T), 0, st, cand, cellCount, Q, scratch, l0, l1, nFrames);
       hipLaunchKernelGGL(k_octree_big, dim3(nFrames, l1 - l0, 1), dim3(1024), 0, st, cand, cellCount, Q, selStage, nselLevel, scratch, maxN, l0,
                          fallback ? 1 : 0);
       int qMost = 1;
@@ -746,7 +769,7 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
   int largest = 512;
   bool anyBig = false;
   for (int l = 0; l < P.nlevels; l++) {
-    inst[l] = force > 0 ? force : octInstanceFor(P.lev[l].quota, hintL ? hintL[l] : 0);
+    inst[l] = force > 0 ? force : octInstanceFor(P.lev[l].quota, hintOf(l));
     if (noSmall && inst[l] != 0 && force == 0) inst[l] = 2048;
     if (inst[l] == 0) anyBig = true;
     largest = std::max(largest, inst[l] == 0 ? 2048 : inst[l]);
@@ -756,11 +779,11 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
   if (nFrames < splitMin && force == 0)
     for (int l = 0; l < P.nlevels; l++) inst[l] = anyBig ? 0 : largest;
   static const char* instEnv = getenv("ORBX_OCT_INST");  // diagnostics: "2048,2048,1024,512,..." = the instance of every level
-  if (instEnv && force == 0 && !anyBig && hintL && hintL[0] > 0) {
+  if (instEnv && force == 0 && !anyBig && hintL && hintOf(0) > 0) {
     const char* q = instEnv;
     for (int l = 0; l < P.nlevels && *q; l++) {
       const int v = atoi(q);
-      if (v == 512 || v == 1024 || v == 2048) inst[l] = std::max(inst[l] == largest ? octInstanceFor(P.lev[l].quota, hintL[l]) : inst[l], v);
+      if (v == 512 || v == 1024 || v == 2048) inst[l] = std::max(inst[l] == largest ? octInstanceFor(P.lev[l].quota, hintOf(l)) : inst[l], v);
       while (*q && *q != ',') q++;
       if (*q == ',') q++;
     }
