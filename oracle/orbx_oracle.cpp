@@ -13,6 +13,7 @@
 // Build: see oracle/Makefile  (g++ -O3 -ffp-contract=off, no -march, like the reference's
 // Release build, CMakeLists.txt:8-10).
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <climits>
@@ -419,11 +420,84 @@ float icAngle(const Image& im, float px, float py, const int* umax, int* m10_out
   return fastAtan2((float)m_01, (float)m_10);
 }
 
-// computeOrbDescriptor, cpp:169-228.  cos/sin of a float argument: evaluated in double and
-// rounded to float (= correctly rounded cosf/sinf up to double-rounding).
+// ---- the libm reading of cpp:174 and cpp:536 (orbo_set_libm_variant, mirrored by the product's orbx_set_libm_variant) ----
+// cpp:174 calls UNQUALIFIED cos(angle) / sin(angle) on a float, and the file has no `using namespace std` (cpp:69-71 import
+// list / pair / vector only).  Which function that is depends on what the OpenCV headers pull in:
+//   * only <cmath>: the global namespace holds ::cos(double) alone -> the float is promoted, the double result converted back:
+//     (float)cos((double)angle)                                                        = variant 0, ORBX_LIBM_DOUBLE
+//   * libstdc++'s <math.h> wrapper anywhere in the include chain (it does `using std::cos;`): overload resolution picks
+//     std::cos(float) = __builtin_cosf -> glibc's cosf                                 = variant 1, ORBX_LIBM_FLOAT
+// glibc >= 2.28 evaluates sinf / cosf with an f64 polynomial that is NOT correctly rounded (sysdeps/ieee754/flt-32/
+// s_sincosf.h, s_sinf.c, s_cosf.c, s_sincosf_data.c; the algorithm of ARM's optimized-routines): over the 1,135,869,953 f32
+// angles in [0, 360] it differs from variant 0 for 483,807 (cos) / 1,001,902 (sin) of them.  Restated below operation for
+// operation (public algorithm, constants from s_sincosf_data.c); tests/test_oracle.py sweeps EVERY angle against the host's own
+// cosf / sinf.  The x86-64 multiarch build contracts the polynomials into FMAs on CPUs that have them, the baseline build does
+// not: both forms are compiled here (USE_FMA) and both agree with each other after the rounding to f32 for every angle of the
+// domain (same sweep), so one variant covers both.  The same reading decides pow(float, float) of the constructor (cpp:536).
+int gLibmVariant = 0;
+namespace glibc_sincosf {
+struct SinCosT { double sign[4]; double hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3; };
+const SinCosT kTab[2] = {
+    {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, 0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5,
+     -0x1.6c087e89a359dp-10, 0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13},
+    {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, -0x1p0, 0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5,
+     0x1.6c087e89a359dp-10, -0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13}};
+inline uint32_t abstop12(float x) { uint32_t u; std::memcpy(&u, &x, 4); return (u >> 20) & 0x7ff; }
+template <bool FMA> inline double ma(double a, double b, double c) { return FMA ? std::fma(a, b, c) : a * b + c; }
+// sinf_poly: sine polynomial for even n, cosine polynomial for odd n
+template <bool FMA> inline float poly(double x, double x2, const SinCosT* p, int n) {
+  if ((n & 1) == 0) {
+    const double x3 = x * x2, s1 = ma<FMA>(x2, p->s3, p->s2), x7 = x3 * x2, s = ma<FMA>(x3, p->s1, x);
+    return (float)ma<FMA>(x7, s1, s);
+  }
+  const double x4 = x2 * x2, c2 = ma<FMA>(x2, p->c4, p->c3), c1 = ma<FMA>(x2, p->c1, p->c0), x6 = x4 * x2, c = ma<FMA>(x4, p->c2, c1);
+  return (float)ma<FMA>(x6, c2, c);
+}
+// reduce_fast (!TOINT_INTRINSICS: x86-64): quadrant from the scaled float-to-int conversion, one multiply-subtract
+template <bool FMA> inline double reduceFast(double x, const SinCosT* p, int* np) {
+  const double r = x * p->hpi_inv;
+  const int n = ((int32_t)r + 0x800000) >> 24;
+  *np = n;
+  return FMA ? std::fma(-(double)n, p->hpi, x) : x - n * p->hpi;
+}
+// valid for 0 <= y < 120 (the keypoint angle in radians is below 6.2832); the huge-argument branch is not restated
+template <bool FMA> float sinF(float y) {
+  double x = y;
+  const SinCosT* p = &kTab[0];
+  if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+    if (abstop12(y) < abstop12(0x1p-12f)) return y;
+    return poly<FMA>(x, x * x, p, 0);
+  }
+  int n;
+  x = reduceFast<FMA>(x, p, &n);
+  const double s = p->sign[n & 3];
+  if (n & 2) p = &kTab[1];
+  return poly<FMA>(x * s, x * x, p, n);
+}
+template <bool FMA> float cosF(float y) {
+  double x = y;
+  const SinCosT* p = &kTab[0];
+  if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+    if (abstop12(y) < abstop12(0x1p-12f)) return 1.0f;
+    return poly<FMA>(x, x * x, p, 1);
+  }
+  int n;
+  x = reduceFast<FMA>(x, p, &n);
+  const double s = p->sign[n & 3];
+  if (n & 2) p = &kTab[1];
+  return poly<FMA>(x * s, x * x, p, n ^ 1);
+}
+}  // namespace glibc_sincosf
+inline void descSinCos(float angle, float* c, float* s) {
+  if (gLibmVariant) { *c = glibc_sincosf::cosF<true>(angle); *s = glibc_sincosf::sinF<true>(angle); }
+  else { *c = (float)std::cos((double)angle); *s = (float)std::sin((double)angle); }
+}
+
+// computeOrbDescriptor, cpp:169-228.  cos / sin of the float argument: see the libm variants above.
 void orbDescriptor(const Image& blurred, const KP& kp, uint8_t* desc) {
   const float angle = kp.angle * factorPI;
-  const float c = (float)std::cos((double)angle), s = (float)std::sin((double)angle);
+  float c, s;
+  descSinCos(angle, &c, &s);
   const int cx = cvRoundF(kp.x), cy = cvRoundF(kp.y);
   const uint8_t* center = &blurred.px[(size_t)cy * blurred.w + cx];
   const int step = blurred.w;
@@ -467,7 +541,11 @@ struct Extractor {
     for (int i = 0; i < nl; i++) { invScale[i] = 1.0f / scale[i]; invSigma2[i] = 1.0f / sigma2[i]; }
     quota.resize(nl);
     const float factor = (float)(1.0f / scaleFactor);
-    float desired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)(float)nl));
+    // cpp:536 pow(float, float): the same overload question as cos / sin (libm variants above): ::pow(double, double) or powf.
+    // powf is the host libm's (what a reference built on this host calls); it differs from the double reading for 89 k of the
+    // 134 M (factor, nlevels) pairs with factor in [0.5, 1) and never for a two-decimal scale factor 1.01 .. 2.00
+    const float powv = gLibmVariant ? powf(factor, (float)nl) : (float)std::pow((double)factor, (double)(float)nl);
+    float desired = nfeatures * (1 - factor) / (1 - powv);
     int sum = 0;
     for (int l = 0; l < nl - 1; l++) {
       quota[l] = cvRoundF(desired);
@@ -972,9 +1050,33 @@ void orbo_descriptor(const uint8_t* blurred, int w, int h, float x, float y, flo
   KP k{}; k.x = x; k.y = y; k.angle = angle;
   orbDescriptor(im, k, desc32);
 }
-void orbo_sincos_deg(float angle_deg, float* c, float* s) {
-  const float a = angle_deg * factorPI;
-  *c = (float)std::cos((double)a); *s = (float)std::sin((double)a);
+void orbo_sincos_deg(float angle_deg, float* c, float* s) { descSinCos(angle_deg * factorPI, c, s); }
+// Sweep of the f32 angles (degrees) with bit patterns [lo_bits, hi_bits]: out[0] / out[1] = angles whose restated glibc cosf / sinf
+// (FMA form) differs from the HOST's own cosf / sinf, out[2] / out[3] = the same for the form without FMAs, out[4] / out[5] =
+// angles whose host cosf / sinf differs from the double reading (float)cos((double)a).  nthreads host threads.
+void orbo_libm_sweep(uint32_t lo_bits, uint32_t hi_bits, int nthreads, long long* out6) {
+  if (nthreads < 1) nthreads = 1;
+  std::vector<std::array<long long, 6>> part((size_t)nthreads);
+  std::vector<std::thread> th;
+  const unsigned long long total = (unsigned long long)hi_bits - lo_bits + 1;
+  for (int t = 0; t < nthreads; t++)
+    th.emplace_back([&, t]() {
+      std::array<long long, 6> a{};
+      const unsigned long long b0 = lo_bits + total * t / nthreads, b1 = lo_bits + total * (t + 1) / nthreads;
+      for (unsigned long long u = b0; u < b1; u++) {
+        const uint32_t uu = (uint32_t)u;
+        float deg; std::memcpy(&deg, &uu, 4);
+        volatile float r = deg * factorPI;  // (volatile: the product is rounded to f32 exactly here)
+        const float rr = r;
+        const float hc = cosf(rr), hs = sinf(rr);
+        a[0] += hc != glibc_sincosf::cosF<true>(rr); a[1] += hs != glibc_sincosf::sinF<true>(rr);
+        a[2] += hc != glibc_sincosf::cosF<false>(rr); a[3] += hs != glibc_sincosf::sinF<false>(rr);
+        a[4] += hc != (float)std::cos((double)rr); a[5] += hs != (float)std::sin((double)rr);
+      }
+      part[(size_t)t] = a;
+    });
+  for (auto& x : th) x.join();
+  for (int k = 0; k < 6; k++) { out6[k] = 0; for (auto& a : part) out6[k] += a[(size_t)k]; }
 }
 void orbo_sincos_deg_batch(const float* angle_deg, int n, float* c, float* s) {  // cpp:173-174 for many angles
   for (int i = 0; i < n; i++) orbo_sincos_deg(angle_deg[i], &c[i], &s[i]);
@@ -1246,6 +1348,7 @@ int orbo_bench_protocol(int nfeatures, float scaleFactor, int nlevels, int iniTh
   return 0;
 }
 
+void orbo_set_libm_variant(int libm_variant) { gLibmVariant = libm_variant ? 1 : 0; }
 void orbo_set_opencv_variant(int gaussian_variant, int gray_variant) {
   gGaussVariant = gaussian_variant ? 1 : 0;
   gGrayVariant = gray_variant ? 1 : 0;

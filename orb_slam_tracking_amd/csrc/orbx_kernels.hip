@@ -1150,9 +1150,17 @@ constexpr IcTables makeIcTables() {
 }
 __device__ const IcTables d_ic = makeIcTables();
 
+#ifndef ORBX_DESC_EXP
+#define ORBX_DESC_EXP 0      // 3 = diagnostic build without the window fetch (timing only: the kernel's issue bound; tools/exp_desc_fetch.sh)
+#endif
+#ifndef ORBX_DESC_LOADMAP
+#define ORBX_DESC_LOADMAP 0  // window staging: 0 = lane is a window row (three 16-byte loads per lane), 1 = lane is a (row, 16-byte piece) slot
+#endif
+#ifndef DESC_WAVES
 #define DESC_WAVES 3   // keypoints (= waves) per workgroup: consecutive keypoints of a frame's list are spatially close, so
                        // putting them on one CU lets their overlapping windows hit in that CU's L1 (1: 0.44 ms, 2: 0.38,
                        // 3: 0.365, 4: 0.39, 8: 0.44, 16: 0.63 per 256 frames; 3 slices of 5.8 KB keep 27 waves per CU)
+#endif
 // GV = Gaussian Q8 tap set (orbx_set_opencv_variant): 0 = [18,34,48,56,48,34,18] (error diffusion, sum 256: OpenCV >= 4.1.1 /
 // 3.4.7), 1 = [18,34,49,55,49,34,18] (every tap rounded, sum 257: the bit-exact path of 3.4.1 .. 4.1.0 and the integer filter
 // before it; a sum of 2^24 or more saturates to 255)
@@ -1320,24 +1328,52 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   const int w = L.w, h = L.h, stride = L.stride;
   const int ax = (kx - 21) & ~3;          // may be -4
   const int s = (kx - 21) - ax;           // byte offset of window column 0 inside a staged row, 0..3
-  // ---- stage the raw window: lanes 0..51 = 4 rows x 13 dwords per step, 11 steps, all loads in flight at once ----
+  // ---- stage the raw window.  Round 5: LANE = WINDOW ROW, the row as three 16-byte loads (4-byte aligned global_load_dwordx4):
+  //      3 vector-memory instructions per keypoint instead of 11 single-dword ones over (4 rows x 13 dwords) -- the CU's address /
+  //      return path charges per instruction and lane, and the window fetch was what kept the kernel off its issue bound (alone
+  //      per 256 frames: 0.334 ms; without any fetch 0.231 = the issue bound; this form 0.265; docs/history.md, round 5).
+  //      Columns kx-21 .. kx+21 end at byte s + 42 <= 45 of the staged row: 48 bytes hold them; dword 12 of a row only ever meets
+  //      zero taps (blurred columns 37..39, the padding of the last group of four, are never sampled) and is left as it is. ----
   {
-    const int rsub = lane / PW_WORDS, d = lane - rsub * PW_WORDS;
-    const int xs = ax + 4 * d;
-    const bool active = lane < 4 * PW_WORDS;
-    const bool fastx = aligned && xs >= 0 && xs + 4 <= w;
     if (lane == 0) { msum[0] = 0; msum[1] = 0; }
-    if (ky - 21 >= 0 && ky + 21 < h) {  // (uniform) no row of the window is reflected: one lane offset, the base steps by 4 rows
-      // (uniform base + 32-bit lane offset: global_load with an SGPR address, no 64-bit vector arithmetic)
-      const uint32_t voff = (uint32_t)(rsub * stride + xs + 4);  // + 4: xs may be -4
-      const uint8_t* pu = img + ((long long)(ky - 21) * stride - 4);
-      const int step = 4 * stride;
-#pragma unroll
-      for (int it = 0; it < 11; it++) {
-        if (active && fastx && it * 4 + rsub < PW_ROWS) raw[it * (4 * PW_WORDS) + lane] = *reinterpret_cast<const uint32_t*>(pu + voff);
-        pu += step;
+    const bool rowsInside = aligned && ax >= 0 && ax + 48 <= w;  // (uniform) no staged dword crosses the level's left / right side
+#if ORBX_DESC_EXP == 3  // TIMING ONLY: no window fetch at all (the kernel's issue bound)
+    if (false)
+#endif
+    if (rowsInside) {
+      typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+#if ORBX_DESC_LOADMAP == 0
+      if (lane < PW_ROWS) {
+        int yy = ky - 21 + lane;
+        yy = yy < 0 ? -yy : yy; yy = yy >= h ? 2 * h - 2 - yy : yy;  // REFLECT_101 (a keypoint is at least 19 px from the border)
+        // (uniform base + 32-bit lane offset: global_load with an SGPR address)
+        const uint8_t* p = img + (uint32_t)(yy * stride + ax);
+        const u32x4_a4 q0 = *reinterpret_cast<const u32x4_a4*>(p), q1 = *reinterpret_cast<const u32x4_a4*>(p + 16),
+                       q2 = *reinterpret_cast<const u32x4_a4*>(p + 32);
+        uint32_t* dst = raw + lane * PW_WORDS;
+        dst[0] = q0.x; dst[1] = q0.y; dst[2] = q0.z; dst[3] = q0.w; dst[4] = q1.x; dst[5] = q1.y; dst[6] = q1.z; dst[7] = q1.w;
+        dst[8] = q2.x; dst[9] = q2.y; dst[10] = q2.z; dst[11] = q2.w;
       }
+#else  // (experiment: slot = (row, 16-byte piece), 129 slots over the lanes of three instructions)
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const int idx = t * 64 + lane, r = idx / 3, c = idx - 3 * r;
+        if (idx < 3 * PW_ROWS) {
+          int yy = ky - 21 + r;
+          yy = yy < 0 ? -yy : yy; yy = yy >= h ? 2 * h - 2 - yy : yy;
+          const u32x4_a4 q = *reinterpret_cast<const u32x4_a4*>(img + (uint32_t)(yy * stride + ax + 16 * c));
+          uint32_t* dst = raw + r * PW_WORDS + 4 * c;
+          dst[0] = q.x; dst[1] = q.y; dst[2] = q.z; dst[3] = q.w;
+        }
+      }
+#endif
     } else {
+      // the window crosses the level's left / right side (or level 0 is not dword-aligned): lanes 0..51 = 4 rows x 13 dwords per
+      // step; dwords inside the level by dword loads, the others byte by byte with REFLECT_101
+      const int rsub = lane / PW_WORDS, d = lane - rsub * PW_WORDS;
+      const int xs = ax + 4 * d;
+      const bool active = lane < 4 * PW_WORDS;
+      const bool fastx = aligned && xs >= 0 && xs + 4 <= w;
 #pragma unroll
       for (int it = 0; it < 11; it++) {
         const int r = it * 4 + rsub;
@@ -1347,20 +1383,20 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
           raw[it * (4 * PW_WORDS) + lane] = *reinterpret_cast<const uint32_t*>(img + (yy * stride + xs));
         }
       }
-    }
-    if (active && !fastx) {  // window dwords that cross the level's left/right edge (or an unaligned level 0): bytes, REFLECT_101
-      for (int r = rsub; r < PW_ROWS; r += 4) {
-        int yy = ky - 21 + r;
-        yy = yy < 0 ? -yy : yy; yy = yy >= h ? 2 * h - 2 - yy : yy;
-        const uint8_t* row = img + (long long)yy * stride;
-        uint32_t word = 0;
+      if (active && !fastx) {
+        for (int r = rsub; r < PW_ROWS; r += 4) {
+          int yy = ky - 21 + r;
+          yy = yy < 0 ? -yy : yy; yy = yy >= h ? 2 * h - 2 - yy : yy;
+          const uint8_t* row = img + (long long)yy * stride;
+          uint32_t word = 0;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-          int xx = xs + b;
-          xx = xx < 0 ? -xx : xx; xx = xx >= w ? 2 * w - 2 - xx : xx; xx = min(max(xx, 0), w - 1);
-          word |= (uint32_t)row[xx] << (8 * b);
+          for (int b = 0; b < 4; b++) {
+            int xx = xs + b;
+            xx = xx < 0 ? -xx : xx; xx = xx >= w ? 2 * w - 2 - xx : xx; xx = min(max(xx, 0), w - 1);
+            word |= (uint32_t)row[xx] << (8 * b);
+          }
+          raw[r * PW_WORDS + d] = word;
         }
-        raw[r * PW_WORDS + d] = word;
       }
     }
   }
