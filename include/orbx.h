@@ -96,6 +96,24 @@ void orbx_destroy(orbx_ctx* ctx);
 #define ORBX_GRAY_14BIT 0
 #define ORBX_GRAY_15BIT 1
 int orbx_set_opencv_variant(orbx_ctx* ctx, int gaussian_variant, int gray_variant);
+
+/* The libm reading of the reference's two unqualified <cmath> calls on floats: cos(angle) / sin(angle) of computeOrbDescriptor
+ * (Features/ORBextractor.cpp:174) and pow(factor, (float)nlevels) of the constructor (cpp:536).  The file has no `using namespace
+ * std` (cpp:69-71 import list / pair / vector only), so which function a call resolves to depends on the headers in the
+ * translation unit (DESIGN.md section 2 derives it from the reference's includes):
+ *   ORBX_LIBM_DOUBLE (default)  only ::cos(double) / ::pow(double, double) are visible in the global namespace (<cmath> alone):
+ *                               the float is promoted, the double result converted back -- (float)cos((double)angle)
+ *   ORBX_LIBM_FLOAT             libstdc++'s <math.h> wrapper is in the include chain (`using std::cos;` ...): std::cos(float) =
+ *                               cosf, std::pow(float, float) = powf.  cosf / sinf = glibc >= 2.28's algorithm, restated in the
+ *                               kernel operation for operation (it is not correctly rounded: of the 1,135,869,953 f32 angles
+ *                               in [0, 360], 1,484,894 give a different (cos, sin) pair than ORBX_LIBM_DOUBLE, and for 96 of
+ *                               them a rotated sample point lands on another pixel); powf = the host libm's.
+ * Takes effect for the calls that follow (batches in flight are waited for; an earlier batch's error is returned as by
+ * orbx_set_opencv_variant).  If the constructor's pow changes a per-level quota (it does for 138 of 8e8 tried (factor, nlevels,
+ * nfeatures) combinations and never for a scale factor with two decimals), the context's buffers are re-planned. */
+#define ORBX_LIBM_DOUBLE 0
+#define ORBX_LIBM_FLOAT 1
+int orbx_set_libm_variant(orbx_ctx* ctx, int libm_variant);
 const char* orbx_last_error(const orbx_ctx* ctx);
 
 /* ---- getters (Features/ORBextractor.hpp:87-108) ------------------------------------------- */

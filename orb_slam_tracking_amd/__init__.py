@@ -99,6 +99,7 @@ def lib() -> ctypes.CDLL:
     L.orbx_extract_match_batch_device_async.argtypes = [vp, i32, vp, i32, i32, i32, sz, vp, vp, i32, vp, i32, vp, vp,
                                                   ctypes.POINTER(_Bounds), i32, f32, i32, vp, vp, vp]
     L.orbx_set_opencv_variant.argtypes = [vp, i32, i32]
+    L.orbx_set_libm_variant.argtypes = [vp, i32]
     L.orbx_set_pipeline_depth.argtypes = [vp, i32]
     L.orbx_wait_one.argtypes = [vp]
     L.orbx_wait.argtypes = [vp]
@@ -204,6 +205,13 @@ class ORBextractor:
     def set_opencv_variant(self, gaussian_variant: int = 0, gray_variant: int = 0) -> None:
         """The two OpenCV-release dependent constants of the path (include/orbx.h): Gaussian Q8 taps, BGR2GRAY coefficients."""
         self._check(self._L.orbx_set_opencv_variant(self._h, int(gaussian_variant), int(gray_variant)), "orbx_set_opencv_variant")
+
+    LIBM_DOUBLE, LIBM_FLOAT = 0, 1
+
+    def set_libm_variant(self, libm_variant: int = 0) -> None:
+        """The libm reading of the reference's unqualified cos / sin / pow on floats (include/orbx.h): 0 = through double,
+        1 = cosf / sinf / powf (glibc >= 2.28's algorithm)."""
+        self._check(self._L.orbx_set_libm_variant(self._h, int(libm_variant)), "orbx_set_libm_variant")
 
     def order_after(self, stream: Optional[int]) -> None:
         """Work issued on this context from now on starts after everything queued on `stream` (hipStream_t handle)."""

@@ -34,7 +34,8 @@ hipError_t launch_pyramid_bands(hipStream_t st, int nFrames, const uint8_t* img0
                                 const Geom& g, const ResizeTab* tab, const PyrBands& pb);
 hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const uint8_t* img0, long long img0FrameStride,
                                  int img0Aligned, const uint8_t* pyr, const Geom& g, const SelKp* sel, const int* nsel,
-                                 orbx_keypoint* kps, uint8_t* desc, int capacity, int gaussVariant, const DescStage* staged);
+                                 orbx_keypoint* kps, uint8_t* desc, int capacity, int gaussVariant, int libmFloat,
+                                 const DescStage* staged);
 hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int* dSecond, const orbx_keypoint* kps,
                         const uint8_t* desc, const int* nkp, int capacity, orbx_bounds b, int window, float nnratio, int checkOri,
                         int* matches12, int* nmatches, int* stats, int* scratch, int pair0, int wideMode, int* hostWide);
@@ -48,7 +49,7 @@ hipError_t launch_to_gray(hipStream_t st, int nFrames, const uint8_t* src, long 
                           int channels, int rgb, uint8_t* dst, long long dstFrameStride, int dstride, int grayVariant);
 hipError_t launch_check_model(hipStream_t st, int nModels, const ScoreArgs& a);
 hipError_t launch_check_rt(hipStream_t st, int nModels, const CheckRtArgs& a);
-hipError_t launch_debug_sincos(hipStream_t st, const float* angle, int n, float* c, float* s);
+hipError_t launch_debug_sincos(hipStream_t st, const float* angle, int n, float* c, float* s, int libmFloat);
 hipError_t launch_undistort(hipStream_t st, int nFrames, const orbx_keypoint* in, const int* nkp, int capacity, const CamD& c,
                             orbx_keypoint* out);
 
@@ -80,6 +81,7 @@ struct orbx_ctx {
   std::vector<int> quota;
   int umax[16]{};
   int gaussVariant = 0, grayVariant = 0;  // orbx_set_opencv_variant
+  int libmVariant = 0;                    // orbx_set_libm_variant
   int selCap = 0;  // sum of the per-level quotas
 
   // geometry of the current frame size
@@ -249,7 +251,9 @@ void computeTables(orbx_ctx* c) {
   }
   c->quota.assign(nl, 0);
   const float factor = (float)(1.0f / scaleFactor);
-  float desired = c->p.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)(float)nl));
+  // cpp:536 pow(float, float): ::pow(double, double) or, with the float overloads visible, powf (orbx_set_libm_variant)
+  const float powv = c->libmVariant ? powf(factor, (float)nl) : (float)std::pow((double)factor, (double)(float)nl);
+  float desired = c->p.nfeatures * (1 - factor) / (1 - powv);
   int sum = 0;
   for (int l = 0; l < nl - 1; l++) {
     c->quota[l] = cvRoundF(desired);
@@ -1131,7 +1135,7 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
     ds.selStride = oct.selStride;
     for (int l = 0; l < ORBX_MAX_LEVELS; l++) ds.selOff[l] = oct.selOff[l];
     HIPCHK(launch_describe_patch(st, n, g.selCap, a.dImg0, a.frameStride0, a.aligned0, ctx->dPyr, g, ctx->dSel, ctx->dNsel,
-                                 a.dKps, a.dDesc, a.capacity, ctx->gaussVariant, staged ? &ds : nullptr));
+                                 a.dKps, a.dDesc, a.capacity, ctx->gaussVariant, ctx->libmVariant, staged ? &ds : nullptr));
     tm.stop(1);
   }
   return ORBX_OK;
@@ -1502,6 +1506,31 @@ int orbx_set_opencv_variant(orbx_ctx* ctx, int gaussian_variant, int gray_varian
   ctx->grayVariant = gray_variant;
   for (orbx_ctx* c : ctx->lanes) { c->gaussVariant = gaussian_variant; c->grayVariant = gray_variant; }
   return ORBX_OK;
+}
+
+int orbx_set_libm_variant(orbx_ctx* ctx, int libm_variant) {
+  if (!ctx || libm_variant < 0 || libm_variant > 1) return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  const int w = waitAll(ctx);  // batches in flight keep the reading they were issued with
+  if (w != ORBX_OK) return w;
+  if (libm_variant == ctx->libmVariant) return ORBX_OK;
+  // the descriptor's cos / sin is a kernel argument; the constructor's pow (cpp:536) feeds the per-level quotas: recomputed, and in
+  // the rare case that they change (never for a two-decimal scale factor) the buffers sized from them are re-planned
+  auto apply = [&](orbx_ctx* c) -> int {
+    const std::vector<int> oldQuota = c->quota;
+    c->libmVariant = libm_variant;
+    computeTables(c);
+    if (c->quota == oldQuota) return ORBX_OK;
+    c->curW = c->curH = 0;
+    c->curStride0 = -1;
+    return growTo(c, c->maxW, c->maxH, c->maxB);
+  };
+  int r = apply(ctx);
+  for (orbx_ctx* c : ctx->lanes) {
+    const int rl = apply(c);
+    if (r == ORBX_OK) r = rl;
+  }
+  return r;
 }
 
 const char* orbx_last_error(const orbx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -1878,6 +1907,7 @@ int orbx_set_pipeline_depth(orbx_ctx* ctx, int depth) {
     c->eventOrdered = ctx->eventOrdered;
     c->gaussVariant = ctx->gaussVariant;
     c->grayVariant = ctx->grayVariant;
+    c->libmVariant = ctx->libmVariant;
     c->profMask = ctx->profMask;
     ctx->lanes.push_back(c);
   }
@@ -2439,7 +2469,7 @@ int orbx_debug_sincos(orbx_ctx* ctx, const float* angle_deg, int n, float* cos_o
   auto body = [&]() -> int {
     HIPCHK(hipMalloc((void**)&d, (size_t)n * 3 * sizeof(float)));
     HIPCHK(hipMemcpyAsync(d, angle_deg, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(launch_debug_sincos(ctx->st, d, n, d + n, d + 2 * (size_t)n));
+    HIPCHK(launch_debug_sincos(ctx->st, d, n, d + n, d + 2 * (size_t)n, ctx->libmVariant));
     HIPCHK(hipMemcpyAsync(cos_out, d + n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(sin_out, d + 2 * (size_t)n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));

@@ -799,7 +799,7 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
   for (int cid = cid0; cid < cid1; cid++) {
   const FastCell c = cells[cid];  // wave-uniform: one s_load_dwordx8
   int* const myCount = cellCount + (long long)f * g.nCellsTotal + cid;
-  const int nw = (int)(c.nw_ch & 0xffffu), ch = (int)(c.nw_ch >> 16);
+  const int ch = (int)(c.nw_ch >> 16);
   if (ch == 0) {  // every cell writes its counter (also 0), so the counters need no clearing between batches
     if (lane == 0) *myCount = 0;
     continue;
@@ -808,29 +808,23 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
   const LevelGeom& L = g.L[level];
   const uint8_t* const base =
       (level == 0 ? img0 + (long long)f * img0FrameStride : pyr + L.imgOff + (long long)f * L.frameStride) + c.imgOff;
-  // ---- stage the cell image: lane = (row mod 4, dword), eight loads per lane in flight.  Rows and dwords beyond the cell
-  //      are clamped to its last ones (in-bounds duplicates), so nothing is predicated ----
+  // ---- stage the cell image: LANE = TILE ROW (a cell image has at most 64 rows), the row's TS bytes as TS / 16 16-byte loads
+  //      (4-byte aligned global_load_dwordx4) and as many ds_write_b128 -- 3 + 3 instructions per cell instead of 9 + 9 with
+  //      lane = (row mod 5, dword) (round 5: the CU's vector-memory path charges per instruction and lane, k_describe_patch).
+  //      Dwords beyond the cell's own nw hold the pixels to its right (inside the level's row or its padding: a cell image ends at
+  //      least ten bytes before the row does, and thirteen rows before the level does); nothing reads them unmasked ----
   {
-    // a load instruction covers RP whole tile rows: 5 rows of 12 dwords (60 lanes; the last four duplicate) or 4 rows of 16, and
-    // NB of them are in flight: 45 or 32 rows -- the cells of every frame size from VGA up (44 rows) in ONE batch
-    constexpr int DW = TS / 4, RP = 64 / DW, NB = TS == 48 ? 9 : 8;
-    const int lrow = TS == 48 ? (int)(((uint32_t)lane * 5462u) >> 16) : lane >> 4;  // lane / DW
-    const int rsub = min(lrow, RP - 1), wcol = lrow < RP ? lane - lrow * DW : DW - 1;
-    const unsigned wsrc = 4u * (unsigned)min(wcol, nw - 1);
+    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    constexpr int NQ = TS / 16;
     const int stride = (int)c.stride;
-    uint32_t* const tile32 = reinterpret_cast<uint32_t*>(tile);
-    for (int r0 = 0; r0 < ch; r0 += RP * NB) {
-      uint32_t v[NB];
+    if (lane < ch) {
+      const uint8_t* p = base + (unsigned)(lane * stride);
+      u32x4_a4 q[NQ];
 #pragma unroll
-      for (int j = 0; j < NB; j++) {
-        const int r = min(r0 + RP * j + rsub, ch - 1);
-        v[j] = *reinterpret_cast<const uint32_t*>(base + ((unsigned)(r * stride) + wsrc));
-      }
+      for (int j = 0; j < NQ; j++) q[j] = *reinterpret_cast<const u32x4_a4*>(p + 16 * j);
+      uint4* const dst = reinterpret_cast<uint4*>(tile + lane * TS);
 #pragma unroll
-      for (int j = 0; j < NB; j++) {
-        const int r = min(r0 + RP * j + rsub, ch - 1);
-        tile32[r * DW + wcol] = v[j];
-      }
+      for (int j = 0; j < NQ; j++) dst[j] = make_uint4(q[j].x, q[j].y, q[j].z, q[j].w);
     }
   }
   const int iw = (int)(c.iw_ih & 0xffffu), ih = (int)(c.iw_ih >> 16), xoff = (int)(c.xoff_level & 0xffffu);
@@ -1086,6 +1080,48 @@ __device__ __forceinline__ void sincosTable(double x, double* sn, double* cs) {
 #define ORBX_SINCOS(x, sn, cs, uniform) sincosTable<uniform>(x, sn, cs)
 #endif
 
+// ORBX_LIBM_FLOAT (orbx_set_libm_variant): cos(angle) / sin(angle) of cpp:174 read as cosf / sinf -- glibc >= 2.28's f64-polynomial
+// algorithm (sysdeps/ieee754/flt-32/s_sincosf.h, s_sinf.c, s_cosf.c; constants of s_sincosf_data.c), which is not correctly
+// rounded, repeated operation for operation in the FMA form of the x86-64 multiarch build.  Valid for 0 <= y < 120 (a keypoint
+// angle in radians is below 6.2832).  The oracle holds the same restatement and sweeps every f32 angle of [0, 360] against the
+// host's libm (tests/test_oracle.py); tests/test_gpu_parity.py::test_sincos_matches_libm compares this one with the oracle.
+__device__ __forceinline__ float sincosfGlibcPoly(double x, double x2, bool neg, bool cosine) {
+  // sinf_poly with __sincosf_table[neg]: the cosine coefficients change sign, the sine coefficients do not
+  if (!cosine) {
+    const double x3 = x * x2, s1 = fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7), x7 = x3 * x2;
+    const double s = fma(x3, -0x1.555545995a603p-3, x);
+    return (float)fma(x7, s1, s);
+  }
+  const double sg = neg ? -1.0 : 1.0;  // (exact: every coefficient of table 1 is the negated coefficient of table 0)
+  const double x4 = x2 * x2, c2 = fma(x2, sg * 0x1.99343027bf8c3p-16, sg * -0x1.6c087e89a359dp-10);
+  const double c1 = fma(x2, sg * -0x1.ffffffd0c621cp-2, sg * 0x1p0), x6 = x4 * x2;
+  const double c = fma(x4, sg * 0x1.55553e1068f19p-5, c1);
+  return (float)fma(x6, c2, c);
+}
+__device__ __forceinline__ void sincosfGlibc(float y, float* sn, float* cs) {
+  const uint32_t top12 = (__float_as_uint(y) >> 20) & 0x7ffu;
+  const double x = (double)y;
+  if (top12 < 0x3f4u) {             // abstop12(y) < abstop12(pi / 4)
+    if (top12 < 0x398u) {           // abstop12(y) < abstop12(0x1p-12f)
+      *sn = y; *cs = 1.0f;
+      return;
+    }
+    const double x2 = x * x;
+    *sn = sincosfGlibcPoly(x, x2, false, false);
+    *cs = sincosfGlibcPoly(x, x2, false, true);
+    return;
+  }
+  // reduce_fast (!TOINT_INTRINSICS): hpi_inv is 2 / pi * 2^24, the quadrant ends up in bits 24..31
+  const double r = x * 0x1.45F306DC9C883p+23;
+  const int n = ((int)r + 0x800000) >> 24;
+  const double xr = fma(-(double)n, 0x1.921FB54442D18p0, x);
+  const double sg = (n & 1) != ((n >> 1) & 1) ? -1.0 : 1.0;  // sign[n & 3] = {1, -1, -1, 1}
+  const bool neg = (n & 2) != 0;
+  const double xs = xr * sg, x2 = xr * xr;
+  *sn = sincosfGlibcPoly(xs, x2, neg, (n & 1) != 0);
+  *cs = sincosfGlibcPoly(xs, x2, neg, ((n ^ 1) & 1) != 0);
+}
+
 // cv::fastAtan2: plain f32 mul/add/div, no contraction
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
@@ -1237,7 +1273,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
                                                        int img0Aligned, const uint8_t* __restrict__ pyr, const Geom g,
                                                        const SelKp* __restrict__ sel, const int* __restrict__ nsel,
                                                        orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                       int capacity, const DescStage ds) {
+                                                       int capacity, const DescStage ds, const int libmFloat) {
   __shared__ __attribute__((aligned(16))) uint32_t ldsAll[DESC_WAVES][PW_WAVE_WORDS];
   static_assert(PW_WAVE_WORDS % 4 == 0, "every wave's LDS slice must stay 16-byte aligned");
   const int f = blockIdx.y + g.frame0, lane = threadIdx.x & 63;
@@ -1519,9 +1555,14 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   // ---- steered BRIEF (cpp:169-228).  cos/sin of the f32 argument are evaluated in f64 and rounded to f32 ----
   const uint8_t* bl = reinterpret_cast<const uint8_t*>(bl32);
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
-  double sd, cd;
-  ORBX_SINCOS((double)(angle * factorPI), &sd, &cd, true);
-  const float cs = (float)cd, sn = (float)sd;
+  float cs, sn;
+  if (libmFloat) {  // (uniform) ORBX_LIBM_FLOAT
+    sincosfGlibc(angle * factorPI, &sn, &cs);
+  } else {
+    double sd, cd;
+    ORBX_SINCOS((double)(angle * factorPI), &sd, &cd, true);
+    cs = (float)cd; sn = (float)sd;
+  }
   unsigned long long words[4];
 #pragma unroll
   for (int wq = 0; wq < 4; wq++) {
@@ -2941,18 +2982,23 @@ hipError_t launch_to_gray(hipStream_t st, int nFrames, const uint8_t* src, long 
 }
 
 // test hook: the cos / sin pair of k_describe_patch for arbitrary angles (degrees)
-__global__ __launch_bounds__(256) void k_debug_sincos(const float* __restrict__ angle, int n, float* __restrict__ c, float* __restrict__ s) {
+__global__ __launch_bounds__(256) void k_debug_sincos(const float* __restrict__ angle, int n, float* __restrict__ c, float* __restrict__ s,
+                                                      const int libmFloat) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
+  if (libmFloat) {
+    sincosfGlibc(angle[i] * factorPI, &s[i], &c[i]);
+    return;
+  }
   double sd, cd;
   ORBX_SINCOS((double)(angle[i] * factorPI), &sd, &cd, false);
   c[i] = (float)cd;
   s[i] = (float)sd;
 }
-hipError_t launch_debug_sincos(hipStream_t st, const float* angle, int n, float* c, float* s) {
+hipError_t launch_debug_sincos(hipStream_t st, const float* angle, int n, float* c, float* s, int libmFloat) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_debug_sincos, dim3((n + 255) / 256), dim3(256), 0, st, angle, n, c, s);
+  hipLaunchKernelGGL(k_debug_sincos, dim3((n + 255) / 256), dim3(256), 0, st, angle, n, c, s, libmFloat);
   return hipGetLastError();
 }
 
@@ -3059,7 +3105,8 @@ hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long lo
 
 hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const uint8_t* img0, long long img0FrameStride,
                                  int img0Aligned, const uint8_t* pyr, const Geom& g, const SelKp* sel, const int* nsel,
-                                 orbx_keypoint* kps, uint8_t* desc, int capacity, int gaussVariant, const DescStage* staged) {
+                                 orbx_keypoint* kps, uint8_t* desc, int capacity, int gaussVariant, int libmFloat,
+                                 const DescStage* staged) {
   // staged (optional): the selection's staging lists -- the kernel indexes them itself and writes the frames' totals (the caller
   // launched no k_sel_compact; see DescStage)
   if (maxSel <= 0 && !staged) return hipSuccess;
@@ -3069,16 +3116,16 @@ hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const 
   if (staged) {
     if (gaussVariant)
       hipLaunchKernelGGL((k_describe_patch<1, true>), grid, block, descPad, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps,
-                         desc, capacity, *staged);
+                         desc, capacity, *staged, libmFloat);
     else
       hipLaunchKernelGGL((k_describe_patch<0, true>), grid, block, descPad, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps,
-                         desc, capacity, *staged);
+                         desc, capacity, *staged, libmFloat);
   } else if (gaussVariant)
     hipLaunchKernelGGL((k_describe_patch<1, false>), grid, block, descPad, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps,
-                       desc, capacity, none);
+                       desc, capacity, none, libmFloat);
   else
     hipLaunchKernelGGL((k_describe_patch<0, false>), grid, block, descPad, st, img0, img0FrameStride, img0Aligned, pyr, g, sel, nsel, kps,
-                       desc, capacity, none);
+                       desc, capacity, none, libmFloat);
   return hipGetLastError();
 }
 

@@ -159,6 +159,26 @@ def set_opencv_variant(gaussian_variant=0, gray_variant=0):
     L.orbo_set_opencv_variant(int(gaussian_variant), int(gray_variant))
 
 
+def set_libm_variant(libm_variant=0):
+    """Process-wide: the libm reading of cos / sin (cpp:174) and pow (cpp:536): 0 = through double, 1 = cosf / sinf / powf;
+    mirrors the product's orbx_set_libm_variant.  Extractors built afterwards take the constructor's pow from it."""
+    L = lib()
+    L.orbo_set_libm_variant.argtypes = [ctypes.c_int]
+    L.orbo_set_libm_variant.restype = None
+    L.orbo_set_libm_variant(int(libm_variant))
+
+
+def libm_sweep(lo_bits: int, hi_bits: int, nthreads: int = 8):
+    """Angles (degrees, f32 bit patterns lo_bits .. hi_bits) for which [0, 1] the restated glibc cosf / sinf (FMA form), [2, 3] the
+    form without FMAs differ from the host's own cosf / sinf, and [4, 5] the host's cosf / sinf differ from (float)cos((double)a)."""
+    L = lib()
+    out = (ctypes.c_longlong * 6)()
+    L.orbo_libm_sweep.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+    L.orbo_libm_sweep.restype = None
+    L.orbo_libm_sweep(lo_bits, hi_bits, nthreads, out)
+    return list(out)
+
+
 def resize_linear(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
     src = np.ascontiguousarray(src)
     dst = np.zeros((dh, dw), np.uint8)
