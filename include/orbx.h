@@ -388,6 +388,12 @@ int orbx_debug_sincos(orbx_ctx* ctx, const float* angle_deg, int n, float* cos_o
  * halves on two streams, bit 1: the descriptor kernel took the selection's staging lists itself (small launches: no k_sel_compact); [5] frames per kernel launch; [6] 1 = the wide matcher kernels went with the batch; [7] lane the batch
  * went to (1-based; 0 = the context itself) }. */
 int orbx_debug_last_launch(const orbx_ctx* ctx, int32_t* info8);
+/* Diagnostic knobs (process-wide; the library itself reads NO environment variable): a named integer that makes the launches that
+ * follow take a particular kernel or launch shape -- e.g. "fast_wg_max_cells" = 0 sends the FAST cells of small batches through
+ * k_fast_wave, "no_split" = 1 keeps a synchronous call on one stream.  None changes a result; tests use them to run one input
+ * through every kernel, the profiling tools to look at a kernel alone.  The names are listed in csrc/orbx_knobs.h; the Python
+ * loader forwards ORBX_<NAME> environment variables here.  value == LLONG_MIN unsets a knob.  ORBX_E_BADARG: unknown name. */
+int orbx_debug_set(const char* key, long long value);
 /* Host only, no device needed: the quadtree path codes (root << 32 | 16 quadrant digits of ExtractorNode::DivideNode,
  * Features/ORBextractor.cpp:617-676, 747) of n points (xs[i], ys[i]) of a width x height candidate region, from the per-level
  * x / y tables the selection kernels look up and by walking the 16 splits per point; the two agree for every point. */

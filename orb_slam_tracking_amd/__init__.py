@@ -136,10 +136,43 @@ def lib() -> ctypes.CDLL:
     L.orbx_debug_distribute_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32]
     L.orbx_debug_std_sort.argtypes = [vp, vp, i32]
     L.orbx_debug_sincos.argtypes = [vp, vp, i32, vp, vp]
+    L.orbx_debug_set.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
     L.orbx_debug_last_launch.argtypes = [vp, vp]
     L.orbx_debug_path_codes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
     _LIB = L
+    # The library reads no environment variable; the profiling scripts' ORBX_<KNOB> settings are forwarded to orbx_debug_set here
+    # (diagnostic knobs, csrc/orbx_knobs.h: they choose among kernels / launch shapes with identical results).
+    for name in KNOBS:
+        v = os.environ.get("ORBX_" + name.upper())
+        if v is not None:
+            debug_set(name, _knob_value(name, v))
     return L
+
+
+KNOBS = ("no_bands", "no_tiles", "tiles_max_frames", "tiles_max_pixels", "pyr_bands", "bands_min_frames", "desc_no_staged",
+         "desc_staged_max", "no_split", "lat_trace", "no_direct_out", "fast_wg", "fast_wg_max_cells", "fast_lds_pad", "fast_debug",
+         "desc_lds_pad", "match_no_general", "oct_no_small", "oct_key64", "oct_split_min", "oct_no_big", "octb_no_512", "oct_inst",
+         "oct_lds_pad", "multi_force_rccl")
+KNOB_UNSET = -(1 << 63)
+
+
+def _knob_value(name: str, text: str) -> int:
+    if name == "oct_inst":  # "2048,2048,1024,512,..." -> one hex digit per level, lowest digit = level 0
+        v = 0
+        for l, t in enumerate(text.split(",")[:16]):
+            v |= {"512": 1, "1024": 2, "2048": 3}.get(t.strip(), 0) << (4 * l)
+        return v
+    try:
+        return int(text)
+    except ValueError:
+        return 1  # (a flag set to anything: on)
+
+
+def debug_set(name: str, value: Optional[int]) -> None:
+    """Diagnostic knob of the library (orbx_debug_set, include/orbx.h): `None` unsets it."""
+    r = lib().orbx_debug_set(name.encode(), KNOB_UNSET if value is None else int(value))
+    if r != 0:
+        raise OrbxError(r, "orbx_debug_set(%r)" % name)
 
 
 def _ptr(a) -> ctypes.c_void_p:

@@ -18,8 +18,16 @@
 #include <vector>
 
 #include "orbx_device.h"
+#include "orbx_knobs.h"
 
 namespace orbx {
+
+// the diagnostic knobs (orbx_knobs.h), all unset: every launch choice is the library's own
+std::atomic<long long> g_knob[KNOB_COUNT] = {
+#define ORBX_KNOB_INIT(e, n) {KNOB_UNSET},
+    ORBX_KNOB_LIST(ORBX_KNOB_INIT)
+#undef ORBX_KNOB_INIT
+};
 
 hipError_t launch_resize(hipStream_t st, int nFrames, const uint8_t* src, long long srcFrameStride, int sw, int sh, int sstride,
                          uint8_t* dst, long long dstFrameStride, int dw, int dh, int dstride, const ResizeTab* xtab,
@@ -1040,15 +1048,15 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   if (part == 0) {
   // whole pyramid in one launch (k_pyramid_bands) when every level meets the dword path's preconditions and the batch
   // is large enough to fill the device with (bands x frames) workgroups; otherwise one launch per level
-  static const bool noBands = getenv("ORBX_NO_BANDS") != nullptr;  // diagnostics
-  static const bool noTiles = getenv("ORBX_NO_TILES") != nullptr;  // diagnostics: small batches launch the levels one by one
+  const bool noBands = knobOn(KNOB_NO_BANDS);  // diagnostics (orbx_debug_set)
+  const bool noTiles = knobOn(KNOB_NO_TILES);  // diagnostics: small batches launch the levels one by one
   // k_pyramid_tiles up to this many frames per launch: measured at 640x480 (tools/batch_sweep.py), one frame 0.108 against 0.117 ms
   // per synchronous call and 22.1 k against 18.3 k frames/s on four lanes, 8 frames level, 16 frames 133 k against 147 k on lanes
   // (and up to eight VGA frames' worth of pixels: 8 frames of 3840x2160 take 0.81 ms in tiles, 0.41 ms level by level)
-  static const int tilesMax = getenv("ORBX_TILES_MAX_FRAMES") ? atoi(getenv("ORBX_TILES_MAX_FRAMES")) : 8;
-  static const long long tilesMaxPx = getenv("ORBX_TILES_MAX_PIXELS") ? std::min(atoll(getenv("ORBX_TILES_MAX_PIXELS")), kPyrTilesMaxPixels) : kPyrTilesMaxPixels;
-  static const int bandsEnv = getenv("ORBX_PYR_BANDS") ? atoi(getenv("ORBX_PYR_BANDS")) : 0;  // diagnostics
-  static const int bandsMin = getenv("ORBX_BANDS_MIN_FRAMES") ? atoi(getenv("ORBX_BANDS_MIN_FRAMES")) : 0;  // diagnostics
+  const int tilesMax = (int)knob(KNOB_TILES_MAX_FRAMES, 8);
+  const long long tilesMaxPx = std::min(knob(KNOB_TILES_MAX_PIXELS, kPyrTilesMaxPixels), kPyrTilesMaxPixels);
+  const int bandsEnv = (int)knob(KNOB_PYR_BANDS, 0);  // diagnostics
+  const int bandsMin = (int)knob(KNOB_BANDS_MIN_FRAMES, 0);  // diagnostics
   // from 32 frames per stream, or from 8 when the frames are large (16 frames 1080p: 0.43 -> 0.30 ms; 16 frames 640x480 are
   // better off with the per-level launches: 0.252 vs 0.263 ms per 32-frame call)
   const bool enough = bandsMin > 0 ? n >= bandsMin : (n >= 32 || (n >= 8 && (long long)n * g.L[0].w * g.L[0].h >= (16ll << 20)));
@@ -1117,8 +1125,8 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
                          ctx->candHintL, 0, &ctx->lastLaunch[3]));
     // small launches (the one-frame call): the descriptor kernel indexes the staging lists itself and does the bookkeeping
     // (DescStage) -- one kernel less on the call's critical path
-    static const bool noStaged = getenv("ORBX_DESC_NO_STAGED") != nullptr;  // diagnostics
-    static const int stagedMax = getenv("ORBX_DESC_STAGED_MAX") ? atoi(getenv("ORBX_DESC_STAGED_MAX")) : ORBX_DESC_STAGED_MAX_UNITS;  // (experiments)
+    const bool noStaged = knobOn(KNOB_DESC_NO_STAGED);  // diagnostics
+    const int stagedMax = (int)knob(KNOB_DESC_STAGED_MAX, ORBX_DESC_STAGED_MAX_UNITS);  // (experiments)
     staged = !noStaged && n * g.nlevels <= stagedMax;
     if (!staged)
       HIPCHK(launch_sel_compact(st, n, ctx->dSelStage, ctx->dNselLevel, oct, ctx->dSel, ctx->dNsel, a.dNuser, ctx->hNselDev, g.selCap,
@@ -1335,7 +1343,7 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
   // two half batches from 16 frames on -- or from 4 when the frames are large (4 x 4K): the selection of such frames is a handful
   // of long latency-bound units (one 1024-thread workgroup per frame and level) under which the other half's pyramid, FAST and
   // descriptors find the chip almost empty (8 frames 4K / 8000 features: 6.0 k -> 8 k frames/s)
-  static const bool noSplitEnv = getenv("ORBX_NO_SPLIT") != nullptr;
+  const bool noSplitEnv = knobOn(KNOB_NO_SPLIT);
   const bool enoughToSplit = B >= 16 || (B >= 4 && (long long)B * w * h >= (32ll << 20));
   const bool split = ctx->st2 != nullptr && enoughToSplit && !noSplitEnv && !ctx->noSplit;
   const int n0 = split ? ((B / 2) & ~1) : B;
@@ -1584,7 +1592,7 @@ int orbx_extract_batch(orbx_ctx* ctx, int n_frames, const uint8_t* imgs, int wid
   const int dstride = alignUp(width, 64);
   const size_t dfs = (size_t)dstride * height;
   const int cap = std::max(ctx->selCap, 1);
-  static const bool latTrace = getenv("ORBX_LAT_TRACE") != nullptr;
+  const bool latTrace = knobOn(KNOB_LAT_TRACE);
   static double latAcc[5] = {0, 0, 0, 0, 0};
   static long latN = 0;
   auto nowUs = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
@@ -1602,7 +1610,7 @@ int orbx_extract_batch(orbx_ctx* ctx, int n_frames, const uint8_t* imgs, int wid
                                 hipMemcpyHostToDevice, ctx->st));
     }
     if (latTrace) tt[1] = nowUs();
-    static const bool noDirect = getenv("ORBX_NO_DIRECT_OUT") != nullptr;  // diagnostics
+    const bool noDirect = knobOn(KNOB_NO_DIRECT_OUT);  // diagnostics
     const bool direct = B <= ctx->pinFrames && !noDirect;
     int r = extractCore(ctx, B, ctx->dIn, width, height, dstride, (long long)dfs, direct ? ctx->hKpsPinDev : ctx->dKps,
                         direct ? ctx->hDescPinDev : ctx->dDesc, cap, nullptr, nullptr);
@@ -2453,6 +2461,21 @@ int orbx_debug_path_codes(int width, int height, int n, const int32_t* xs, const
     from_walk[i] = code;
   }
   return ORBX_OK;
+}
+
+int orbx_debug_set(const char* key, long long value) {
+  static const char* const names[KNOB_COUNT] = {
+#define ORBX_KNOB_NAME(e, n) n,
+      ORBX_KNOB_LIST(ORBX_KNOB_NAME)
+#undef ORBX_KNOB_NAME
+  };
+  if (!key) return ORBX_E_BADARG;
+  for (int k = 0; k < KNOB_COUNT; k++)
+    if (std::strcmp(key, names[k]) == 0) {
+      g_knob[k].store(value, std::memory_order_relaxed);
+      return ORBX_OK;
+    }
+  return ORBX_E_BADARG;
 }
 
 int orbx_debug_last_launch(const orbx_ctx* ctx, int32_t* info8) {

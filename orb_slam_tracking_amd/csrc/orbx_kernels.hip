@@ -27,6 +27,7 @@
 
 #include "../../include/orbx.h"
 #include "orbx_device.h"
+#include "orbx_knobs.h"
 
 namespace orbx {
 
@@ -3061,12 +3062,11 @@ hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long lo
     cw = std::max(cw, std::min(g.L[l].wCell + 6, ORBX_CELL_MAX));
     ch = std::max(ch, std::min(g.L[l].hCell + 6, ORBX_CELL_MAX));
   }
-  static const bool forceOld = getenv("ORBX_FAST_WG") != nullptr;  // diagnostics: the workgroup-per-cell kernel
+  const bool forceOld = knobOn(KNOB_FAST_WG);  // diagnostics (orbx_debug_set): the workgroup-per-cell kernel
   // a lone wave needs 17 us for its cell; the four waves of k_fast's workgroup 8.8 us: the latter for the one-frame call, whose
   // cells cannot fill the chip either way (measured up to eight 640x480 frames = 4616 cells per launch: tools/exp_fast_small.sh)
-  // (read per launch, not once: the parity tests run their small batches through both kernels)
-  const char* wgEnv = getenv("ORBX_FAST_WG_MAX_CELLS");
-  const int wgMaxCells = wgEnv ? atoi(wgEnv) : 5000;
+  // (the parity tests run their small batches through both kernels: knob fast_wg_max_cells = 0)
+  const int wgMaxCells = (int)knob(KNOB_FAST_WG_MAX_CELLS, 5000);
   const bool small = (long long)nFrames * g.nCellsTotal <= wgMaxCells;
   if (usedWave) *usedWave = (waveOk && img0Aligned && cells && !forceOld && !small) ? 1 : 0;
   if (waveOk && img0Aligned && cells && !forceOld && !small) {
@@ -3075,9 +3075,9 @@ hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long lo
     const int ts = waveOk == 2 ? 48 : 64;  // tile / strength-map row stride: 48 when every cell image is <= 12 dwords wide
     // (+ 16: the quick reject's dword reads reach a few bytes beyond the last tile row)
     const int tileBytes = ch * ts + 16, smapBytes = (ch - 6 + 2) * ts;
-    static const int fastPad = getenv("ORBX_FAST_LDS_PAD") ? atoi(getenv("ORBX_FAST_LDS_PAD")) : 0;  // diagnostics: fewer waves per CU
+    const int fastPad = (int)knob(KNOB_FAST_LDS_PAD, 0);  // diagnostics: fewer waves per CU
     const size_t lds = (size_t)(tileBytes + smapBytes + (FW_RING + 64) * 2 + (FW_CORN + 64) * 2) + fastPad;
-    static const bool dbg = getenv("ORBX_FAST_DEBUG") != nullptr;
+    const bool dbg = knobOn(KNOB_FAST_DEBUG);
     if (dbg) {
       int nb48 = -1, nb64 = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb48, k_fast_wave<48>, 64, lds);
@@ -3111,7 +3111,7 @@ hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const 
   // launched no k_sel_compact; see DescStage)
   if (maxSel <= 0 && !staged) return hipSuccess;
   dim3 block(64 * DESC_WAVES, 1, 1), grid(((maxSel + DESC_WAVES - 1) / DESC_WAVES + 7) / 8 * 8, nFrames, 1);  // x: multiple of 8
-  static const int descPad = getenv("ORBX_DESC_LDS_PAD") ? atoi(getenv("ORBX_DESC_LDS_PAD")) : 0;  // diagnostics: fewer waves per CU
+  const int descPad = (int)knob(KNOB_DESC_LDS_PAD, 0);  // diagnostics: fewer waves per CU
   const DescStage none = {};
   if (staged) {
     if (gaussVariant)
@@ -3137,7 +3137,7 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
   if (nPairs <= 0) return hipSuccess;
   MatchParams mp;
   mp.capacity = capacity; mp.window = window; mp.nnratio = nnratio; mp.checkOri = checkOri; mp.b = b;
-  mp.noGeneral = getenv("ORBX_MATCH_NO_GENERAL") ? 1 : 0;  // tests: see which pairs the parallel paths complete
+  mp.noGeneral = knobOn(KNOB_MATCH_NO_GENERAL) ? 1 : 0;  // tests: see which pairs the parallel paths complete
   mp.pair0 = pair0;
   // With bestDist <= TH_LOW required, a train at distance s can matter as best only if s <= TH_LOW and as second-best
   // only if nnratio * s < TH_LOW (ORBmatcher.cpp:84-87: accepted iff bestDist <= nnratio * bestDist2 in f32, and f32

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/orbx.h"
+#include "orbx_knobs.h"
 
 namespace {
 
@@ -275,8 +276,7 @@ int orbx_multi_create(const orbx_params* params, int n_devices, const int* devic
     return ORBX_E_HIP;
   }
   {
-    const char* force = getenv("ORBX_MULTI_FORCE_RCCL");
-    m->useRccl = n_devices > 1 || (force && force[0] && force[0] != '0');
+    m->useRccl = n_devices > 1 || orbx::knobOn(orbx::KNOB_MULTI_FORCE_RCCL);  // (orbx_debug_set "multi_force_rccl": tests)
   }
   if (m->useRccl) {
     std::string e;

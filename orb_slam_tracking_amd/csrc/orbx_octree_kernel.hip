@@ -25,6 +25,7 @@
 
 #include "../../include/orbx.h"
 #include "orbx_device.h"
+#include "orbx_knobs.h"
 
 namespace orbx {
 
@@ -703,21 +704,21 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
   // workgroup handles the rare outlier and no second kernel is launched.
   // force: 0 = choose per level from hintL (nullptr = unknown); 2048 / 1024 / 512 = that LDS instance for every level (test
   // hook, diagnostics); -1 = every unit on global scratch (test hook).
-  static const bool noSmall = getenv("ORBX_OCT_NO_SMALL") != nullptr;  // diagnostics: always the 2048-candidate instance
-  static const bool key64Env = getenv("ORBX_OCT_KEY64") != nullptr;    // diagnostics: always 64-bit sort keys
+  const bool noSmall = knobOn(KNOB_OCT_NO_SMALL);  // diagnostics (orbx_debug_set): always the 2048-candidate instance
+  const bool key64Env = knobOn(KNOB_OCT_KEY64);    // diagnostics: always 64-bit sort keys
   const bool key64 = key64Env || (force & 0x10000) != 0;               // (test hook: force | 0x10000)
   force = force < 0 ? force : (force & 0xffff);
-  // ORBX_OCT_SPLIT_MIN (diagnostics) = batch size from which every group of consecutive levels with the same instance gets its
+  // knob oct_split_min (diagnostics) = batch size from which every group of consecutive levels with the same instance gets its
   // own launch.  Off by default: measured on the bench workload (256 frames, four lanes) 2048 | 1024 x 2 | 512 x 5 gives 295.9 k
   // frames/s, 2048 x 3 | 512 x 5 300.2 k, 2048 | 1024 x 7 302.3 k against 306.6 k with ONE launch on the largest instance --
   // consecutive launches of a stream do not overlap (hipExtAnyOrderLaunch is ignored on gfx9: tools/microbench/any_order.hip),
   // so every group adds its own tail, and that costs more than the smaller units' LDS gives back to the other lanes.
-  static const int splitMin = getenv("ORBX_OCT_SPLIT_MIN") ? atoi(getenv("ORBX_OCT_SPLIT_MIN")) : (1 << 30);
+  const int splitMin = (int)knob(KNOB_OCT_SPLIT_MIN, 1 << 30);
   if (usedInstance) *usedInstance = 0;
   // Large units (levels that expect them): k_octree_buckets sorts every unit's keys bucket by bucket on many workgroups,
   // k_octree_big does the tree arithmetic with one workgroup per unit (and redoes a unit it cannot take with the one-workgroup
-  // code of k_octree_global, the round-1..3 path), k_octree_emit picks the keypoints.  ORBX_OCT_NO_BIG (diagnostics): the old path.
-  static const bool noBig = getenv("ORBX_OCT_NO_BIG") != nullptr;
+  // code of k_octree_global, the round-1..3 path), k_octree_emit picks the keypoints.  knob oct_no_big (diagnostics): the old path.
+  const bool noBig = knobOn(KNOB_OCT_NO_BIG);
   OctLaunch Q = P;  // the launch's bucket depths: from the candidate counts of the previous batch (octBigChoose)
   // (hintL: ORBX_OCT_FEEDBACK values -- the previous batch's largest candidate count and fullest bucket per level)
   auto hintOf = [&](int l) { return hintL ? ORBX_OCT_FB_COUNT(hintL[l]) : 0; };
@@ -741,7 +742,7 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
           known = known && fl > 0;
           fillMost = std::max(fillMost, fl);
         }
-      static const bool noSmallSlots = getenv("ORBX_OCTB_NO_512") != nullptr;  // diagnostics
+      const bool noSmallSlots = knobOn(KNOB_OCTB_NO_512);  // diagnostics
       const dim3 bgrid((unsigned)(8 * ((most + OCTB_WAVES - 1) / OCTB_WAVES)), 1, 1);
       if (known && !noSmallSlots && fillMost * 4 <= 512 * 3)
         hipLaunchKernelGGL(k_octree_buckets<512>, bgrid, dim3(OCTB_T), 0, st, cand, cellCount, Q, scratch, l0, l1, nFrames);
@@ -778,14 +779,12 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
   // candidates -> 30 KB units; sparse scenes with small quotas -> 17 KB units).
   if (nFrames < splitMin && force == 0)
     for (int l = 0; l < P.nlevels; l++) inst[l] = anyBig ? 0 : largest;
-  static const char* instEnv = getenv("ORBX_OCT_INST");  // diagnostics: "2048,2048,1024,512,..." = the instance of every level
-  if (instEnv && force == 0 && !anyBig && hintL && hintOf(0) > 0) {
-    const char* q = instEnv;
-    for (int l = 0; l < P.nlevels && *q; l++) {
-      const int v = atoi(q);
-      if (v == 512 || v == 1024 || v == 2048) inst[l] = std::max(inst[l] == largest ? octInstanceFor(P.lev[l].quota, hintOf(l)) : inst[l], v);
-      while (*q && *q != ',') q++;
-      if (*q == ',') q++;
+  const long long instKnob = knob(KNOB_OCT_INST, 0);  // diagnostics: one hex digit per level, 1 = 512, 2 = 1024, 3 = 2048
+  if (instKnob && force == 0 && !anyBig && hintL && hintOf(0) > 0) {
+    for (int l = 0; l < P.nlevels && l < 16; l++) {
+      const int dgt = (int)((instKnob >> (4 * l)) & 15);
+      const int v = dgt == 1 ? 512 : dgt == 2 ? 1024 : dgt == 3 ? 2048 : 0;
+      if (v) inst[l] = std::max(inst[l] == largest ? octInstanceFor(P.lev[l].quota, hintOf(l)) : inst[l], v);
     }
   }
   if (usedInstance) {  // the smallest instance any level runs on (0: some level goes to k_octree_global)
@@ -804,7 +803,7 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
       const int rootBits = P.lev[l].nIni > 1 ? 32 - __builtin_clz((unsigned)(P.lev[l].nIni - 1)) : 0;
       k32 = k32 && P.lev[l].depthBits >= 1 && rootBits + 2 * P.lev[l].depthBits <= 21;
     }
-    static const int ldsPad = getenv("ORBX_OCT_LDS_PAD") ? atoi(getenv("ORBX_OCT_LDS_PAD")) : 0;  // diagnostics: fewer units per CU
+    const int ldsPad = (int)knob(KNOB_OCT_LDS_PAD, 0);  // diagnostics: fewer units per CU
 #define ORBX_OCT_LAUNCH(N_, Q_, DEFER_)                                                                                             \
   do {                                                                                                                              \
     if (k32)                                                                                                                        \

@@ -33,6 +33,7 @@ int main(int argc, char** argv) {
   std::vector<uint8_t> a = readRaw(argv[3], (size_t)W * H), b = readRaw(argv[4], (size_t)W * H);
   using namespace ORB_SLAM_Tracking;
   orbx::verbose() = false;
+  if (std::getenv("ORBX_LAT_TRACE")) orbx_debug_set("lat_trace", 1);  // (tools/cpp_latency.sh: the library itself reads no environment)
   try {
     ORBextractor extractor(std::atoi(argv[5]), 1.2f, 8, std::atoi(argv[6]), std::atoi(argv[7]), W, H);
     std::vector<int> unused{0, 0};

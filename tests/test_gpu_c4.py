@@ -298,18 +298,21 @@ def test_multi_c_abi_async_one_device(orbx, c4_oracle, depth):
 
 
 def test_multi_c_abi_forced_rccl_one_device(orbx, c4_oracle, monkeypatch):
-    """ORBX_MULTI_FORCE_RCCL=1: a ONE-device orbx_multi context goes through RCCL -- dlopen(librccl.so), ncclCommInitAll(1), a
+    """Diagnostic knob multi_force_rccl = 1 (orbx_debug_set): a ONE-device orbx_multi context goes through RCCL -- dlopen(librccl.so), ncclCommInitAll(1), a
     grouped ncclAllGather of the counts on the collective stream per batch, ncclCommDestroy -- so these code paths run on a
     one-GPU box too (they used to see their first execution on the driver's 8-GPU node).  The synchronous form and the
     stream-ordered form (three lanes, batches in flight) must both give the oracle's counts, blocks and pairs."""
     import torch
     torch.cuda.init()
-    monkeypatch.setenv("ORBX_MULTI_FORCE_RCCL", "1")
     monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    _multi_run(orbx, [0], 64, c4_oracle)
-    assert "librccl" in open("/proc/self/maps").read(), "RCCL was not loaded: the forced path did not run"
-    _multi_async_run(orbx, [0], c4_oracle, 3, nbatch=4, n_frames=64)
-    _multi_async_run(orbx, [0], c4_oracle, 0, nbatch=3, n_frames=64)
+    orbx.debug_set("multi_force_rccl", 1)
+    try:
+        _multi_run(orbx, [0], 64, c4_oracle)
+        assert "librccl" in open("/proc/self/maps").read(), "RCCL was not loaded: the forced path did not run"
+        _multi_async_run(orbx, [0], c4_oracle, 3, nbatch=4, n_frames=64)
+        _multi_async_run(orbx, [0], c4_oracle, 0, nbatch=3, n_frames=64)
+    finally:
+        orbx.debug_set("multi_force_rccl", None)
 
 
 def test_bench_force_collective_one_rank(orbx):

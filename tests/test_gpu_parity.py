@@ -11,13 +11,13 @@ SHIPPED = (2000, 1.2, 8, 0, 0)
 
 
 @pytest.fixture(autouse=True, params=["fast_default", "fast_wave_per_cell"])
-def fast_kernel_choice(request, monkeypatch):
-    """Launches of up to 5000 FAST cells (eight 640x480 frames) take k_fast, a workgroup per cell; ORBX_FAST_WG_MAX_CELLS=0 (read per
-    launch) sends them through k_fast_wave, one wave per cell, like the large batches.  Every test of this module runs both ways."""
-    if request.param == "fast_wave_per_cell":
-        monkeypatch.setenv("ORBX_FAST_WG_MAX_CELLS", "0")
-    else:
-        monkeypatch.delenv("ORBX_FAST_WG_MAX_CELLS", raising=False)
+def fast_kernel_choice(request, orbx):
+    """Launches of up to 5000 FAST cells (eight 640x480 frames) take k_fast, a workgroup per cell; the diagnostic knob
+    fast_wg_max_cells = 0 (orbx_debug_set) sends them through k_fast_wave, one wave per cell, like the large batches.  Every test of
+    this module runs both ways."""
+    orbx.debug_set("fast_wg_max_cells", 0 if request.param == "fast_wave_per_cell" else None)
+    yield
+    orbx.debug_set("fast_wg_max_cells", None)
 
 
 @pytest.fixture(scope="module")
@@ -228,7 +228,7 @@ def _clustered_desc_pair(orbx, rng, n, protos, flips, w, h, level0_share, jitter
     return k1, d1, k2, d2
 
 
-def test_wide_matcher_contention(orbx, ext640, oracle, monkeypatch):
+def test_wide_matcher_contention(orbx, ext640, oracle):
     """Pairs beyond the LDS instances (more than 512 octave-0 queries / eligible trains): descriptors drawn from few
     prototypes, so trains are claimed by several queries, stolen and blocked, and the fixpoint needs several sweeps.
     Every case must equal the oracle whichever kernel ends up taking it; the first cases must be taken by the wide path
@@ -261,9 +261,11 @@ def test_wide_matcher_contention(orbx, ext640, oracle, monkeypatch):
         assert nm == onm and np.array_equal(m12, om12) and list(m.last_stats) == ost.tolist(), (n, npro, win)
         if must:
             assert onm > 50
-            monkeypatch.setenv("ORBX_MATCH_NO_GENERAL", "1")
-            nm2, m12b = m.SearchForInitialization(fa, fb, win)
-            monkeypatch.delenv("ORBX_MATCH_NO_GENERAL")
+            orbx.debug_set("match_no_general", 1)
+            try:
+                nm2, m12b = m.SearchForInitialization(fa, fb, win)
+            finally:
+                orbx.debug_set("match_no_general", None)
             assert nm2 == onm and np.array_equal(m12b, om12), "the wide path handed the pair on: %r" % ((n, npro, win),)
 
 
@@ -941,16 +943,14 @@ def test_to_gray_and_colour_chain(orbx, ext640, oracle):
 
 
 @pytest.mark.parametrize("nosplit", [False, True])
-def test_banded_pyramid_large_batch(orbx, oracle, nosplit, monkeypatch):
+def test_banded_pyramid_large_batch(orbx, oracle, nosplit, request):
     """Batches of >= 32 frames per stream build the pyramid with k_pyramid_bands (one launch, row bands with halos; three
     bands per 640x480 frame from 86 frames per stream, more and thinner ones below: ceil(256 / frames)): pyramid levels and extraction results equal the oracle, for an
     even-sized and an odd-height frame size."""
     import torch
     from orb_slam_tracking_amd import synth
-    if nosplit:
-        monkeypatch.setenv("ORBX_NO_SPLIT", "1")
-    else:
-        monkeypatch.delenv("ORBX_NO_SPLIT", raising=False)
+    orbx.debug_set("no_split", 1 if nosplit else None)
+    request.addfinalizer(lambda: orbx.debug_set("no_split", None))
     cap = 1000
     for (w, h, B) in ((640, 480, 72), (324, 243, 66), (322, 243, 40)):  # the last: rows not 4-byte aligned (unaligned 8-byte taps)
         frames = synth.synth_frames(B, w, h, 5200)
@@ -1130,6 +1130,62 @@ def test_sincos_matches_libm(orbx, ext640, oracle):
     ec, es = oracle.sincos_deg_batch(a)
     bad = np.nonzero((c != ec) | (s != es))[0]
     assert len(bad) == 0, (len(bad), a[bad[:5]], c[bad[:5]], ec[bad[:5]], s[bad[:5]], es[bad[:5]])
+
+
+def test_libm_float_variant(orbx, oracle):
+    """orbx_set_libm_variant(ORBX_LIBM_FLOAT): cos / sin of cpp:174 read as glibc's cosf / sinf (restated on the device) and the
+    constructor's pow as powf (cpp:536), against the oracle with the same reading: the (cos, sin) pairs for all multiples of
+    1/128 degree, 3 million random angles and the known angles at which the two readings put a sample point on different pixels
+    (bitwise; tools/sincos_exhaustive.py 1 sweeps every f32 angle); whole extractions; a scale factor whose quotas the reading
+    changes (the context re-plans its buffers)."""
+    from orb_slam_tracking_amd import synth
+    rng = np.random.default_rng(3)
+    moved = np.array([0x40506FD5, 0x4062B34D, 0x40E8408C, 0x40E8408D, 0x40F35541, 0x40F35542, 0x410B3FE6, 0x4126BE39, 0x4152F830,
+                      0x416EF42B, 0x416EF42C, 0x41790BB9], np.uint32).view(np.float32)
+    a = np.concatenate([np.arange(0, 360 * 128 + 1, dtype=np.float32) / np.float32(128), moved,
+                        np.float32(2.0) ** np.arange(-30, 0, dtype=np.float32),  # tiny angles: sinf returns its argument below 2^-12
+                        rng.uniform(0, 360, 3_000_000).astype(np.float32), rng.uniform(0, 50, 500_000).astype(np.float32)])
+    exotic = float(np.uint32(0x3F817EE4).view(np.float32))  # tests/test_oracle.py EXOTIC_SCALE
+    frames = [synth.synth(640, 480, 31), synth.synth(640, 480, 32)]
+    e = orbx.ORBextractor(*CANON, max_width=640, max_height=480, max_batch=2)
+    e2 = orbx.ORBextractor(500, exotic, 9, 20, 7, max_width=320, max_height=240, max_batch=2)
+    try:
+        c0, s0 = e.debug_sincos(a)
+        oracle.set_libm_variant(1)
+        e.set_libm_variant(1)
+        c, s = e.debug_sincos(a)
+        ec, es = oracle.sincos_deg_batch(a)
+        bad = np.nonzero((c.view(np.uint32) != ec.view(np.uint32)) | (s.view(np.uint32) != es.view(np.uint32)))[0]
+        assert len(bad) == 0, (len(bad), a[bad[:5]], c[bad[:5]], ec[bad[:5]], s[bad[:5]], es[bad[:5]])
+        assert ((c != c0) | (s != s0)).sum() > 1000  # (the readings differ for ~0.13 % of the angles)
+        oe = oracle.Extractor(*CANON)
+        for fr in frames:
+            r, k, d = e(fr)
+            orr, ok, od = oe(fr)
+            assert r == orr
+            _same(k, d, ok, od)
+        q0 = np.array(e2.GetNumFeaturesPerLevel())
+        e2.set_libm_variant(1)
+        oe2 = oracle.Extractor(500, exotic, 9, 20, 7)
+        q1 = np.array(e2.GetNumFeaturesPerLevel())
+        assert np.array_equal(q1, oe2.tables()["quota"]) and not np.array_equal(q0, q1)
+        fr = synth.synth(320, 240, 33)
+        r, k, d = e2(fr)
+        orr, ok, od = oe2(fr)
+        assert r == orr
+        _same(k, d, ok, od)
+        oracle.set_libm_variant(0)
+        e2.set_libm_variant(0)
+        assert np.array_equal(np.array(e2.GetNumFeaturesPerLevel()), q0)
+        r, k, d = e2(fr)
+        orr, ok, od = oracle.Extractor(500, exotic, 9, 20, 7)(fr)
+        _same(k, d, ok, od)
+        with pytest.raises(Exception):
+            e.set_libm_variant(2)
+    finally:
+        oracle.set_libm_variant(0)
+        e.close()
+        e2.close()
 
 
 def test_check_rt(orbx, ext640, oracle):

@@ -29,6 +29,24 @@ def test_abi_exports_every_declared_symbol(orbx):
         assert hasattr(L, n), "liborbx.so does not export %s" % n
 
 
+def test_library_reads_no_environment(orbx):
+    """The shipped library holds no getenv and no ORBX_* variable name: kernel choices are the library's own, and what the tests
+    and tools want to steer goes through orbx_debug_set's named knobs (csrc/orbx_knobs.h), which the Python loader mirrors."""
+    src = os.path.join(ROOT, "orb_slam_tracking_amd", "csrc")
+    for fn in os.listdir(src):
+        if fn.endswith((".cpp", ".hip", ".inc", ".h")):
+            assert "getenv" not in open(os.path.join(src, fn), errors="replace").read(), fn
+    blob = open(orbx.lib_path(), "rb").read()
+    assert not re.findall(rb"\x00ORBX_[A-Z0-9_]+\x00", blob)
+    names = re.findall(r'X\(KNOB_[A-Z0-9_]+, "([a-z0-9_]+)"\)', open(os.path.join(src, "orbx_knobs.h")).read())
+    assert tuple(names) == orbx.KNOBS and len(names) >= 20
+    L = ctypes.CDLL(orbx.lib_path())
+    L.orbx_debug_set.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
+    for n in names:
+        assert L.orbx_debug_set(n.encode(), orbx.KNOB_UNSET) == 0, n
+    assert L.orbx_debug_set(b"no_such_knob", 1) == orbx.E_BADARG and L.orbx_debug_set(None, 1) == orbx.E_BADARG
+
+
 def test_no_cpu_fallback(orbx):
     """Without a usable HIP device the product must refuse to compute (no CPU path exists)."""
     if _has_gpu():

@@ -509,3 +509,42 @@ def test_opencv_variants(oracle):
         assert k0.tobytes() == k1.tobytes() and not np.array_equal(d0, d1)
     finally:
         oracle.set_opencv_variant(0, 0)
+
+
+# one of the 45 (scale factor, nlevels <= 16, nfeatures in {500 .. 8000}) with a scale factor in [1.01, 2] for which powf and
+# (float)pow(double) give different per-level quotas (cpp:536): 1.01168489, nine levels, 500 features
+EXOTIC_SCALE = float(np.uint32(0x3F817EE4).view(np.float32))
+
+
+def test_libm_variants(oracle):
+    """The libm reading of the reference's unqualified cos / sin / pow on floats (cpp:174, cpp:536; orbo_set_libm_variant /
+    orbx_set_libm_variant).  ORBX_LIBM_FLOAT = glibc >= 2.28's sinf / cosf, restated in the oracle: EVERY f32 angle of [0, 360]
+    (1,135,869,953 of them) against this host's own cosf / sinf -- 0 differing, in the FMA form and in the form without; the two
+    readings themselves differ (483,807 cosines / 1,001,902 sines with glibc 2.35), and at 96 angles a rotated sample point
+    lands on another pixel: one of them is pinned here through the descriptor."""
+    hi = int(np.float32(360.0).view(np.uint32))
+    out = oracle.libm_sweep(0, hi, max(1, min(os.cpu_count() or 1, 16)))
+    assert out[:4] == [0, 0, 0, 0], out
+    assert out[4] > 0 and out[5] > 0, out  # (the readings are different functions)
+    rng = np.random.default_rng(5)
+    blurred = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    moved = float(np.uint32(0x40E8408C).view(np.float32))   # 7.25787926 degrees: six of the 512 points move
+    same = 7.25
+    try:
+        d = {}
+        for v in (0, 1):
+            oracle.set_libm_variant(v)
+            d[v] = (oracle.descriptor(blurred, 32.0, 32.0, moved), oracle.descriptor(blurred, 32.0, 32.0, same))
+            c, s = oracle.sincos_deg_batch(np.array([moved], np.float32))
+            d[v] += (c[0], s[0])
+        assert not np.array_equal(d[0][0], d[1][0]) and np.array_equal(d[0][1], d[1][1])
+        assert (d[0][2], d[0][3]) != (d[1][2], d[1][3])
+        # the constructor's pow: equal quotas for the usual parameters, different ones for an exotic scale factor
+        q = {}
+        for v in (0, 1):
+            oracle.set_libm_variant(v)
+            q[v] = (oracle.Extractor(1000, 1.2, 8, 20, 7).tables()["quota"], oracle.Extractor(500, EXOTIC_SCALE, 9, 20, 7).tables()["quota"])
+        assert np.array_equal(q[0][0], q[1][0]) and q[0][0].sum() == 1000
+        assert not np.array_equal(q[0][1], q[1][1]) and q[0][1].sum() == q[1][1].sum() == 500
+    finally:
+        oracle.set_libm_variant(0)

@@ -181,11 +181,8 @@ for t in range(trials):
     if kind == "pairs_noise" and mode == "big":
         w, h = w // 2, h // 2
     params = (nf, sf, nlev, ini, mn)
-    # small launches take k_fast (a workgroup per cell), large ones k_fast_wave; every other trial forces the latter (read per launch)
-    if t & 1:
-        os.environ["ORBX_FAST_WG_MAX_CELLS"] = "0"
-    else:
-        os.environ.pop("ORBX_FAST_WG_MAX_CELLS", None)
+    # small launches take k_fast (a workgroup per cell), large ones k_fast_wave; every other trial forces the latter (diagnostic knob)
+    orbx.debug_set("fast_wg_max_cells", 0 if t & 1 else None)
     tag = "trial %d: %dx%d B=%d %s params=%r%s" % (t, w, h, B, kind, params, " wave-per-cell" if t & 1 else "")
     try:
         e = orbx.ORBextractor(*params, max_width=w, max_height=h, max_batch=B)

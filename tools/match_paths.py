@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostics: how many pairs of a batch the parallel matcher kernels complete themselves (ORBX_MATCH_NO_GENERAL leaves
+"""Diagnostics: how many pairs of a batch the parallel matcher kernels complete themselves (the diagnostic knob match_no_general leaves
 the pairs they hand on to the general kernel at INT_MIN), per configuration of tools/configs_rate.py."""
 import json
 import os
@@ -24,12 +24,13 @@ for name, w, h, nf, ini, mn, B in CASES:
     first = np.arange(0, B, 2, dtype=np.int32)
     ext = orbx.ORBextractor(nf, 1.2, 8, ini, mn, max_width=w, max_height=h, max_batch=B)
     out = {"case": name, "pairs": B // 2}
-    for label, env in (("all kernels", {}), ("without the sequential loop", {"ORBX_MATCH_NO_GENERAL": "1"})):
-        os.environ.update(env)
+    for label, env in (("all kernels", {}), ("without the sequential loop", {"match_no_general": 1})):
+        for k, v in env.items():
+            orbx.debug_set(k, v)
         ext.extract_match_batch_device(d_img, B, w, h, w, w * h, d_k, d_d, d_n, first, first + 1, (0, w, 0, h), d_m, d_nm, None,
                                        100, 0.9, True, nf)
         for k in env:
-            del os.environ[k]
+            orbx.debug_set(k, None)
         nm = d_nm.cpu().numpy()
         out[label] = {"completed": int((nm != -2**31).sum()), "nmatches_sum": int(nm[nm != -2**31].sum())}
     kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, nf)

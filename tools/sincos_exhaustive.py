@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """EVERY f32 keypoint angle in [0, 360]: the (cos, sin) pair k_describe_patch computes (orbx_debug_sincos: f64 evaluation rounded to
 f32) against the oracle's (float)cos((double)(angle * factorPI)) / (float)sin(...) (Features/ORBextractor.cpp:172-174 with glibc's
-libm).  1,135,869,953 angles in chunks of 2^24; prints the number of differing values (must be 0).  Run on the GPU box."""
+libm).  1,135,869,953 angles in chunks of 2^24; prints the number of differing values (must be 0).  Run on the GPU box.
+usage: sincos_exhaustive.py [libm variant: 0 = through double (default), 1 = glibc cosf / sinf] [number of angles]"""
 import os
 import sys
 import time
@@ -16,8 +17,11 @@ import oracle_lib as O  # noqa: E402
 
 top = int(np.float32(360.0).view(np.uint32))  # bit pattern of 360.0f: every non-negative float up to it
 chunk = 1 << 24
-lim = int(sys.argv[1]) if len(sys.argv) > 1 else top + 1
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+lim = int(sys.argv[2]) if len(sys.argv) > 2 else top + 1
 e = orbx.ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=1)
+e.set_libm_variant(variant)
+O.set_libm_variant(variant)
 from concurrent.futures import ThreadPoolExecutor  # noqa: E402
 ex = ThreadPoolExecutor(16)
 bad = 0
@@ -35,5 +39,5 @@ for lo in range(0, lim, chunk):
         print("chunk %#x: %d differ, first angle %r: device (%r, %r) oracle (%r, %r)" % (lo, len(i), ang[i[0]], c[i[0]], s[i[0]], co[i[0]], so[i[0]]), flush=True)
     if (lo // chunk) % 8 == 0:
         print("... %#010x of %#010x, %d differing so far, %.0f s" % (lo, lim, bad, time.time() - t0), flush=True)
-print("EXHAUSTIVE SINCOS: %d angles, %d differing values, %.0f s" % (lim, bad, time.time() - t0))
+print("EXHAUSTIVE SINCOS (libm variant %d): %d angles, %d differing values, %.0f s" % (variant, lim, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
