@@ -204,6 +204,25 @@ int orbx_extract_match_batch_device_async(orbx_ctx* ctx, int n_frames, const uin
                                           float nnratio, int check_orientation, int32_t* d_matches12,
                                           int32_t* d_nmatches, int32_t* d_stats);
 
+/* The same stream-ordered call for frames and results in HOST memory -- what the reference's call site hands over (a host
+ * cv::Mat per frame, SlamTypes/Frame.cpp:58-60), batched: per batch the frames are uploaded, the kernels run and every result array
+ * is copied back, all stream-ordered on the lane the batch goes to, so that with orbx_set_pipeline_depth(N >= 2) the upload of one
+ * batch runs under the kernels of the batches in front of it and the call is bound by the slower of the PCIe link and the
+ * kernels (640x480: the link; bench.py reports the rate beside the H2D rate of the box as `host_pipeline`).  h_imgs and the
+ * result arrays should be page-locked (hipHostMalloc, orbx_host_register): from pageable memory the runtime stages every copy
+ * synchronously and the call degenerates to orbx_extract_batch's rate.  All arrays are host pointers with the layout of the
+ * device call (h_kps [n_frames][capacity], h_desc32 [n_frames][capacity][32], h_n_out [n_frames], h_matches12 [n_pairs][capacity],
+ * h_nmatches [n_pairs], h_stats nullable [n_pairs][3]); entries beyond a frame's count are unspecified.  Valid once an
+ * orbx_wait_one / orbx_wait has covered the batch; inputs and outputs must stay untouched until then.  With pipeline depth 0 one
+ * batch is in flight at a time (the call first waits for the previous one).  From its first use on, every batch of the context
+ * carries all of its matcher kernels (as after orbx_order_before): the copies back run behind the kernels, not behind a wait. */
+int orbx_extract_match_batch_host_async(orbx_ctx* ctx, int n_frames, const uint8_t* h_imgs, int width, int height,
+                                        int stride, size_t frame_stride_bytes, orbx_keypoint* h_kps, uint8_t* h_desc32,
+                                        int capacity, int32_t* h_n_out, int n_pairs, const int32_t* h_first,
+                                        const int32_t* h_second, const orbx_bounds* bounds, int window_size,
+                                        float nnratio, int check_orientation, int32_t* h_matches12,
+                                        int32_t* h_nmatches, int32_t* h_stats);
+
 /* Pipeline depth of the stream-ordered call (default 0).  depth 0: a batch is cut into two halves that run on the context's two
  * streams, at most two batches in flight.  depth >= 1: the context keeps `depth` lanes (each with its own stream and its own
  * copy of the internal buffers, sized like the context) and every stream-ordered batch goes, whole, to the next lane; at most

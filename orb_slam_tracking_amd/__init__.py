@@ -98,6 +98,7 @@ def lib() -> ctypes.CDLL:
                                                   ctypes.POINTER(_Bounds), i32, f32, i32, vp, vp, vp]
     L.orbx_extract_match_batch_device_async.argtypes = [vp, i32, vp, i32, i32, i32, sz, vp, vp, i32, vp, i32, vp, vp,
                                                   ctypes.POINTER(_Bounds), i32, f32, i32, vp, vp, vp]
+    L.orbx_extract_match_batch_host_async.argtypes = L.orbx_extract_match_batch_device_async.argtypes
     L.orbx_set_opencv_variant.argtypes = [vp, i32, i32]
     L.orbx_set_libm_variant.argtypes = [vp, i32]
     L.orbx_set_pipeline_depth.argtypes = [vp, i32]
@@ -390,6 +391,24 @@ class ORBextractor:
                                                           _ptr(second), ctypes.byref(b), int(windowSize), float(nnratio),
                                                           int(bool(checkOri)), _ptr(d_matches12), _ptr(d_nmatches), _ptr(d_stats))
         self._check(r, "orbx_extract_match_batch_device_async")
+
+    def extract_match_batch_host_async(self, h_imgs, n_frames: int, width: int, height: int, stride: int, frame_stride: int,
+                                       h_kps, h_desc, h_n, first: np.ndarray, second: np.ndarray,
+                                       bounds: Tuple[int, int, int, int], h_matches12, h_nmatches, h_stats=None,
+                                       windowSize: int = 100, nnratio: float = 0.9, checkOri: bool = True,
+                                       capacity: Optional[int] = None) -> None:
+        """Stream-ordered call for HOST frames and HOST result arrays (numpy arrays or pinned torch CPU tensors; page-locked memory
+        keeps the copies asynchronous): upload, kernels and the copies back are queued on the lane the batch goes to.  Valid after
+        ``wait_one`` / ``wait``; everything must stay untouched until then."""
+        first = np.ascontiguousarray(first, np.int32)
+        second = np.ascontiguousarray(second, np.int32)
+        b = _Bounds(*[int(v) for v in bounds])
+        r = self._L.orbx_extract_match_batch_host_async(self._h, int(n_frames), _ptr(h_imgs), int(width), int(height),
+                                                        int(stride), int(frame_stride), _ptr(h_kps), _ptr(h_desc),
+                                                        int(capacity or self.capacity), _ptr(h_n), len(first), _ptr(first),
+                                                        _ptr(second), ctypes.byref(b), int(windowSize), float(nnratio),
+                                                        int(bool(checkOri)), _ptr(h_matches12), _ptr(h_nmatches), _ptr(h_stats))
+        self._check(r, "orbx_extract_match_batch_host_async")
 
     def set_pipeline_depth(self, depth: int) -> None:
         """depth >= 1: every stream-ordered batch goes, whole, to the next of `depth` lanes (own stream, own buffers); at most `depth`

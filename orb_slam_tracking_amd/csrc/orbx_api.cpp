@@ -56,6 +56,7 @@ size_t octScratchBytes(int nMax, int qMax);
 hipError_t launch_to_gray(hipStream_t st, int nFrames, const uint8_t* src, long long srcFrameStride, int sstride, int w, int h,
                           int channels, int rgb, uint8_t* dst, long long dstFrameStride, int dstride, int grayVariant);
 hipError_t launch_check_model(hipStream_t st, int nModels, const ScoreArgs& a);
+hipError_t launch_copy_out(hipStream_t st, const CopyOut& c, int nseg, int maxRows);
 hipError_t launch_check_rt(hipStream_t st, int nModels, const CheckRtArgs& a);
 hipError_t launch_debug_sincos(hipStream_t st, const float* angle, int n, float* c, float* s, int libmFloat);
 hipError_t launch_undistort(hipStream_t st, int nFrames, const orbx_keypoint* in, const int* nkp, int capacity, const CamD& c,
@@ -219,6 +220,13 @@ struct orbx_ctx {
   std::vector<orbx_ctx*> lanes;
   unsigned laneIssue = 0, laneDone = 0;  // batches issued to / waited for on the lanes (round-robin in issue order)
   bool noSplit = false;                  // (a lane) never cuts a batch into halves
+  // orbx_extract_match_batch_host_async: the batch's frames go up into dIn and its results come down from these device
+  // buffers behind its kernels, all stream-ordered; evOut = the copies back have landed (waited for by waitOldest)
+  uint8_t* dPipeOut = nullptr;           // [kps | desc | n | matches12 | nmatches | stats]
+  size_t pipeOutBytes = 0;
+  hipEvent_t evOut[2]{};
+  bool outUsed[2]{};
+  bool hostInput = false;                // (while such a batch is issued) the second stream forks behind the upload
   unsigned seqIssue = 0;   // batches issued so far
   int pending = 0;         // issued and not yet waited for (0 .. 2)
   int parity = 0;          // of the batch being issued
@@ -1242,6 +1250,10 @@ int waitOldest(orbx_ctx* ctx) {
   const int parity = (int)((ctx->seqIssue - (unsigned)ctx->pending) & 1u);
   HIPCHK(hipEventSynchronize(ctx->evDone[parity]));
   if (ctx->done2Used[parity]) HIPCHK(hipEventSynchronize(ctx->evDone2[parity]));
+  if (ctx->outUsed[parity]) {  // a host-frame batch: its results are in the caller's buffers
+    HIPCHK(hipEventSynchronize(ctx->evOut[parity]));
+    ctx->outUsed[parity] = false;
+  }
   ctx->pending--;
   {
     const int sm = settleMatch(ctx, parity);
@@ -1369,7 +1381,7 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
       // new tables.  Only a stream-ordered (_async) call on the context's own stream with another batch in flight and an
       // unchanged pair list skips the fork: nothing but the previous batches sits on st then (every other entry point
       // drains the batches in flight first), and the frames are the caller's own resident array.
-      const bool needFork = !async || pairsCopied || ctx->pending == 0 || !ctx->ownStream;
+      const bool needFork = !async || pairsCopied || ctx->pending == 0 || !ctx->ownStream || ctx->hostInput;
       if (needFork) {
         HIPCHK(hipEventRecord(ctx->evFork, st));
         HIPCHK(hipStreamWaitEvent(ctx->st2, ctx->evFork, 0));
@@ -1500,6 +1512,9 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
   if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
   if (ctx->evOrder) (void)hipEventDestroy(ctx->evOrder);
+  for (int par = 0; par < 2; par++)
+    if (ctx->evOut[par]) (void)hipEventDestroy(ctx->evOut[par]);
+  if (ctx->dPipeOut) (void)hipFree(ctx->dPipeOut);
   if (ctx->st2) (void)hipStreamDestroy(ctx->st2);
   if (ctx->ownStream && ctx->st) (void)hipStreamDestroy(ctx->st);
   delete ctx;
@@ -1888,6 +1903,150 @@ int orbx_extract_match_batch_device_async(orbx_ctx* ctx, int n_frames, const uin
   ctx->lastLaunch[7] = 0;
   return extractMatch(ctx, n_frames, d_imgs, width, height, stride, frame_stride_bytes, d_kps, d_desc32, capacity, d_n_out, n_pairs,
                       h_first, h_second, bounds, window_size, nnratio, check_orientation, d_matches12, d_nmatches, d_stats, true);
+}
+
+// The host-frame form of the stream-ordered call: frames come from (page-locked) host memory, results go to (page-locked) host
+// memory.  Per batch, on the lane's stream: upload -> the kernels -> copies back; the uploads of the lanes' batches overlap the
+// kernels of the batches in front of them, so a caller that keeps `depth` batches in flight is bound by the slower of PCIe and
+// the kernels (640x480: PCIe).
+}  // extern "C"
+namespace {
+int hostBatchIssue(orbx_ctx* c, int n_frames, const uint8_t* h_imgs, int width, int height, int stride, size_t frame_stride_bytes,
+                   orbx_keypoint* h_kps, uint8_t* h_desc32, int capacity, int32_t* h_n_out, int n_pairs, const int32_t* h_first,
+                   const int32_t* h_second, const orbx_bounds* bounds, int window_size, float nnratio, int check_orientation,
+                   int32_t* h_matches12, int32_t* h_nmatches, int32_t* h_stats) {
+  orbx_ctx* ctx = c;  // (HIPCHK reports into the context that issues)
+  int r = waitAll(c);  // one batch per context: dIn and the result block are the batch's own
+  if (r != ORBX_OK) return r;
+  if (capacity < c->selCap) return ORBX_E_CAPACITY;
+  if (width > c->maxW || height > c->maxH || n_frames > c->maxB) {  // any image size, any batch size: the context grows first
+    Geom gChk;
+    r = buildGeometry(c, width, height, alignUp(width, 64), &gChk, nullptr);
+    if (r != ORBX_OK) return r;
+    r = growTo(c, std::max(width, c->maxW), std::max(height, c->maxH), std::max(n_frames, c->maxB));
+    if (r != ORBX_OK) return r;
+  }
+  const int dstride = alignUp(width, 64);
+  const size_t dfs = (size_t)dstride * height;
+  // the result block: [kps][desc][n][matches12][nmatches][stats], every part 256-byte aligned
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t oK = 0, oD = al(oK + sizeof(orbx_keypoint) * (size_t)capacity * n_frames), oN = al(oD + (size_t)32 * capacity * n_frames),
+               oM = al(oN + sizeof(int32_t) * (size_t)n_frames), oNm = al(oM + sizeof(int32_t) * (size_t)capacity * n_pairs),
+               oSt = al(oNm + sizeof(int32_t) * (size_t)n_pairs), total = al(oSt + sizeof(int32_t) * 3 * (size_t)n_pairs);
+  if (total > c->pipeOutBytes) {
+    if (c->dPipeOut) (void)hipFree(c->dPipeOut);
+    c->dPipeOut = nullptr;
+    c->pipeOutBytes = 0;
+    HIPCHK(hipMalloc((void**)&c->dPipeOut, total));
+    c->pipeOutBytes = total;
+  }
+  for (int par = 0; par < 2; par++)
+    if (!c->evOut[par]) HIPCHK(hipEventCreateWithFlags(&c->evOut[par], hipEventDisableTiming));
+  // nothing of a batch may be left to the host-side wait (the copies back run behind the kernels): the wide matcher kernels travel
+  // with every batch of this context from now on, as after orbx_order_before
+  c->eventOrdered = true;
+  // ---- upload (stream-ordered; asynchronous when the caller's memory is page-locked) ----
+  if (frame_stride_bytes == (size_t)stride * height || n_frames == 1) {
+    if (stride == dstride)
+      HIPCHK(hipMemcpyAsync(c->dIn, h_imgs, dfs * n_frames, hipMemcpyHostToDevice, c->st));
+    else
+      HIPCHK(hipMemcpy2DAsync(c->dIn, dstride, h_imgs, stride, width, (size_t)height * n_frames, hipMemcpyHostToDevice, c->st));
+  } else {
+    for (int f = 0; f < n_frames; f++)
+      HIPCHK(hipMemcpy2DAsync(c->dIn + f * dfs, dstride, h_imgs + (size_t)f * frame_stride_bytes, stride, width, height,
+                              hipMemcpyHostToDevice, c->st));
+  }
+  orbx_keypoint* dK = reinterpret_cast<orbx_keypoint*>(c->dPipeOut + oK);
+  uint8_t* dD = c->dPipeOut + oD;
+  int32_t* dN = reinterpret_cast<int32_t*>(c->dPipeOut + oN);
+  int32_t* dM = reinterpret_cast<int32_t*>(c->dPipeOut + oM);
+  int32_t* dNm = reinterpret_cast<int32_t*>(c->dPipeOut + oNm);
+  int32_t* dSt = h_stats ? reinterpret_cast<int32_t*>(c->dPipeOut + oSt) : nullptr;
+  c->hostInput = true;
+  r = extractMatch(c, n_frames, c->dIn, width, height, dstride, dfs, dK, dD, capacity, dN, n_pairs, h_first, h_second, bounds,
+                   window_size, nnratio, check_orientation, dM, dNm, dSt, true);
+  c->hostInput = false;
+  if (r != ORBX_OK) return r;
+  // ---- results back, behind the batch's kernels on both streams ----
+  const int par = (int)((c->seqIssue - 1u) & 1u);
+  if (c->done2Used[par]) HIPCHK(hipStreamWaitEvent(c->st, c->evDone2[par], 0));
+  // Page-locked result arrays are filled by a KERNEL storing over the link (k_copy_out): a copy command behind the kernels would sit
+  // at the head of its DMA queue until they have finished and hold up the next batches' uploads queued behind it.  Pageable
+  // arrays (no device mapping) take copy commands.
+  auto mapped = [&](void* h) -> void* {
+    void* d = nullptr;
+    if (!h) return nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return d;
+  };
+  void* mK = mapped(h_kps); void* mD = mapped(h_desc32); void* mN = mapped(h_n_out);
+  void* mM = n_pairs > 0 ? mapped(h_matches12) : nullptr; void* mNm = n_pairs > 0 ? mapped(h_nmatches) : nullptr;
+  void* mSt = n_pairs > 0 && h_stats ? mapped(h_stats) : nullptr;
+  const bool allMapped = mK && mD && mN && (n_pairs == 0 || (mM && mNm && (!h_stats || mSt)));
+  if (allMapped) {
+    CopyOut co{};
+    int ns = 0;
+    auto seg = [&](const void* src, void* dst, const int32_t* cnt, int rows, int rowDwords, int mult) {
+      co.s[ns].src = (const uint32_t*)src; co.s[ns].dst = (uint32_t*)dst; co.s[ns].cnt = cnt;
+      co.s[ns].rows = rows; co.s[ns].rowDwords = rowDwords; co.s[ns].mult = mult;
+      ns++;
+    };
+    seg(dK, mK, dN, n_frames, capacity * 7, 7);
+    seg(dD, mD, dN, n_frames, capacity * 8, 8);
+    seg(dN, mN, nullptr, 1, n_frames, 0);
+    if (n_pairs > 0) {
+      seg(dM, mM, nullptr, n_pairs, capacity, 0);
+      seg(dNm, mNm, nullptr, 1, n_pairs, 0);
+      if (h_stats) seg(dSt, mSt, nullptr, 1, 3 * n_pairs, 0);
+    }
+    HIPCHK(launch_copy_out(c->st, co, ns, std::max(n_frames, n_pairs)));
+  } else {
+    HIPCHK(hipMemcpyAsync(h_kps, dK, sizeof(orbx_keypoint) * (size_t)capacity * n_frames, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipMemcpyAsync(h_desc32, dD, (size_t)32 * capacity * n_frames, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipMemcpyAsync(h_n_out, dN, sizeof(int32_t) * (size_t)n_frames, hipMemcpyDeviceToHost, c->st));
+    if (n_pairs > 0) {
+      HIPCHK(hipMemcpyAsync(h_matches12, dM, sizeof(int32_t) * (size_t)capacity * n_pairs, hipMemcpyDeviceToHost, c->st));
+      HIPCHK(hipMemcpyAsync(h_nmatches, dNm, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost, c->st));
+      if (h_stats) HIPCHK(hipMemcpyAsync(h_stats, dSt, sizeof(int32_t) * 3 * (size_t)n_pairs, hipMemcpyDeviceToHost, c->st));
+    }
+  }
+  HIPCHK(hipEventRecord(c->evOut[par], c->st));
+  c->outUsed[par] = true;
+  return ORBX_OK;
+}
+}  // namespace
+extern "C" {
+
+int orbx_extract_match_batch_host_async(orbx_ctx* ctx, int n_frames, const uint8_t* h_imgs, int width, int height, int stride,
+                                        size_t frame_stride_bytes, orbx_keypoint* h_kps, uint8_t* h_desc32, int capacity,
+                                        int32_t* h_n_out, int n_pairs, const int32_t* h_first, const int32_t* h_second,
+                                        const orbx_bounds* bounds, int window_size, float nnratio, int check_orientation,
+                                        int32_t* h_matches12, int32_t* h_nmatches, int32_t* h_stats) {
+  if (!ctx) return ORBX_E_BADARG;
+  if (!h_imgs || width <= 0 || height <= 0) return ORBX_E_EMPTY;
+  if (!h_kps || !h_desc32 || !h_n_out || stride < width || n_frames < 1 || n_pairs < 0 ||
+      (n_pairs > 0 && (!h_first || !h_second || !bounds || !h_matches12 || !h_nmatches)))
+    return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  if (!ctx->lanes.empty()) {  // pipeline mode: the whole batch to the next lane, at most one batch per lane in flight
+    const unsigned L = (unsigned)ctx->lanes.size();
+    if (ctx->laneIssue - ctx->laneDone >= L) {
+      const int w = laneWaitOne(ctx);
+      if (w != ORBX_OK) return w;
+    }
+    orbx_ctx* c = ctx->lanes[ctx->laneIssue % L];
+    const int r = hostBatchIssue(c, n_frames, h_imgs, width, height, stride, frame_stride_bytes, h_kps, h_desc32, capacity, h_n_out,
+                                 n_pairs, h_first, h_second, bounds, window_size, nnratio, check_orientation, h_matches12, h_nmatches,
+                                 h_stats);
+    if (r != ORBX_OK) { ctx->err = c->err; return r; }
+    memcpy(ctx->lastLaunch, c->lastLaunch, sizeof ctx->lastLaunch);
+    ctx->lastLaunch[7] = (int)(ctx->laneIssue % L) + 1;
+    ctx->laneIssue++;
+    return ORBX_OK;
+  }
+  ctx->lastLaunch[7] = 0;
+  return hostBatchIssue(ctx, n_frames, h_imgs, width, height, stride, frame_stride_bytes, h_kps, h_desc32, capacity, h_n_out, n_pairs,
+                        h_first, h_second, bounds, window_size, nnratio, check_orientation, h_matches12, h_nmatches, h_stats);
 }
 
 int orbx_set_pipeline_depth(orbx_ctx* ctx, int depth) {

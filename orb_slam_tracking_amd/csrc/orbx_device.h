@@ -170,6 +170,18 @@ inline void octBigChoose(OctLevel* O, int nMax, int hint) {
   O->bigD0 = d; O->bigBuckets = (int32_t)nb; O->bigCapB = cap;
 }
 
+// k_copy_out: the result arrays of a host-frame batch, copied by a kernel into the caller's page-locked (device-mapped) arrays:
+// segment s = `rows` rows of `rowDwords` dwords, of which the first cnt[row] * mult are copied (cnt == nullptr: the whole row)
+struct CopySeg {
+  const uint32_t* src;
+  uint32_t* dst;
+  const int32_t* cnt;
+  int32_t rows, rowDwords, mult, pad;
+};
+struct CopyOut {
+  CopySeg s[6];
+};
+
 struct ResizeTab {
   int32_t ofs;    // source index
   int32_t coef;   // c0 | c1 << 16 (Q11)

@@ -2982,6 +2982,25 @@ hipError_t launch_to_gray(hipStream_t st, int nFrames, const uint8_t* src, long 
   return hipGetLastError();
 }
 
+// Results of a host-frame batch (orbx_extract_match_batch_host_async) into the caller's page-locked arrays, by stores over the link
+// instead of copy commands: a copy command queued behind a batch's kernels sits at the head of its DMA queue until they have
+// finished, and the NEXT batches' uploads queue behind it (measured: uploads and kernels of four lanes strictly alternate, 0.61 of
+// the link's rate; tools/host_pipeline_timeline.py).  grid = (chunks, rows, segments); only the entries a frame really has travel.
+__global__ __launch_bounds__(256) void k_copy_out(const CopyOut c) {
+  const CopySeg& s = c.s[blockIdx.z];
+  for (int row = blockIdx.y; row < s.rows; row += gridDim.y) {
+    const int n = s.cnt ? min(max(s.cnt[row], 0) * s.mult, s.rowDwords) : s.rowDwords;
+    const uint32_t* src = s.src + (long long)row * s.rowDwords;
+    uint32_t* dst = s.dst + (long long)row * s.rowDwords;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = src[i];
+  }
+}
+hipError_t launch_copy_out(hipStream_t st, const CopyOut& c, int nseg, int maxRows) {
+  if (nseg <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_copy_out, dim3(8, (unsigned)std::min(std::max(maxRows, 1), 1024), (unsigned)nseg), dim3(256), 0, st, c);
+  return hipGetLastError();
+}
+
 // test hook: the cos / sin pair of k_describe_patch for arbitrary angles (degrees)
 __global__ __launch_bounds__(256) void k_debug_sincos(const float* __restrict__ angle, int n, float* __restrict__ c, float* __restrict__ s,
                                                       const int libmFloat) {

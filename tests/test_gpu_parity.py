@@ -662,6 +662,67 @@ def test_async_batches_equal_sync(orbx):
     e.close()
 
 
+def test_host_async_batches_equal_oracle(orbx, oracle):
+    """orbx_extract_match_batch_host_async: frames from host memory (page-locked and pageable, a row stride that differs from the
+    width, frames with gaps between them), results into host arrays, on three lanes with three batches in flight, with depth 0, and
+    with a frame size that makes the lanes grow -- every frame and every pair against the oracle.  A wide window sends pairs
+    through the wide matcher kernels, which must travel with the batch (the copies back run behind the kernels)."""
+    import torch
+    from orb_slam_tracking_amd import synth
+    KP = orbx.KEYPOINT_DTYPE
+    B, cap = 18, 1000
+    oe = oracle.Extractor(*CANON)
+    e = orbx.ORBextractor(*CANON, max_width=400, max_height=300, max_batch=4)  # (smaller than what comes: the lanes grow)
+    first = np.arange(0, B - 1, 2, dtype=np.int32)
+
+    def outs(pin):
+        mk = (lambda n, dt: torch.zeros(n, dtype=dt).pin_memory()) if pin else (lambda n, dt: torch.zeros(n, dtype=dt))
+        return dict(k=mk(B * cap * 28, torch.uint8), d=mk(B * cap * 32, torch.uint8), n=mk(B, torch.int32), m=mk((B // 2) * cap, torch.int32),
+                    nm=mk(B // 2, torch.int32), st=mk((B // 2) * 3, torch.int32))
+
+    def check(o, frames, w, h, win):
+        n = o["n"].numpy()
+        kk = o["k"].numpy().view(KP).reshape(B, cap)
+        dd = o["d"].numpy().reshape(B, cap, 32)
+        mm = o["m"].numpy().reshape(B // 2, cap)
+        ora = [oe(f) for f in frames]
+        for f in range(B):
+            assert n[f] == len(ora[f][1])
+            _same(kk[f, :n[f]], dd[f, :n[f]], ora[f][1], ora[f][2])
+        for p_ in range(B // 2):
+            a, b = ora[2 * p_], ora[2 * p_ + 1]
+            onm, om12, ost = oracle.match_init(a[1], a[2], b[1], b[2], (0, w, 0, h), win, 0.9, True)
+            assert o["nm"].numpy()[p_] == onm and np.array_equal(mm[p_, :len(om12)], om12)
+            assert o["st"].numpy().reshape(-1, 3)[p_].tolist() == ost.tolist()
+
+    cases = []  # (host array handed over, frames, w, h, stride, frame stride, window, pinned outputs)
+    for i, (w, h, pad, gap, win, pin) in enumerate([(640, 480, 0, 0, 100, True), (640, 480, 0, 0, 4096, True), (324, 243, 12, 1000, 100, True),
+                                                    (640, 480, 0, 0, 100, False), (500, 375, 0, 0, 100, True)]):
+        fr = synth.synth_frames(B, w, h, seed0=900 + 50 * i)
+        stride, fs = w + pad, (w + pad) * h + gap
+        host = torch.zeros(B * fs, dtype=torch.uint8)
+        if pin:
+            host = host.pin_memory()
+        hv = host.numpy()
+        for f in range(B):
+            hv[f * fs:f * fs + stride * h].reshape(h, stride)[:, :w] = fr[f]
+        cases.append((host, fr, w, h, stride, fs, win, pin))
+    for depth in (3, 0):
+        e.set_pipeline_depth(depth)
+        sets = [outs(c[7]) for c in cases]
+        for j, (host, fr, w, h, stride, fs, win, pin) in enumerate(cases):
+            o = sets[j]
+            e.extract_match_batch_host_async(host, B, w, h, stride, fs, o["k"], o["d"], o["n"], first, first + 1, (0, w, 0, h), o["m"],
+                                             o["nm"], o["st"], win, 0.9, True, cap)
+        e.wait()
+        for j, (host, fr, w, h, stride, fs, win, pin) in enumerate(cases):
+            check(sets[j], fr, w, h, win)
+    with pytest.raises(orbx.OrbxError):
+        e.extract_match_batch_host_async(None, B, 640, 480, 640, 640 * 480, sets[0]["k"], sets[0]["d"], sets[0]["n"], first, first + 1,
+                                         (0, 640, 0, 480), sets[0]["m"], sets[0]["nm"], None, 100, 0.9, True, cap)
+    e.close()
+
+
 def test_pipeline_lanes_equal_sync(orbx):
     """orbx_set_pipeline_depth(3): seven stream-ordered batches go, whole, to three lanes (three in flight, a fourth call waits for
     the oldest) and give what the synchronous call gives; batch size, pair list and frame size change on the way; synchronous
