@@ -1016,11 +1016,34 @@ struct ExtractArgs {
 // Row bands of k_pyramid_bands.  Band b owns rows [b*h/K, (b+1)*h/K) of every level and, on top of that, every row of
 // level l-1 that its rows of level l read (cv::resize's y table: source rows ofs and ofs+1, clamped), from the last
 // level upwards.
-PyrBands computePyrBands(const orbx_ctx* ctx, int K) {
+PyrBands computePyrBands(const orbx_ctx* ctx, int K, int S = 1) {
   const Geom& g = ctx->g;
   const int nl = g.nlevels;
   PyrBands pb{};
   pb.nBands = K = std::min(K, ORBX_PYR_BANDS_MAX);
+  // Column strips: strip s owns groups [ng * s / S, ng * (s + 1) / S) of every level and, on top of that, every group of level l - 1
+  // that its groups of level l read: a group's taps lie in the 12 bytes from its first source dword (PyrXGroup::o), i.e. in source
+  // groups base / 4 .. base / 4 + 2.  No strip may be empty on any level (the last level decides how many there can be).
+  S = std::max(1, std::min(S, ORBX_PYR_STRIPS_MAX));
+  while (S > 1 && (g.L[nl - 1].w + 3) / 4 < 16 * S) S--;
+  pb.nStrips = S;
+  for (int s = 0; s < S; s++) {
+    int need0 = 0, need1 = 0;
+    for (int l = nl - 1; l >= 1; l--) {
+      const int ng = (g.L[l].w + 3) / 4;
+      int a = (int)((long long)ng * s / S), b = (int)((long long)ng * (s + 1) / S);
+      if (l < nl - 1 && need1 > need0) { a = std::min(a, need0); b = std::max(b, need1); }
+      pb.g0[s][l] = (int16_t)a;
+      pb.g1[s][l] = (int16_t)b;
+      need0 = need1 = 0;
+      if (b > a && l >= 2) {
+        const ResizeTab* xt = ctx->hTab.data() + g.L[l].xtabOff;
+        const int ngs = (g.L[l - 1].w + 3) / 4;
+        need0 = std::min(std::max((xt[4 * a].ofs & ~3) / 4, 0), ngs - 1);
+        need1 = std::min((xt[4 * (b - 1)].ofs & ~3) / 4 + 3, ngs);
+      }
+    }
+  }
   pb.dual2 = ctx->pyrInfo.dual2;
   for (int l = 0; l < nl; l++) { pb.xoff[l] = ctx->pyrInfo.xoff[l]; pb.yoff[l] = ctx->pyrInfo.yoff[l]; }
   for (int b = 0; b < K; b++) {
@@ -1065,10 +1088,12 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   const long long tilesMaxPx = std::min(knob(KNOB_TILES_MAX_PIXELS, kPyrTilesMaxPixels), kPyrTilesMaxPixels);
   const int bandsEnv = (int)knob(KNOB_PYR_BANDS, 0);  // diagnostics
   const int bandsMin = (int)knob(KNOB_BANDS_MIN_FRAMES, 0);  // diagnostics
+  const int stripsEnv = (int)knob(KNOB_PYR_STRIPS, 0);       // diagnostics
   // from 32 frames per stream, or from 8 when the frames are large (16 frames 1080p: 0.43 -> 0.30 ms; 16 frames 640x480 are
   // better off with the per-level launches: 0.252 vs 0.263 ms per 32-frame call)
-  const bool enough = bandsMin > 0 ? n >= bandsMin : (n >= 32 || (n >= 8 && (long long)n * g.L[0].w * g.L[0].h >= (16ll << 20)));
-  // (four 3840x2160 frames in 32 thin bands: 0.46 ms against 0.39 ms level by level; eight on a lane: level with the resize launches)
+  // (round 5: with column strips also few large frames -- the four-frame halves of a 3840x2160 batch in 32 bands x 4 strips: 0.227 ms
+  // per batch against 0.352 level by level and 0.456 in 32 bands without strips; tools/exp_pyr_strips.sh)
+  const bool enough = bandsMin > 0 ? n >= bandsMin : (n >= 32 || (n >= 2 && (long long)n * g.L[0].w * g.L[0].h >= (16ll << 20)));
   bool banded = nl > 1 && ctx->pyrInfo.ok && a.aligned0 && enough && !noBands;  // (dword loads: level 0 rows 4-byte aligned)
   PyrBands pb{};
   if (banded) {  // a band's rows of one level are staged by one pass of the workgroup: at most 256
@@ -1079,8 +1104,13 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
     const int rowBands = std::min(std::max(g.L[1].h / 130, 3), ORBX_PYR_BANDS_MAX);
     int K = n * rowBands >= 256 ? rowBands : std::min(ORBX_PYR_BANDS_MAX, std::max(rowBands, (256 + n - 1) / n));
     if (bandsEnv > 0) K = bandsEnv;
-    pb = computePyrBands(ctx, K);
-    while (pb.maxRows > 256 && K < ORBX_PYR_BANDS_MAX) pb = computePyrBands(ctx, K = std::min(2 * K, ORBX_PYR_BANDS_MAX));
+    // strips when the bands alone leave half the chip without a workgroup (n K <= 128): the fewest of 2 / 4 / 8 that give 384
+    int S = 1;
+    if (n * K <= 128)
+      while (S < ORBX_PYR_STRIPS_MAX && n * K * S < 384) S *= 2;
+    if (stripsEnv > 0) S = stripsEnv;
+    pb = computePyrBands(ctx, K, S);
+    while (pb.maxRows > 256 && K < ORBX_PYR_BANDS_MAX) pb = computePyrBands(ctx, K = std::min(2 * K, ORBX_PYR_BANDS_MAX), S);
     banded = pb.maxRows <= 256;
     pb.safeFrom = a.safeFrom;
   }
@@ -1089,7 +1119,7 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
     HIPCHK(launch_pyramid_bands(st, n, a.dImg0, a.frameStride0, ctx->dPyr, g, ctx->dTab, pb));
     tm.stop(1);
     ctx->lastLaunch[0] = 1;
-    ctx->lastLaunch[1] = pb.nBands;
+    ctx->lastLaunch[1] = pb.nBands * pb.nStrips;
   } else if (nl > 1 && ctx->nPyrTiles > 0 && !noTiles && n <= tilesMax && (long long)n * g.L[0].w * g.L[0].h <= tilesMaxPx) {
     // small batches: one launch, a workgroup per tile of a frame, the level chain through LDS
     StageTimer tm(ctx, ORBX_STAGE_PYRAMID, si, st);

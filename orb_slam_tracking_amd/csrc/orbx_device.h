@@ -203,12 +203,18 @@ struct PyrTileTap {
 
 // k_pyramid_bands: rows [r0, r1) of level l that band b of a frame produces (host: computePyrBands)
 #define ORBX_PYR_BANDS_MAX 32
+#define ORBX_PYR_STRIPS_MAX 8
 struct PyrBands {
   int32_t nBands, dual2;                                 // dual2: pixel 2 of some group needs the second dword pair
   int32_t safeFrom;                                      // frames >= safeFrom (batch index): nothing is known to follow their level 0
   int32_t maxRows;                                       // most rows any band has on any level (<= 256)
   int32_t xoff[ORBX_MAX_LEVELS], yoff[ORBX_MAX_LEVELS];  // the level's PyrXGroup / PyrYRow tables, in uint4 units from the table base
   int16_t r0[ORBX_PYR_BANDS_MAX][ORBX_MAX_LEVELS], r1[ORBX_PYR_BANDS_MAX][ORBX_MAX_LEVELS];
+  // column strips (round 5: few large frames -- four 3840x2160 frames are 128 workgroups of 32 bands, half the chip's CUs with one
+  // workgroup each): strip s of a band produces the 4-pixel groups [g0, g1) of level l, its own share of the row plus the groups
+  // its share of level l + 1 reads; workgroup = (band, strip).  One strip = the whole row (every 640x480 batch).
+  int32_t nStrips;
+  int16_t g0[ORBX_PYR_STRIPS_MAX][ORBX_MAX_LEVELS], g1[ORBX_PYR_STRIPS_MAX][ORBX_MAX_LEVELS];
 };
 // column constants of one group of 4 output pixels (host: appendPyrTables).  The group's taps lie in the 12 bytes of three
 // dwords at byte offsets o[0] = (first tap & ~3), o[1], o[2] of a source row (o[1], o[2]: + 4, + 8, but never beyond the

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(PYR_T) void k_pyramid_bands(const uint8_t* __restri
   // cost an LDS read instead of a global load in front of the source loads that depend on them
   ORBX_SETPRIO();
   extern __shared__ uint4 yrows[];  // [2][pb.maxRows]
-  const int f = blockIdx.y + g.frame0, band = blockIdx.x, tid = threadIdx.x;
+  const int f = blockIdx.y + g.frame0, strip = (int)blockIdx.x / pb.nBands, band = (int)blockIdx.x - strip * pb.nBands, tid = threadIdx.x;
   const int nl = g.nlevels;
 #ifdef ORBX_PYR_STAMPS
   const unsigned stampWg_ = blockIdx.y * gridDim.x + blockIdx.x;
@@ -314,11 +314,12 @@ __global__ __launch_bounds__(PYR_T) void k_pyramid_bands(const uint8_t* __restri
   // column constants of this thread for level l
   struct Cols {
     uint32_t o[2], sel[2][6], cf[2][4];
-    int G, rpp, rsub, col;
+    int G, rpp, rsub, col, gOff;
     bool lanes, haveG[2];
   };
   auto loadCols = [&](int l, Cols& c) {
-    const int ng = (g.L[l].w + 3) >> 2;          // groups of 4 output pixels per row
+    c.gOff = pb.g0[strip][l];
+    const int ng = max(pb.g1[strip][l] - c.gOff, 1);   // groups of 4 output pixels per row of this workgroup's strip
     // A thread keeps its column(s): it owns G adjacent groups (8 or 4 output pixels) of one thread-column and walks down the
     // band's rows, so the column constants of its pixels are loaded ONCE per level and stay in registers.  rpp rows are
     // covered per pass; G (1 or 2) = whichever fills more of the 256 lanes with whole rows (134 groups: 67 thread-columns
@@ -336,8 +337,8 @@ __global__ __launch_bounds__(PYR_T) void k_pyramid_bands(const uint8_t* __restri
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int gx = c.col * c.G + j;
-      c.haveG[j] = c.lanes && j < c.G && gx < ng;
-      const uint4* e = xg + (unsigned)(c.haveG[j] ? gx : 0) * 4u;
+      c.haveG[j] = c.lanes && j < c.G && gx < pb.g1[strip][l] - c.gOff;
+      const uint4* e = xg + (unsigned)(c.haveG[j] ? c.gOff + gx : 0) * 4u;
       const uint4 X0 = e[0], X1 = e[1], X2 = e[2];
       const uint32_t X3 = e[3].x;
       c.o[j] = X0.x;
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(PYR_T) void k_pyramid_bands(const uint8_t* __restri
           // (u + 2) >> 2 on two 16-bit fields at a time; bytes 0 and 2 of each pair are the pixels
           const uint32_t s01 = ((u[0] | (u[1] << 16)) + 0x00020002u) >> 2, s23 = ((u[2] | (u[3] << 16)) + 0x00020002u) >> 2;
           const uint32_t packed = __builtin_amdgcn_perm(s23, s01, 0x06040200u);
-          if (liveR[q] && C.haveG[j]) *reinterpret_cast<uint32_t*>(dst + (unsigned)(dy * dstride + (C.col * G + j) * 4)) = packed;
+          if (liveR[q] && C.haveG[j]) *reinterpret_cast<uint32_t*>(dst + (unsigned)(dy * dstride + (C.gOff + C.col * G + j) * 4)) = packed;
         }
       }
     }
@@ -3062,8 +3063,8 @@ hipError_t launch_resize(hipStream_t st, int nFrames, const uint8_t* src, long l
 hipError_t launch_pyramid_bands(hipStream_t st, int nFrames, const uint8_t* img0, long long img0FrameStride, uint8_t* pyr,
                                 const Geom& g, const ResizeTab* tab, const PyrBands& pb) {
   if (nFrames <= 0 || g.nlevels <= 1) return hipSuccess;
-  dim3 block(PYR_T, 1, 1), grid(pb.nBands, nFrames, 1);
-  if (pb.maxRows > 256 || pb.maxRows < 1) return hipErrorInvalidValue;  // (the host picks the band count accordingly)
+  dim3 block(PYR_T, 1, 1), grid(pb.nBands * pb.nStrips, nFrames, 1);
+  if (pb.maxRows > 256 || pb.maxRows < 1 || pb.nStrips < 1 || pb.nStrips > ORBX_PYR_STRIPS_MAX) return hipErrorInvalidValue;  // (the host picks the band count accordingly)
   if (pb.dual2)
     hipLaunchKernelGGL(k_pyramid_bands<1>, grid, block, 2 * (size_t)pb.maxRows * sizeof(uint4), st, img0, img0FrameStride, pyr, g,
                        reinterpret_cast<const uint4*>(tab), pb);

@@ -1355,10 +1355,72 @@ def test_tiled_pyramid_small_batches(orbx, oracle, params):
         e.close()
 
 
+def test_banded_pyramid_column_strips(orbx, oracle):
+    """k_pyramid_bands with column strips (round 5: few large frames; a workgroup = a row band x a column strip, each strip with the
+    groups its share of the next level reads): every pyramid level of every frame byte for byte against the oracle, for 2 .. 8
+    strips forced through the diagnostic knobs on frame sizes whose levels end in partial groups, at two scale factors; then the
+    library's own choice for the four-frame halves of a 3840x2160 batch (32 bands x 4 strips), whole extraction against the oracle."""
+    import torch
+    from orb_slam_tracking_amd import synth
+    try:
+        orbx.debug_set("bands_min_frames", 1)
+        for (w, h, B, params, K, S) in ((1280, 720, 3, (1500, 1.2, 8, 20, 7), 8, 2), (1284, 723, 2, (1500, 1.2, 8, 20, 7), 6, 4),
+                                        (2044, 600, 2, (1500, 1.2, 6, 20, 7), 4, 8), (1600, 900, 2, (1000, 1.5, 5, 20, 7), 5, 3),
+                                        (900, 500, 2, (1000, 1.2, 8, 20, 7), 3, 8)):  # (the last: fewer strips than asked, a level is too narrow)
+            orbx.debug_set("pyr_bands", K)
+            orbx.debug_set("pyr_strips", S)
+            frames = synth.synth_frames(B, w, h, 8100 + w)
+            oe = oracle.Extractor(*params)
+            e = orbx.ORBextractor(*params, max_width=w, max_height=h, max_batch=B)
+            cap = params[0]
+            d_img = torch.from_numpy(frames).cuda()
+            d_k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+            d_d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+            d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+            e.extract_batch_device(d_img, B, w, h, w, w * h, d_k, d_d, d_n, cap)
+            info = e.debug_last_launch()
+            assert info["pyramid_banded"] == 1 and info["pyramid_bands"] % K == 0 and (info["pyramid_bands"] == K * S or w == 900), info
+            n = d_n.cpu().numpy()
+            kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, cap)
+            dd = d_d.cpu().numpy().reshape(B, cap, 32)
+            for f in range(B):
+                _, ko, do = oe(frames[f], cap=cap)
+                for l in range(1, params[2]):
+                    assert np.array_equal(e.image_pyramid(l, f), oe.level_image(l)), (w, h, K, S, f, l)
+                assert n[f] == len(ko)
+                _same(kk[f, :n[f]], dd[f, :n[f]], ko, do)
+            e.close()
+    finally:
+        for k in ("bands_min_frames", "pyr_bands", "pyr_strips"):
+            orbx.debug_set(k, None)
+    w, h, B, cap = 3840, 2160, 8, 8000
+    params = (8000, 1.2, 8, 20, 7)
+    frames = synth.synth_frames(B, w, h, 7400)
+    oe = oracle.Extractor(*params)
+    e = orbx.ORBextractor(*params, max_width=w, max_height=h, max_batch=B)
+    d_img = torch.from_numpy(frames).cuda()
+    d_k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+    d_d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    e.extract_batch_device(d_img, B, w, h, w, w * h, d_k, d_d, d_n, cap)  # synchronous: two halves of four frames
+    info = e.debug_last_launch()
+    assert info["pyramid_banded"] == 1 and info["pyramid_bands"] == 32 * 4 and info["split"] == 1 and info["frames_per_launch"] == 4, info
+    n = d_n.cpu().numpy()
+    kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, cap)
+    dd = d_d.cpu().numpy().reshape(B, cap, 32)
+    for f in (0, 3, 4, B - 1):
+        _, ko, do = oe(frames[f], cap=cap)
+        for l in (1, 4, 7):
+            assert np.array_equal(e.image_pyramid(l, f), oe.level_image(l)), (f, l)
+        assert n[f] == len(ko)
+        _same(kk[f, :n[f]], dd[f, :n[f]], ko, do)
+    e.close()
+
+
 def test_banded_pyramid_wide_levels(orbx, oracle):
     """k_pyramid_bands on 3840x2160 frames (BASELINE config 5's size; levels 1 .. 7 up to 3200 pixels wide: 400 thread-columns of two
-    4-pixel groups, one row per pass): eight frames on a lane take it (the halves of a synchronous call, four frames, go level by
-    level); the extraction results (keypoints of all eight levels, descriptors) equal the oracle."""
+    4-pixel groups, one row per pass): eight frames on a lane take it in 32 bands (the four-frame halves of a synchronous call take
+    32 bands x 4 column strips: test_banded_pyramid_column_strips); the extraction results (keypoints of all eight levels, descriptors) equal the oracle."""
     import torch
     from orb_slam_tracking_amd import synth
     w, h, B, cap = 3840, 2160, 8, 8000
