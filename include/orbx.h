@@ -133,7 +133,8 @@ int orbx_extract(orbx_ctx* ctx, const uint8_t* img, int width, int height, int s
 
 /* Optional, for a host that keeps its frames in buffers of its own (a camera ring, a decoder's pool): page-locks [ptr, ptr + bytes)
  * so that orbx_extract / orbx_extract_batch copy a frame out of it with one asynchronous DMA instead of through the runtime's
- * staging copy of pageable memory (640x480: ~25 us of the call's ~100).  Thin wrappers over hipHostRegister / hipHostUnregister
+ * staging copy of pageable memory (measured at 640x480: 1-2 us of the call's ~85, BENCH_r04 single_frame.cpp_shim 0.0849 against
+ * 0.0836 ms; more for large frames, and it is what keeps orbx_extract_match_batch_host_async's uploads asynchronous).  Thin wrappers over hipHostRegister / hipHostUnregister
  * (a C++ host need not link HIP); the buffer must be unregistered before it is freed.  Results are the same either way. */
 int orbx_host_register(orbx_ctx* ctx, void* ptr, size_t bytes);
 int orbx_host_unregister(orbx_ctx* ctx, void* ptr);
@@ -381,6 +382,10 @@ int orbx_multi_wait(orbx_multi* m);
  * into the reference's order (cell row, cell col, y, x): xyr = (x, y, response) triples relative to
  * (minBorderX, minBorderY) like vToDistributeKeys (cpp:1134-1137).  Returns the count. */
 int orbx_debug_candidates(orbx_ctx* ctx, int frame, int level, float* xyr, int cap);
+/* The selection units (frame, level) of the context's last batch: counts[level] = keypoints the unit selected (negative: it
+ * failed), redone[level] (nullable) = 1 if the many-workgroup kernels could not take the unit (a bucket of keys overflowed its slot)
+ * and its workgroup redid it with the one-workgroup code -- results are the same, only the time differs. */
+int orbx_debug_selection_units(orbx_ctx* ctx, int frame, int32_t* counts, int32_t* redone);
 /* The quadtree selection alone, DistributeOctTree (cpp:698-1011), on the device (the kernels the pipeline uses).  Candidates must be given in row-major (y, x)
  * order with integer coordinates in [0, 4095] relative to (min_x, min_y) and integer responses in [0, 255].
  * variant 0 = LDS-resident kernel (redoing a unit that does not fit on global scratch), variant 1 = global-scratch kernel

@@ -150,15 +150,25 @@ class ORBextractor {
   int operator()(const orbx::Image8& image, const orbx::Image8& /*mask*/, std::vector<orbx::KeyPoint>& keypoints,
                  std::vector<uint8_t>& descriptors, std::vector<int>& vLappingArea) {
     if (image.empty()) return -1;  // cpp:1536
-    // (no zero-fill per call: the library overwrites the first n entries, and the vectors are cut to n below)
-    if (keypoints.size() < (size_t)std::max(capacity_, 1)) keypoints.resize(std::max(capacity_, 1));
-    if (descriptors.size() < (size_t)std::max(capacity_, 1) * 32) descriptors.resize((size_t)std::max(capacity_, 1) * 32);
+    // extraction into the extractor's own scratch (kept across calls: no allocation and no value-initialisation of capacity-sized
+    // vectors per frame), then exactly n entries into the caller's vectors; on an error the caller's vectors are left empty, as the
+    // reference leaves them.  An ORBextractor is used by one thread at a time, like the reference's.
+    static_assert(sizeof(orbx::KeyPoint) == sizeof(orbx_keypoint), "orbx::KeyPoint layout");
+    std::vector<orbx_keypoint>& k = scratchK_;
+    std::vector<uint8_t>& d = scratchD_;
+    if (k.size() < (size_t)std::max(capacity_, 1)) k.resize(std::max(capacity_, 1));
+    if (d.size() < (size_t)std::max(capacity_, 1) * 32) d.resize((size_t)std::max(capacity_, 1) * 32);
     int n = 0;
-    const int r = orbx_extract(ctx_, image.data, image.cols, image.rows, image.step, vLappingArea[0], vLappingArea[1],
-                               reinterpret_cast<orbx_keypoint*>(keypoints.data()), descriptors.data(), capacity_, &n);
-    if (r < 0) throw orbx::Error(r, orbx_last_error(ctx_));
-    keypoints.resize(n);          // _keypoints = vector(nkeypoints), cpp:1581
-    descriptors.resize((size_t)n * 32);  // rows == #keypoints, cols == 32, CV_8U
+    const int r = orbx_extract(ctx_, image.data, image.cols, image.rows, image.step, vLappingArea[0], vLappingArea[1], k.data(), d.data(),
+                               capacity_, &n);
+    if (r < 0) {
+      keypoints.clear();
+      descriptors.clear();
+      throw orbx::Error(r, orbx_last_error(ctx_));
+    }
+    const orbx::KeyPoint* kp = reinterpret_cast<const orbx::KeyPoint*>(k.data());
+    keypoints.assign(kp, kp + n);                              // _keypoints = vector(nkeypoints), cpp:1581
+    descriptors.assign(d.begin(), d.begin() + (size_t)n * 32);  // rows == #keypoints, cols == 32, CV_8U
     return r;
   }
   std::vector<std::vector<uint8_t>> mvImagePyramid;  // filled on demand by imagePyramid()

@@ -139,6 +139,7 @@ def lib() -> ctypes.CDLL:
     L.orbx_debug_sincos.argtypes = [vp, vp, i32, vp, vp]
     L.orbx_debug_set.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
     L.orbx_debug_last_launch.argtypes = [vp, vp]
+    L.orbx_debug_selection_units.argtypes = [vp, i32, vp, vp]
     L.orbx_debug_path_codes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
     _LIB = L
     # The library reads no environment variable; the profiling scripts' ORBX_<KNOB> settings are forwarded to orbx_debug_set here
@@ -152,7 +153,7 @@ def lib() -> ctypes.CDLL:
 
 KNOBS = ("no_bands", "no_tiles", "tiles_max_frames", "tiles_max_pixels", "pyr_bands", "pyr_strips", "bands_min_frames", "desc_no_staged",
          "desc_staged_max", "no_split", "lat_trace", "no_direct_out", "fast_wg", "fast_wg_max_cells", "fast_lds_pad", "fast_debug",
-         "desc_lds_pad", "match_no_general", "oct_no_small", "oct_key64", "oct_split_min", "oct_no_big", "octb_no_512", "oct_inst",
+         "desc_lds_pad", "match_no_general", "oct_no_small", "oct_key64", "oct_split_min", "oct_no_big", "oct_big_depth", "oct_big_no_fallback", "octb_no_512", "oct_inst",
          "oct_lds_pad", "multi_force_rccl")
 KNOB_UNSET = -(1 << 63)
 
@@ -582,6 +583,12 @@ class ORBextractor:
         return dict(pyramid_banded=int(v[0]), pyramid_bands=int(v[1]), fast_wave=int(v[2]), octree_instance=int(v[3]),
                     split=int(v[4]) & 1, staged_lists=(int(v[4]) >> 1) & 1, frames_per_launch=int(v[5]), wide_with_batch=int(v[6]),
                     lane=int(v[7]))
+
+    def debug_selection_units(self, frame: int = 0):
+        """(counts, redone) per pyramid level of one frame of the last batch (include/orbx.h: orbx_debug_selection_units)."""
+        c, r = np.zeros(self.GetLevels(), np.int32), np.zeros(self.GetLevels(), np.int32)
+        self._check(self._L.orbx_debug_selection_units(self._h, int(frame), _ptr(c), _ptr(r)), "orbx_debug_selection_units")
+        return c, r
 
     def debug_candidates(self, frame: int, level: int) -> np.ndarray:
         n = self._check(self._L.orbx_debug_candidates(self._h, frame, level, None, 0))

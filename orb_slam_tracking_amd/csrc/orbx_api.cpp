@@ -2516,6 +2516,23 @@ int orbx_debug_candidates(orbx_ctx* ctx, int frame, int level, float* xyr, int c
   return cnt;
 }
 
+int orbx_debug_selection_units(orbx_ctx* ctx, int frame, int32_t* counts, int32_t* redone) {
+  if (!ctx || frame < 0 || frame >= ctx->lastB || !counts) return ORBX_E_BADARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  {
+    const int w = waitAll(ctx);
+    if (w == ORBX_E_HIP) return w;
+  }
+  const int nl = ctx->p.nlevels;
+  std::vector<int32_t> raw((size_t)nl);
+  HIPCHK(hipMemcpy(raw.data(), ctx->dNselLevel + (size_t)frame * nl, sizeof(int32_t) * (size_t)nl, hipMemcpyDeviceToHost));
+  for (int l = 0; l < nl; l++) {
+    counts[l] = raw[l] < 0 ? raw[l] : (raw[l] & ~ORBX_OCT_REDONE);
+    if (redone) redone[l] = raw[l] >= 0 && (raw[l] & ORBX_OCT_REDONE) ? 1 : 0;
+  }
+  return ORBX_OK;
+}
+
 }  // extern "C"
 
 // ---- device-side test hooks for the selection stage ------------------------------------------------------------

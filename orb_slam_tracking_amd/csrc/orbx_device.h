@@ -1,5 +1,6 @@
 // orbx_device.h — POD structures shared between the host pipeline and the HIP kernels of liborbx.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 
 #include "../../include/orbx.h"
@@ -139,10 +140,52 @@ struct OctLaunch {
 #define ORBX_OCT_MAX_CAND ((1 << 19) - 1)  // candidates per (frame, level) the selection stage can index
 // what a unit reports for the next batch's launch choices (maxN[], hostMaxN[], the host's candHintL[]): its candidate count and, from
 // k_octree_big, the fill of its fullest bucket; the reducers take the maximum of each field
-#define ORBX_OCT_FEEDBACK(n, fill) ((int)(n) | ((int)(fill) << 20))
-#define ORBX_OCT_FB_COUNT(v) ((int)(v) & 0xfffff)
-#define ORBX_OCT_FB_FILL(v) ((int)(v) >> 20)
-#define ORBX_OCT_FB_MAX(a, b) ORBX_OCT_FEEDBACK(ORBX_OCT_FB_COUNT(a) > ORBX_OCT_FB_COUNT(b) ? ORBX_OCT_FB_COUNT(a) : ORBX_OCT_FB_COUNT(b), ORBX_OCT_FB_FILL(a) > ORBX_OCT_FB_FILL(b) ? ORBX_OCT_FB_FILL(a) : ORBX_OCT_FB_FILL(b))
+// (round 5: and the bucket depth the unit ran with -- a fill says nothing without it: ADVICE r04.)  Bits 0..18 count, 19..27 the
+// fill in units of four keys (rounded up), 28..30 the depth.
+#define ORBX_OCT_FEEDBACK(n, fill, depth) ((int)(n) | ((((int)(fill) + 3) >> 2) << 19) | ((int)(depth) << 28))
+#define ORBX_OCT_FB_COUNT(v) ((int)(v) & 0x7ffff)
+#define ORBX_OCT_FB_FILL(v) ((((int)(v) >> 19) & 0x1ff) << 2)
+#define ORBX_OCT_FB_DEPTH(v) (((int)(v) >> 28) & 7)
+#define ORBX_OCT_FB_MAXF(a, b, F) (F(a) > F(b) ? F(a) : F(b))
+#define ORBX_OCT_FB_MAX(a, b) ORBX_OCT_FEEDBACK(ORBX_OCT_FB_MAXF(a, b, ORBX_OCT_FB_COUNT), ORBX_OCT_FB_MAXF(a, b, ORBX_OCT_FB_FILL), ORBX_OCT_FB_MAXF(a, b, ORBX_OCT_FB_DEPTH))
+#define ORBX_OCT_REDONE 0x40000000  // bit of a (frame, level) count in nselLevel[]: k_octree_big redid the unit in place with the one-workgroup code
+
+#if defined(__HIPCC__)
+// ---- bookkeeping of the selection stage shared by k_sel_compact and the staged form of k_describe_patch (small launches, which
+//      run no k_sel_compact): ONE definition of what a unit's raw count means and of what is published per frame ----
+// a unit's raw count in nselLevel[]: negative = the unit failed; ORBX_OCT_REDONE set = k_octree_big redid it in place (same result)
+__device__ __forceinline__ int selUnitCount(int raw, bool* failed) {
+  *failed = *failed || raw < 0;
+  return raw < 0 ? 0 : (raw & ~ORBX_OCT_REDONE);
+}
+// a frame's totals: to the context's array (k_describe_patch's launch bound), the caller's array, the host's mapped mirror; a failed
+// unit raises the host's error flag (ORBX_E_CAPACITY at the batch's wait)
+__device__ __forceinline__ void selPublishFrame(int f, int total, bool failed, int* __restrict__ nsel, int* __restrict__ nselUser,
+                                                int* __restrict__ hostNsel, int* __restrict__ hostErr) {
+  nsel[f] = total;
+  if (nselUser) nselUser[f] = total;
+  if (hostNsel) hostNsel[f] = total;
+  if (failed) *hostErr = 1;
+}
+// per-level maxima (field by field, ORBX_OCT_FEEDBACK) of the units' reports of frames [frame0, frame0 + nFrames), by ONE wave:
+// lane = (frame % 4, level); the reports are reset for the next launch
+__device__ __forceinline__ void selReduceReports(int lane, int frame0, int nFrames, int nlevels, int* __restrict__ maxN,
+                                                 int* __restrict__ hostMaxN) {
+  static_assert(ORBX_MAX_LEVELS <= 16, "sixteen lanes per frame");
+  int m = 0;
+  if ((lane & 15) < nlevels)
+    for (int fr = lane >> 4; fr < nFrames; fr += 4) {
+      const int idx = (frame0 + fr) * nlevels + (lane & 15);
+      const int v = maxN[idx];
+      m = ORBX_OCT_FB_MAX(m, v);
+      maxN[idx] = 0;
+    }
+  { const int t = __shfl_xor(m, 16); m = ORBX_OCT_FB_MAX(m, t); }
+  { const int t = __shfl_xor(m, 32); m = ORBX_OCT_FB_MAX(m, t); }
+  if (lane < nlevels) hostMaxN[lane] = m;
+}
+#endif
+
 
 // Bucket depth of a level for one launch of the many-workgroup selection (k_octree_buckets / k_octree_big): the coarsest depth
 // that leaves a bucket at most 256 keys on average of the `hint` candidates a unit of that level had in the previous batch (a
@@ -151,8 +194,15 @@ struct OctLaunch {
 // many small buckets cost more than few full ones: 40 us against 13 for the 600 k keys of four 4K frames) -- or, without a hint,
 // about 16 k pixels: 250 keys at 1.5 %.  nMax = the candidates the unit's scratch is sized for (OctLaunch::scrNMax):
 // the buckets' slots share its key array.  bigBuckets == 0: no plan, the level keeps the one-workgroup kernel.
-inline void octBigChoose(OctLevel* O, int nMax, int hint) {
+// fillPrev / dPrev (round 5): the fullest bucket of the previous batch's units of this level and the depth they ran with.
+// A bucket of a coarser depth d holds at most fillPrev * 4^(dPrev - d) keys, one of a finer depth at most fillPrev: the depth is
+// deepened until that bound leaves a quarter of the bucket's slot free.  (Before, the depth came from the count alone; a unit
+// whose bucket overflowed reported the largest count, got the deepest depth for one batch, reported its true count from there and
+// returned to the depth that overflowed: every second batch of a scene with one dense cluster went through the in-place redo.)
+// *estFill = that bound for the chosen depth (0 = unknown): picks k_octree_buckets' LDS slot count.
+inline void octBigChoose(OctLevel* O, int nMax, int hint, int fillPrev = 0, int dPrev = 0, int* estFill = nullptr) {
   O->bigD0 = 0; O->bigBuckets = 0; O->bigCapB = 0;
+  if (estFill) *estFill = 0;
   if (O->bigDMax < 0) return;
   int d = 0;
   if (hint > 0) {
@@ -163,11 +213,22 @@ inline void octBigChoose(OctLevel* O, int nMax, int hint) {
   }
   long long nPad = 1024;
   while (nPad < nMax) nPad <<= 1;
+  auto capOf = [&](int dd) {
+    const long long nb = (long long)O->nIni << (2 * dd);
+    int cap = ORBX_OCTB_CAP;
+    while (cap > 0 && (long long)cap * nb > nPad) cap >>= 1;
+    return cap;
+  };
+  auto bound = [&](int dd) -> long long {
+    if (fillPrev <= 0) return 0;
+    return dd <= dPrev ? (long long)fillPrev << (2 * (dPrev - dd)) : (long long)fillPrev;
+  };
+  while (d < O->bigDMax && bound(d) * 4 > 3ll * capOf(d)) d++;
   const long long nb = (long long)O->nIni << (2 * d);
-  int cap = ORBX_OCTB_CAP;
-  while (cap > 0 && (long long)cap * nb > nPad) cap >>= 1;
+  const int cap = capOf(d);
   if (cap < 256 || nb > ORBX_OCTB_MAX_BUCKETS) return;
   O->bigD0 = d; O->bigBuckets = (int32_t)nb; O->bigCapB = cap;
+  if (estFill) *estFill = (int)std::min<long long>(bound(d), 1 << 20);
 }
 
 // k_copy_out: the result arrays of a host-frame batch, copied by a kernel into the caller's page-locked (device-mapped) arrays:

@@ -1293,35 +1293,16 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe_patch(const uint8_
   if constexpr (STAGED) {
     // keypoint i of the level-major order = entry i - (keypoints of the levels below) of its level's staging list; the counts of
     // the frame's levels come through scalar loads (a unit the selection redid carries a tag bit, a failed one a negative count)
-    int off = 0, total = 0, kl = 0, bad = 0;
+    int off = 0, total = 0, kl = 0;
+    bool bad = false;
     for (int l = 0; l < g.nlevels; l++) {
-      int c = ds.nselLevel[f * g.nlevels + l];
-      bad |= c < 0;
-      c = c < 0 ? 0 : (c & ~0x40000000);
+      const int c = selUnitCount(ds.nselLevel[f * g.nlevels + l], &bad);
       if (i >= total) { off = total; kl = l; }
       total += c;
     }
-    if (i == 0) {  // the frame's designated wave: k_sel_compact's bookkeeping
-      if (lane == 0) {
-        ds.nsel[f] = total;
-        if (ds.nselUser) ds.nselUser[f] = total;
-        if (ds.hostNsel) ds.hostNsel[f] = total;
-        if (bad) *ds.hostErr = 1;
-      }
-      if (blockIdx.y == 0 && ds.maxN) {  // per-level maxima of the units' candidate counts, counts reset (lane = frame % 4, level)
-        static_assert(ORBX_MAX_LEVELS <= 16, "sixteen lanes per frame");
-        int m = 0;
-        if ((lane & 15) < g.nlevels)
-          for (int fr = lane >> 4; fr < (int)gridDim.y; fr += 4) {
-            const int idx = (g.frame0 + fr) * g.nlevels + (lane & 15);
-            const int v = ds.maxN[idx];
-            m = ORBX_OCT_FB_MAX(m, v);  // (count and bucket fill: the maximum of each field)
-            ds.maxN[idx] = 0;
-          }
-        { const int t = __shfl_xor(m, 16); m = ORBX_OCT_FB_MAX(m, t); }
-        { const int t = __shfl_xor(m, 32); m = ORBX_OCT_FB_MAX(m, t); }
-        if (lane < g.nlevels) ds.hostMaxN[lane] = m;
-      }
+    if (i == 0) {  // the frame's designated wave: k_sel_compact's bookkeeping (orbx_device.h: one definition for both)
+      if (lane == 0) selPublishFrame(f, total, bad, ds.nsel, ds.nselUser, ds.hostNsel, ds.hostErr);
+      if (blockIdx.y == 0 && ds.maxN) selReduceReports(lane, g.frame0, (int)gridDim.y, g.nlevels, ds.maxN, ds.hostMaxN);
     }
     if (i >= total) return;  // wave-uniform
     k = ds.selStage[(long long)f * ds.selStride + ds.selOff[kl] + (i - off)];

@@ -32,6 +32,8 @@ namespace orbx {
   X(KNOB_OCT_KEY64, "oct_key64")              /* selection: always 64-bit sort keys */                                           \
   X(KNOB_OCT_SPLIT_MIN, "oct_split_min")      /* batch size from which every group of levels with one instance gets its own launch */ \
   X(KNOB_OCT_NO_BIG, "oct_no_big")            /* large units on one workgroup (k_octree_global) instead of the bucket kernels */ \
+  X(KNOB_OCT_BIG_DEPTH, "oct_big_depth")      /* bucket depth of the many-workgroup selection (tests: a depth whose buckets overflow) */ \
+  X(KNOB_OCT_BIG_NO_FALLBACK, "oct_big_no_fallback") /* k_octree_big does not redo a unit it cannot take: the unit fails (tests) */ \
   X(KNOB_OCTB_NO_512, "octb_no_512")          /* k_octree_buckets: always 1024 LDS slots per wave */                             \
   X(KNOB_OCT_INST, "oct_inst")                /* LDS instance per level, one hex digit per level from level 0 upwards (lowest digit
                                                  first): 1 = 512, 2 = 1024, 3 = 2048, 0 = the default choice */                 \

@@ -109,7 +109,6 @@ typedef unsigned long long u64;
 #define OCT_PAR_NEED(capN) (((capN) + 8) + ((capN) + 2 > 130 * ((capN) / 128 < 4 ? 4 : (capN) / 128) ? (capN) + 2 : 130 * ((capN) / 128 < 4 ? 4 : (capN) / 128)) + (capN) / 16 + 2)
 static_assert(OCT_PAR_NEED(256) <= OCT_PAR_SCR_FOR(256) && OCT_PAR_NEED(512) <= OCT_PAR_SCR_FOR(512) && OCT_PAR_NEED(2048) <= OCT_PAR_SCR_FOR(2048),
               "scratch of the parallel std::sort replay");
-#define ORBX_OCT_REDONE 0x40000000  // bit of a (frame, level) count: k_octree_emit redid the unit with the one-workgroup code
 #define OCTBIG_NODES 8192   // k_octree_big: list nodes of a unit (LDS tables; M < 4 N)
 #define OCTBIG_PEND 2048    // ... pending nodes of a partial-pass round (< N)
 #define OCTBIG_XCHG 4096    // ... u64 entries of its sort exchange buffer (8192 32-bit node keys, 4096 64-bit ones)
@@ -624,21 +623,11 @@ __global__ __launch_bounds__(ORBX_TAIL_T) void k_sel_compact(const SelKp* __rest
   // (small launches: the first workgroup, one count per thread; else workgroup l takes level l)
   const int nUnits = (int)gridDim.x * P.nlevels;
   if (maxN && part == 0 && (nUnits <= 256 ? blockIdx.x == 0 : (int)blockIdx.x < P.nlevels)) {
-    __shared__ int red[ORBX_MAX_LEVELS], redFill[ORBX_MAX_LEVELS];  // (ORBX_OCT_FEEDBACK: count and bucket fill, the maximum of each)
-    if (threadIdx.x < P.nlevels) { red[threadIdx.x] = 0; redFill[threadIdx.x] = 0; }
+    __shared__ int red[ORBX_MAX_LEVELS], redFill[ORBX_MAX_LEVELS], redDepth[ORBX_MAX_LEVELS];  // (ORBX_OCT_FEEDBACK: the maximum of each field)
+    if (threadIdx.x < P.nlevels) { red[threadIdx.x] = 0; redFill[threadIdx.x] = 0; redDepth[threadIdx.x] = 0; }
     __syncthreads();
-    if (nUnits <= 256) {
-      for (int u = threadIdx.x; u < nUnits; u += T) {
-        const int idx = P.frame0 * P.nlevels + u;
-        const int v = maxN[idx];
-        maxN[idx] = 0;
-        if (v > 0) {
-          atomicMax(&red[u % P.nlevels], ORBX_OCT_FB_COUNT(v));
-          atomicMax(&redFill[u % P.nlevels], ORBX_OCT_FB_FILL(v));
-        }
-      }
-      __syncthreads();
-      if (threadIdx.x < P.nlevels) hostMaxN[threadIdx.x] = ORBX_OCT_FEEDBACK(red[threadIdx.x], redFill[threadIdx.x]);
+    if (nUnits <= 256) {  // (one wave, the code the staged descriptor kernel runs: orbx_device.h)
+      if (threadIdx.x < 64) selReduceReports((int)threadIdx.x, P.frame0, (int)gridDim.x, P.nlevels, maxN, hostMaxN);
     } else {
       const int l = blockIdx.x;
       int m = 0;
@@ -650,9 +639,11 @@ __global__ __launch_bounds__(ORBX_TAIL_T) void k_sel_compact(const SelKp* __rest
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(m, o); m = ORBX_OCT_FB_MAX(m, t); }
-      if ((threadIdx.x & 63) == 0 && m > 0) { atomicMax(&red[l], ORBX_OCT_FB_COUNT(m)); atomicMax(&redFill[l], ORBX_OCT_FB_FILL(m)); }
+      if ((threadIdx.x & 63) == 0 && m > 0) {
+        atomicMax(&red[l], ORBX_OCT_FB_COUNT(m)); atomicMax(&redFill[l], ORBX_OCT_FB_FILL(m)); atomicMax(&redDepth[l], ORBX_OCT_FB_DEPTH(m));
+      }
       __syncthreads();
-      if (threadIdx.x == 0) hostMaxN[l] = ORBX_OCT_FEEDBACK(red[l], redFill[l]);
+      if (threadIdx.x == 0) hostMaxN[l] = ORBX_OCT_FEEDBACK(red[l], redFill[l], redDepth[l]);
     }
   }
   __shared__ int off[ORBX_MAX_LEVELS + 1];
@@ -661,18 +652,10 @@ __global__ __launch_bounds__(ORBX_TAIL_T) void k_sel_compact(const SelKp* __rest
     bool bad = false;
     for (int l = 0; l < P.nlevels; l++) {
       off[l] = acc;
-      int c = nselLevel[f * P.nlevels + l];
-      if (c >= 0) c &= ~ORBX_OCT_REDONE;  // (k_octree_emit marks the count of a unit it redid)
-      bad |= c < 0;
-      acc += max(c, 0);
+      acc += selUnitCount(nselLevel[f * P.nlevels + l], &bad);
     }
     off[P.nlevels] = acc;
-    if (part == 0) {
-      nsel[f] = acc;
-      if (nselUser) nselUser[f] = acc;
-      if (hostNsel) hostNsel[f] = acc;
-      if (bad) *hostErr = 1;
-    }
+    if (part == 0) selPublishFrame(f, acc, bad, nsel, nselUser, hostNsel, hostErr);
   }
   __syncthreads();
   for (int l = 0; l < P.nlevels; l++) {
@@ -722,7 +705,21 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
   OctLaunch Q = P;  // the launch's bucket depths: from the candidate counts of the previous batch (octBigChoose)
   // (hintL: ORBX_OCT_FEEDBACK values -- the previous batch's largest candidate count and fullest bucket per level)
   auto hintOf = [&](int l) { return hintL ? ORBX_OCT_FB_COUNT(hintL[l]) : 0; };
-  for (int l = 0; l < Q.nlevels; l++) octBigChoose(&Q.lev[l], Q.scrNMax[l], hintOf(l));
+  int estFill[ORBX_MAX_LEVELS] = {};  // (bound of the fullest bucket at the chosen depth, from the previous batch's fill and depth)
+  for (int l = 0; l < Q.nlevels; l++)
+    octBigChoose(&Q.lev[l], Q.scrNMax[l], hintOf(l), hintL ? ORBX_OCT_FB_FILL(hintL[l]) : 0, hintL ? ORBX_OCT_FB_DEPTH(hintL[l]) : 0, &estFill[l]);
+  const int depthKnob = (int)knob(KNOB_OCT_BIG_DEPTH, -1);  // diagnostics / tests: this depth whatever the previous batch reported
+  if (depthKnob >= 0)
+    for (int l = 0; l < Q.nlevels; l++)
+      if (Q.lev[l].bigBuckets > 0 && depthKnob <= Q.lev[l].bigDMax) {
+        OctLevel& O = Q.lev[l];
+        long long nPad = 1024;
+        while (nPad < Q.scrNMax[l]) nPad <<= 1;
+        const long long nb = (long long)O.nIni << (2 * depthKnob);
+        int cap = ORBX_OCTB_CAP;
+        while (cap > 0 && (long long)cap * nb > nPad) cap >>= 1;
+        if (cap >= 256 && nb <= ORBX_OCTB_MAX_BUCKETS) { O.bigD0 = depthKnob; O.bigBuckets = (int32_t)nb; O.bigCapB = cap; estFill[l] = 0; }
+      }
   auto launchBig = [&](int l0, int l1, bool fallback) {
     int nBuckets = 0;
     for (int l = l0; l < l1; l++) nBuckets += Q.lev[l].bigBuckets;
@@ -738,7 +735,7 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
       bool known = hintL != nullptr;
       for (int l = l0; l < l1; l++)
         if (Q.lev[l].bigBuckets > 0) {
-          const int fl = hintL ? ORBX_OCT_FB_FILL(hintL[l]) : 0;
+          const int fl = estFill[l];  // (scaled to this launch's depth)
           known = known && fl > 0;
           fillMost = std::max(fillMost, fl);
         }
@@ -819,7 +816,7 @@ hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, cons
         bool planned = !noBig;
         for (int l = l0; l < l1; l++) planned = planned && Q.lev[l].bigBuckets > 0;
         if (planned) {
-          launchBig(l0, l1, true);
+          launchBig(l0, l1, !knobOn(KNOB_OCT_BIG_NO_FALLBACK));
         } else {  // what fits the LDS layout is done there, the rest is deferred to the one-workgroup kernel
           ORBX_OCT_LAUNCH(2048, 256, 1);
           hipLaunchKernelGGL(k_octree_global, grid, dim3(1024), 0, st, cand, cellCount, P, selStage, nselLevel, scratch, 0, l0);

@@ -556,6 +556,97 @@ def test_device_octree_many_workgroups(orbx, ext640, oracle, shape):
         assert e.code == orbx.E_CAPACITY
 
 
+def test_dense_cluster_does_not_alternate_redos(orbx, oracle):
+    """a scene with one dense cluster of corners at 1920x1080 / 4000 features.  The many-workgroup selection picks its
+    bucket depth from the previous batch; from the candidate COUNT alone the level-0 unit would get a depth whose bucket under the
+    cluster overflows, be redone in place, report the largest count, get the deepest depth, report its true count from there and
+    return to the depth that overflowed -- every second batch through the one-workgroup code.  With the fullest bucket's fill and
+    its depth in the feedback no batch after the second redoes a unit, and every batch equals the oracle."""
+    import torch
+    w, h, B, cap = 1920, 1080, 4, 4000
+    params = (4000, 1.2, 8, 20, 7)
+    rng = np.random.default_rng(77)
+    frames = np.full((B, h, w), 90, np.uint8)
+    for f in range(B):
+        frames[f, 300:640, 500:840] = rng.integers(0, 256, (340, 340), dtype=np.uint8)  # the cluster
+        for _ in range(60):  # a few corners elsewhere
+            y, x = int(rng.integers(30, h - 40)), int(rng.integers(30, w - 40))
+            frames[f, y:y + 9, x:x + 9] = int(rng.integers(150, 256))
+    oe = oracle.Extractor(*params)
+    _, ko, do = oe(frames[0], cap=cap)
+    c0 = oe.level_candidates(0)
+    assert len(c0) > 1500, len(c0)  # (what makes a depth-1 bucket of 1024 slots overflow)
+    e = orbx.ORBextractor(*params, max_width=w, max_height=h, max_batch=B)
+    d_img = torch.from_numpy(frames).cuda()
+    d_k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+    d_d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    redone = []
+    for it in range(8):
+        e.extract_batch_device(d_img, B, w, h, w, w * h, d_k, d_d, d_n, cap)
+        assert e.debug_last_launch()["octree_instance"] == 0  # (large units: the many-workgroup kernels)
+        redone.append(int(sum(e.debug_selection_units(f)[1].sum() for f in range(B))))
+        n = d_n.cpu().numpy()
+        kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, cap)
+        dd = d_d.cpu().numpy().reshape(B, cap, 32)
+        assert n[0] == len(ko)
+        _same(kk[0, :n[0]], dd[0, :n[0]], ko, do)
+    print("units redone per batch:", redone)
+    assert sum(redone[2:]) == 0, redone
+    e.close()
+
+
+@pytest.mark.parametrize("B", [4, 16])
+def test_redone_and_failed_units_through_both_bookkeepers(orbx, oracle, B):
+    """the per-frame bookkeeping of the selection stage exists once (orbx_device.h) and runs in two places -- in
+    k_sel_compact, and for launches of up to 64 units inside k_describe_patch, which then reads the staging lists itself (B = 4:
+    32 units; B = 16: 128 units, k_sel_compact).  Through both: a unit the many-workgroup kernels REDO in place (bucket depth 0
+    forced: the cluster overfills its bucket) gives the oracle's result and carries the tag bit; a unit that FAILS (the redo switched
+    off) raises ORBX_E_CAPACITY at the batch's wait."""
+    import torch
+    w, h, cap = 1920, 1080, 4000
+    params = (4000, 1.2, 8, 20, 7)
+    rng = np.random.default_rng(78)
+    frames = np.full((B, h, w), 90, np.uint8)
+    for f in range(B):
+        frames[f, 300:640, 500:840] = rng.integers(0, 256, (340, 340), dtype=np.uint8)
+    oe = oracle.Extractor(*params)
+    ora = [oe(frames[f], cap=cap) for f in (0, B - 1)]
+    e = orbx.ORBextractor(*params, max_width=w, max_height=h, max_batch=B)
+    d_img = torch.from_numpy(frames).cuda()
+    d_k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+    d_d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    try:
+        orbx.debug_set("no_split", 1)  # (one launch of B frames: B * 8 units)
+        orbx.debug_set("oct_big_depth", 0)
+        for it in range(2):
+            e.extract_batch_device(d_img, B, w, h, w, w * h, d_k, d_d, d_n, cap)
+            info = e.debug_last_launch()
+            assert info["staged_lists"] == (1 if B * 8 <= 64 else 0) and info["octree_instance"] == 0, info
+            assert e.debug_selection_units(0)[1][0] == 1 and e.debug_selection_units(B - 1)[1][0] == 1  # level 0 was redone
+            n = d_n.cpu().numpy()
+            kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, cap)
+            dd = d_d.cpu().numpy().reshape(B, cap, 32)
+            for f, (_, ko, do) in zip((0, B - 1), ora):
+                assert n[f] == len(ko)
+                _same(kk[f, :n[f]], dd[f, :n[f]], ko, do)
+        orbx.debug_set("oct_big_no_fallback", 1)
+        with pytest.raises(orbx.OrbxError) as ex:
+            e.extract_batch_device(d_img, B, w, h, w, w * h, d_k, d_d, d_n, cap)
+        assert ex.value.code == orbx.E_CAPACITY
+        assert e.debug_selection_units(0)[0][0] < 0
+        orbx.debug_set("oct_big_no_fallback", None)
+        orbx.debug_set("oct_big_depth", None)
+        e.extract_batch_device(d_img, B, w, h, w, w * h, d_k, d_d, d_n, cap)  # the context works on
+        n = d_n.cpu().numpy()
+        assert n[0] == len(ora[0][1])
+    finally:
+        for k in ("no_split", "oct_big_depth", "oct_big_no_fallback"):
+            orbx.debug_set(k, None)
+        e.close()
+
+
 def test_fused_two_stream_batch(orbx, oracle):
     """orbx_extract_match_batch_device (half-batches on two streams, matching fused behind extraction) gives exactly
     the results of the separate calls and of the oracle, incl. pairs that straddle the halves or are out of order."""
