@@ -566,6 +566,15 @@ def main():
                                "hbm_algorithmic_frac_on_lanes": r["lanes"]["algorithmic_frac_of_8TBs"],
                                "mean_keypoints": r["sync"]["mean_keypoints"], "mean_nmatches": r["sync"]["mean_nmatches"],
                                "checked": BC.check(cfg, device=local_rank)}
+                # BASELINE config 4 as written: 256 frames over 8 GPUs = 32 frames + 16 pairs per GPU and step (the
+                # headline's weak scaling keeps 256 frames PER GPU)
+                r4 = BC.measure("c2", steps=200, depth=4, batch=32, modes=("sync", "lanes"), device=local_rank)
+                oc["c4_per_gpu"] = {"workload": "32 frames 640x480 / 1000 features + 16 consecutive-pair matches per call: one GPU's share of "
+                                                "BASELINE config 4's 256-frame batch over 8 GPUs",
+                                    "frames_per_s_synchronous": r4["sync"]["frames_per_s"], "frames_per_s_on_lanes": r4["lanes"]["frames_per_s"],
+                                    "lanes": r4["lanes"]["depth"], "ms_per_batch_synchronous": r4["sync"]["ms_per_batch"],
+                                    "ms_per_batch_on_lanes": 32e3 / r4["lanes"]["frames_per_s"], "stage_ms": r4["sync"]["stage_ms"],
+                                    "checked": BC.check("c2", device=local_rank)}
                 bf, bf_data = BC.measure_bf(steps=20, device=local_rank)
                 oc["bf_2000x2000"] = {"us_per_2000x2000": bf["ms_per_2000x2000"] * 1e3, "descriptor_pairs_per_s": bf["descriptor_pairs_per_s"],
                                       "frac_of_4.9T_popcount_bound": bf["frac_of_4.9T_pairs_per_s"],
