@@ -36,3 +36,24 @@ for t, d in ev:
     cur += d
 tot = sum(hist.values())
 print("kernels running at once (share of time):", {k: round(v / tot, 3) for k, v in sorted(hist.items())})
+# which kernels run together, time-weighted (round 5): a step is short when an issue-bound kernel (k_fast_wave, k_describe_patch) is
+# always among them; time in which only latency-bound kernels run is issue capacity left unused
+ev2 = []
+for r in rows:
+    ev2.append((int(r['Start_Timestamp']), 1, short(r['Kernel_Name']))); ev2.append((int(r['End_Timestamp']), 0, short(r['Kernel_Name'])))
+ev2.sort(key=lambda x: (x[0], x[1]))
+cur2, last2, combo = collections.Counter(), ev2[0][0], collections.Counter()
+for t, d, k in ev2:
+    key = "+".join(sorted(kk.replace("k_", "") for kk, c in cur2.items() for _ in range(c))) or "(none)"
+    combo[key] += t - last2
+    last2 = t
+    if d:
+        cur2[k] += 1
+    else:
+        cur2[k] -= 1
+tot2 = sum(combo.values())
+print("kernels running together (share of time, top 16):")
+for k, v in combo.most_common(16):
+    print("  %-60s %5.1f %%" % (k, 100.0 * v / tot2))
+bound = ("fast_wave", "describe_patch")
+print("time with no issue-bound kernel running: %.1f %%" % (100.0 * sum(v for k, v in combo.items() if not any(b in k for b in bound)) / tot2))
