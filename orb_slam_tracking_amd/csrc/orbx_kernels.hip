@@ -2499,13 +2499,18 @@ __global__ __launch_bounds__(256) void k_match_wide_lists(const int* __restrict_
         ORBX_BCNT4(0, b0[j].x) ORBX_BCNT4(1, b0[j].y) ORBX_BCNT4(2, b0[j].z) ORBX_BCNT4(3, b0[j].w)
         ORBX_BCNT4(4, b1[j].x) ORBX_BCNT4(5, b1[j].y) ORBX_BCNT4(6, b1[j].z) ORBX_BCNT4(7, b1[j].w)
 #undef ORBX_BCNT4
+        // (round 5) one test for the four trains: a random descriptor lies ~128 bits away and dmax is ~56, so a lane finds a
+        // candidate among four trains once in hundreds of steps -- four compares and exec-mask branches per step became one
+        const int dmin = min(min(dd[0], dd[1]), min(dd[2], dd[3]));
+        if (__ballot(valid && dmin < mp.dmax) != 0ull) {  // (wave-uniform)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          if (j0 + j >= cntT) break;  // (uniform)
-          const int dist = dd[j];
-          if (valid && dist < mp.dmax) {  // a farther train can neither be accepted nor fail the ratio test of a nearer one
-            const int slot = atomicAdd(&cnt[lane], 1);
-            if (slot < MW_CP) lists[(size_t)slot * capl + q] = ((uint32_t)dist << 16) | (uint32_t)(eb + j0 + j);
+          for (int j = 0; j < 4; j++) {
+            if (j0 + j >= cntT) break;  // (uniform)
+            const int dist = dd[j];
+            if (valid && dist < mp.dmax) {  // a farther train can neither be accepted nor fail the ratio test of a nearer one
+              const int slot = atomicAdd(&cnt[lane], 1);
+              if (slot < MW_CP) lists[(size_t)slot * capl + q] = ((uint32_t)dist << 16) | (uint32_t)(eb + j0 + j);
+            }
           }
         }
       }
