@@ -122,7 +122,8 @@ struct DescStage {
   int32_t selStride;
   int32_t selOff[ORBX_MAX_LEVELS];
 };
-#define ORBX_DESC_STAGED_MAX_UNITS 64  // units (frames x levels) up to which the descriptor kernel takes the staged lists
+#define ORBX_DESC_STAGED_MAX_UNITS 256  // units (frames x levels) up to which the descriptor kernel takes the staged lists (round 5:
+                                        // 64 -> 256: 32 frames of eight levels per launch; synchronous 32-frame call 132.7 k -> 143.7 k frames/s)
 
 struct OctLaunch {
   OctLevel lev[ORBX_MAX_LEVELS];

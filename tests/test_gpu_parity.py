@@ -596,11 +596,11 @@ def test_dense_cluster_does_not_alternate_redos(orbx, oracle):
     e.close()
 
 
-@pytest.mark.parametrize("B", [4, 16])
+@pytest.mark.parametrize("B", [4, 40])
 def test_redone_and_failed_units_through_both_bookkeepers(orbx, oracle, B):
     """the per-frame bookkeeping of the selection stage exists once (orbx_device.h) and runs in two places -- in
-    k_sel_compact, and for launches of up to 64 units inside k_describe_patch, which then reads the staging lists itself (B = 4:
-    32 units; B = 16: 128 units, k_sel_compact).  Through both: a unit the many-workgroup kernels REDO in place (bucket depth 0
+    k_sel_compact, and for launches of up to 256 units inside k_describe_patch, which then reads the staging lists itself (B = 4:
+    32 units; B = 40: 320 units, k_sel_compact).  Through both: a unit the many-workgroup kernels REDO in place (bucket depth 0
     forced: the cluster overfills its bucket) gives the oracle's result and carries the tag bit; a unit that FAILS (the redo switched
     off) raises ORBX_E_CAPACITY at the batch's wait."""
     import torch
@@ -623,7 +623,7 @@ def test_redone_and_failed_units_through_both_bookkeepers(orbx, oracle, B):
         for it in range(2):
             e.extract_batch_device(d_img, B, w, h, w, w * h, d_k, d_d, d_n, cap)
             info = e.debug_last_launch()
-            assert info["staged_lists"] == (1 if B * 8 <= 64 else 0) and info["octree_instance"] == 0, info
+            assert info["staged_lists"] == (1 if B * 8 <= 256 else 0) and info["octree_instance"] == 0, info
             assert e.debug_selection_units(0)[1][0] == 1 and e.debug_selection_units(B - 1)[1][0] == 1  # level 0 was redone
             n = d_n.cpu().numpy()
             kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, cap)
@@ -1432,8 +1432,8 @@ def test_tiled_pyramid_small_batches(orbx, oracle, params):
         e.extract_batch_device(d_img, B, w, h, stride, stride * h, d_k, d_d, d_n, cap)
         info = e.debug_last_launch()
         assert info["pyramid_banded"] == (2 if B <= 8 else 0), (w, h, B, info)
-        # launches of up to 64 (frame, level) units: k_describe_patch indexes the selection's staging lists itself (no k_sel_compact)
-        assert info["staged_lists"] == (1 if B * nlev <= 64 else 0), (w, h, B, info)
+        # launches of up to 256 (frame, level) units: k_describe_patch indexes the selection's staging lists itself (no k_sel_compact)
+        assert info["staged_lists"] == (1 if B * nlev <= 256 else 0), (w, h, B, info)
         n = d_n.cpu().numpy()
         kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, cap)
         dd = d_d.cpu().numpy().reshape(B, cap, 32)
