@@ -151,7 +151,7 @@ def lib() -> ctypes.CDLL:
     return L
 
 
-KNOBS = ("no_bands", "no_tiles", "tiles_max_frames", "tiles_max_pixels", "pyr_bands", "pyr_strips", "bands_min_frames", "desc_no_staged",
+KNOBS = ("no_bands", "no_tiles", "tiles_max_frames", "tiles_max_pixels", "pyr_bands", "pyr_gmax", "pyr_strips", "bands_min_frames", "desc_no_staged",
          "desc_staged_max", "no_split", "lat_trace", "no_direct_out", "fast_wg", "fast_wg_max_cells", "fast_lds_pad", "fast_debug",
          "desc_lds_pad", "match_no_general", "oct_no_small", "oct_key64", "oct_split_min", "oct_no_big", "oct_big_depth", "oct_big_no_fallback", "octb_no_512", "oct_inst",
          "oct_lds_pad", "multi_force_rccl")

@@ -296,7 +296,9 @@ extern "C" int orbx_diag_pyr_stamps(uint32_t* out, int nWgs) {  // out: nWgs x 4
                     // against 201 of 256) and take three fat bands per frame (3.5 % shared rows instead of 11 % with seven)
 #endif
 #define PYR_R 2   // output rows in flight per thread and step
-template <int DUAL2>
+// GMAX = groups of 4 pixels a thread may own: 2 in general; 1 (round 5) when no level (strip) is wider than PYR_T groups -- every
+// frame up to 2457 pixels wide, and the strips of larger ones -- which keeps one set of column constants and row registers
+template <int DUAL2, int GMAX>
 __global__ __launch_bounds__(PYR_T) void k_pyramid_bands(const uint8_t* __restrict__ img0, long long img0FrameStride,
                                                        uint8_t* __restrict__ pyr, const Geom g,
                                                        const uint4* __restrict__ ptab, const PyrBands pb) {
@@ -313,9 +315,9 @@ __global__ __launch_bounds__(PYR_T) void k_pyramid_bands(const uint8_t* __restri
   PYR_STAMP_RT(36);
   // column constants of this thread for level l
   struct Cols {
-    uint32_t o[2], sel[2][6], cf[2][4];
+    uint32_t o[GMAX], sel[GMAX][6], cf[GMAX][4];
     int G, rpp, rsub, col, gOff;
-    bool lanes, haveG[2];
+    bool lanes, haveG[GMAX];
   };
   auto loadCols = [&](int l, Cols& c) {
     c.gOff = pb.g0[strip][l];
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(PYR_T) void k_pyramid_bands(const uint8_t* __restri
     // i.e. at most PYR_T = 512 thread-columns of two groups: 3840x2160 frames qualify.)
     const int ngt2 = (ng + 1) >> 1;
     const int use1 = ng <= PYR_T ? ng * (PYR_T / ng) : 0, use2 = ngt2 * (PYR_T / ngt2);
-    c.G = use2 > use1 ? 2 : 1;
+    c.G = GMAX == 2 && use2 > use1 ? 2 : 1;
     const int ngt = c.G == 2 ? ngt2 : ng;
     c.rpp = max(PYR_T / ngt, 1);
     c.rsub = tid / ngt;
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(PYR_T) void k_pyramid_bands(const uint8_t* __restri
     c.lanes = c.rsub < c.rpp;
     const uint4* xg = ptab + pb.xoff[l];
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < GMAX; j++) {
       const int gx = c.col * c.G + j;
       c.haveG[j] = c.lanes && j < c.G && gx < pb.g1[strip][l] - c.gOff;
       const uint4* e = xg + (unsigned)(c.haveG[j] ? c.gOff + gx : 0) * 4u;
@@ -375,60 +377,81 @@ __global__ __launch_bounds__(PYR_T) void k_pyramid_bands(const uint8_t* __restri
     // 3 x 12 for single dwords at this pitch).  At the end of a row that reads up to 11 bytes beyond the last pixel: the next
     // row, the next level, the next frame, or the slack the pyramid buffer ends with; only behind the last row of the
     // caller's last frame nothing is known to follow, so frames f >= pb.safeFrom take level 1 with clamped single dwords.
+    // Round 5: a step's two rows are ADJACENT output rows dy, dy + 1.  At the pyramid's scale 1.2 the lower source row of dy is
+    // the upper source row of dy + 1 for five row pairs of six (same byte offset in PyrYRow): that row is loaded once and its
+    // horizontal interpolation (perms, dot2, mask: 14 of a group's 50 instructions) is computed once for both outputs -- three
+    // loads and three interpolations per row pair and group instead of four.  A pair that does not share (every pair at scale 2)
+    // takes the fourth behind one wave-uniform test; values are those of the separate evaluation either way (same source bytes,
+    // same column constants).  (Before: rows dy and dy + rpp, four of each; a timing-only build with a fifth less pyramid work
+    // gave the step +3 %.)
+    static_assert(PYR_R == 2, "the row loop pairs adjacent rows");
     auto rows = [&](auto safeTag) {
     constexpr bool SAFE = decltype(safeTag)::value;
-    for (int dy0 = r0 + C.rsub; dy0 < r1; dy0 += PYR_R * rpp) {  // PYR_R rows per step: their loads are in flight together
-      uint32_t wy[PYR_R][2];
-      bool liveR[PYR_R];
-      PyrU3 ra[PYR_R][2], rb[PYR_R][2];
-#pragma unroll
-      for (int q = 0; q < PYR_R; q++) {
-        const int dy = dy0 + q * rpp;
-        liveR[q] = C.lanes && dy < r1;
-        const uint4 ty = yr[liveR[q] ? dy - r0 : 0];
-        wy[q][0] = ty.z; wy[q][1] = ty.w;
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-          if (j < G) {
-            if (SAFE) {
-              // a dword beyond the row's last one is replaced by the last one and can only supply bytes of weight 0
-              const uint32_t lim = (uint32_t)(S.w - 1) & ~3u, o0 = C.o[j], o1 = min(o0 + 4u, lim), o2 = min(o0 + 8u, lim);
-              ra[q][j].a = *reinterpret_cast<const uint32_t*>(src + (ty.x + o0)); rb[q][j].a = *reinterpret_cast<const uint32_t*>(src + (ty.y + o0));
-              ra[q][j].b = *reinterpret_cast<const uint32_t*>(src + (ty.x + o1)); rb[q][j].b = *reinterpret_cast<const uint32_t*>(src + (ty.y + o1));
-              ra[q][j].c = *reinterpret_cast<const uint32_t*>(src + (ty.x + o2)); rb[q][j].c = *reinterpret_cast<const uint32_t*>(src + (ty.y + o2));
-            } else {
-              ra[q][j] = *reinterpret_cast<const PyrU3*>(src + (ty.x + C.o[j]));
-              rb[q][j] = *reinterpret_cast<const PyrU3*>(src + (ty.y + C.o[j]));
-            }
-          }
+    auto load3 = [&](const uint32_t rowOff, const int j) -> PyrU3 {
+      PyrU3 v;
+      if (SAFE) {
+        // a dword beyond the row's last one is replaced by the last one and can only supply bytes of weight 0
+        const uint32_t lim = (uint32_t)(S.w - 1) & ~3u, o0 = C.o[j], o1 = min(o0 + 4u, lim), o2 = min(o0 + 8u, lim);
+        v.a = *reinterpret_cast<const uint32_t*>(src + (rowOff + o0));
+        v.b = *reinterpret_cast<const uint32_t*>(src + (rowOff + o1));
+        v.c = *reinterpret_cast<const uint32_t*>(src + (rowOff + o2));
+      } else {
+        v = *reinterpret_cast<const PyrU3*>(src + (rowOff + C.o[j]));
       }
+      return v;
+    };
+    // horizontal interpolation of one source row for the group's four pixels: 16 t, low byte masked (see mulHiU24 above)
+    auto hrow = [&](const PyrU3 a, const int j, uint32_t (&t)[4]) {
+      uint32_t p[4];
+      p[0] = __builtin_amdgcn_perm(a.b, a.a, C.sel[j][0]);
+      p[1] = __builtin_amdgcn_perm(a.b, a.a, C.sel[j][1]);
+      p[2] = __builtin_amdgcn_perm(a.b, a.a, C.sel[j][2]);
+      if (DUAL2) p[2] |= __builtin_amdgcn_perm(a.c, a.b, C.sel[j][3]);
+      p[3] = __builtin_amdgcn_perm(a.b, a.a, C.sel[j][4]) | __builtin_amdgcn_perm(a.c, a.b, C.sel[j][5]);
 #pragma unroll
-      for (int q = 0; q < PYR_R; q++) {
-        const int dy = dy0 + q * rpp;
+      for (int i = 0; i < 4; i++) t[i] = dot2u16(p[i], C.cf[j][i], 0u) & ~0xffu;
+    };
+    for (int dy0 = r0 + 2 * C.rsub; dy0 < r1; dy0 += 2 * rpp) {  // two adjacent rows per step: their loads are in flight together
+      const bool live0 = C.lanes && dy0 < r1, live1 = C.lanes && dy0 + 1 < r1;
+      const uint4 ty0 = yr[live0 ? dy0 - r0 : 0], ty1 = yr[live1 ? dy0 + 1 - r0 : 0];
+      const bool shared = ty1.x == ty0.y;                               // the rows' common source row
+      const bool fourth = __ballot(live1 && !shared) != 0ull;           // (wave-uniform) some lane's pair does not share one
+      PyrU3 ra0[GMAX], rb0[GMAX], ra1[GMAX], rb1[GMAX];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-          if (j >= G) continue;
-          const PyrU3 a = ra[q][j], b = rb[q][j];
-          uint32_t p0[4], p1[4];
-          p0[0] = __builtin_amdgcn_perm(a.b, a.a, C.sel[j][0]); p1[0] = __builtin_amdgcn_perm(b.b, b.a, C.sel[j][0]);
-          p0[1] = __builtin_amdgcn_perm(a.b, a.a, C.sel[j][1]); p1[1] = __builtin_amdgcn_perm(b.b, b.a, C.sel[j][1]);
-          p0[2] = __builtin_amdgcn_perm(a.b, a.a, C.sel[j][2]); p1[2] = __builtin_amdgcn_perm(b.b, b.a, C.sel[j][2]);
-          if (DUAL2) {
-            p0[2] |= __builtin_amdgcn_perm(a.c, a.b, C.sel[j][3]); p1[2] |= __builtin_amdgcn_perm(b.c, b.b, C.sel[j][3]);
-          }
-          p0[3] = __builtin_amdgcn_perm(a.b, a.a, C.sel[j][4]) | __builtin_amdgcn_perm(a.c, a.b, C.sel[j][5]);
-          p1[3] = __builtin_amdgcn_perm(b.b, b.a, C.sel[j][4]) | __builtin_amdgcn_perm(b.c, b.b, C.sel[j][5]);
-          uint32_t u[4];
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const uint32_t t0 = dot2u16(p0[i], C.cf[j][i], 0u) & ~0xffu, t1 = dot2u16(p1[i], C.cf[j][i], 0u) & ~0xffu;
-            u[i] = mulHiU24(wy[q][0], t0) + mulHiU24(wy[q][1], t1);
-          }
-          // (u + 2) >> 2 on two 16-bit fields at a time; bytes 0 and 2 of each pair are the pixels
-          const uint32_t s01 = ((u[0] | (u[1] << 16)) + 0x00020002u) >> 2, s23 = ((u[2] | (u[3] << 16)) + 0x00020002u) >> 2;
-          const uint32_t packed = __builtin_amdgcn_perm(s23, s01, 0x06040200u);
-          if (liveR[q] && C.haveG[j]) *reinterpret_cast<uint32_t*>(dst + (unsigned)(dy * dstride + (C.gOff + C.col * G + j) * 4)) = packed;
+      for (int j = 0; j < GMAX; j++)
+        if (j < G) {
+          ra0[j] = load3(ty0.x, j);
+          rb0[j] = load3(ty0.y, j);
+          rb1[j] = load3(ty1.y, j);
+          if (fourth) ra1[j] = load3(ty1.x, j);
         }
+#pragma unroll
+      for (int j = 0; j < GMAX; j++) {
+        if (j >= G) continue;
+        uint32_t ta0[4], tb0[4], ta1[4], tb1[4];
+        hrow(ra0[j], j, ta0);
+        hrow(rb0[j], j, tb0);
+        hrow(rb1[j], j, tb1);
+        if (fourth) {
+          hrow(ra1[j], j, ta1);
+#pragma unroll
+          for (int i = 0; i < 4; i++) ta1[i] = shared ? tb0[i] : ta1[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; i++) ta1[i] = tb0[i];
+        }
+        uint32_t u[4], v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          u[i] = mulHiU24(ty0.z, ta0[i]) + mulHiU24(ty0.w, tb0[i]);
+          v[i] = mulHiU24(ty1.z, ta1[i]) + mulHiU24(ty1.w, tb1[i]);
+        }
+        // (u + 2) >> 2 on two 16-bit fields at a time; bytes 0 and 2 of each pair are the pixels
+        const uint32_t s01 = ((u[0] | (u[1] << 16)) + 0x00020002u) >> 2, s23 = ((u[2] | (u[3] << 16)) + 0x00020002u) >> 2;
+        const uint32_t q01 = ((v[0] | (v[1] << 16)) + 0x00020002u) >> 2, q23 = ((v[2] | (v[3] << 16)) + 0x00020002u) >> 2;
+        const unsigned col = (unsigned)((C.gOff + C.col * G + j) * 4);
+        if (live0 && C.haveG[j]) *reinterpret_cast<uint32_t*>(dst + ((unsigned)(dy0 * dstride) + col)) = __builtin_amdgcn_perm(s23, s01, 0x06040200u);
+        if (live1 && C.haveG[j]) *reinterpret_cast<uint32_t*>(dst + ((unsigned)((dy0 + 1) * dstride) + col)) = __builtin_amdgcn_perm(q23, q01, 0x06040200u);
       }
     }
     };
@@ -3051,12 +3074,28 @@ hipError_t launch_pyramid_bands(hipStream_t st, int nFrames, const uint8_t* img0
   if (nFrames <= 0 || g.nlevels <= 1) return hipSuccess;
   dim3 block(PYR_T, 1, 1), grid(pb.nBands * pb.nStrips, nFrames, 1);
   if (pb.maxRows > 256 || pb.maxRows < 1 || pb.nStrips < 1 || pb.nStrips > ORBX_PYR_STRIPS_MAX) return hipErrorInvalidValue;  // (the host picks the band count accordingly)
-  if (pb.dual2)
-    hipLaunchKernelGGL(k_pyramid_bands<1>, grid, block, 2 * (size_t)pb.maxRows * sizeof(uint4), st, img0, img0FrameStride, pyr, g,
-                       reinterpret_cast<const uint4*>(tab), pb);
-  else
-    hipLaunchKernelGGL(k_pyramid_bands<0>, grid, block, 2 * (size_t)pb.maxRows * sizeof(uint4), st, img0, img0FrameStride, pyr, g,
-                       reinterpret_cast<const uint4*>(tab), pb);
+  // one group per thread when no level's strip is wider than PYR_T groups (GMAX = 1: fewer registers)
+  bool one = true;
+  for (int l = 1; l < g.nlevels; l++)
+    for (int s2 = 0; s2 < pb.nStrips; s2++) one = one && pb.g1[s2][l] - pb.g0[s2][l] <= PYR_T;
+  // ... and when rows of at most 256 groups leave 512 threads at least two rows per pass: with one row of 270 .. 400 groups per
+  // pass (1920x1080: levels 1 .. 3) two groups per thread fill the lanes so much better that they win (config 3: pyramid 0.242
+  // against 0.285 ms per batch; 640x480 and the strips of 3840x2160 the other way round: 425.2 k against 416.8 k frames/s,
+  // 0.206 against 0.243 ms)
+  one = one && g.nlevels > 1 && pb.g1[0][1] - pb.g0[0][1] <= PYR_T / 2;
+  const int gmaxKnob = (int)knob(KNOB_PYR_GMAX, 0);  // diagnostics
+  if (gmaxKnob == 2) one = false;
+  if (gmaxKnob == 1) {
+    one = true;
+    for (int l = 1; l < g.nlevels; l++)
+      for (int s2 = 0; s2 < pb.nStrips; s2++) one = one && pb.g1[s2][l] - pb.g0[s2][l] <= PYR_T;
+  }
+  const size_t lds = 2 * (size_t)pb.maxRows * sizeof(uint4);
+  const uint4* tab4 = reinterpret_cast<const uint4*>(tab);
+  if (pb.dual2 && one) hipLaunchKernelGGL((k_pyramid_bands<1, 1>), grid, block, lds, st, img0, img0FrameStride, pyr, g, tab4, pb);
+  else if (pb.dual2) hipLaunchKernelGGL((k_pyramid_bands<1, 2>), grid, block, lds, st, img0, img0FrameStride, pyr, g, tab4, pb);
+  else if (one) hipLaunchKernelGGL((k_pyramid_bands<0, 1>), grid, block, lds, st, img0, img0FrameStride, pyr, g, tab4, pb);
+  else hipLaunchKernelGGL((k_pyramid_bands<0, 2>), grid, block, lds, st, img0, img0FrameStride, pyr, g, tab4, pb);
   return hipGetLastError();
 }
 

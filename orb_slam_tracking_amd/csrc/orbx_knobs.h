@@ -15,6 +15,7 @@ namespace orbx {
   X(KNOB_TILES_MAX_FRAMES, "tiles_max_frames") /* k_pyramid_tiles up to this many frames per launch (default 8) */               \
   X(KNOB_TILES_MAX_PIXELS, "tiles_max_pixels") /* ... and this many pixels per launch */                                         \
   X(KNOB_PYR_BANDS, "pyr_bands")              /* bands per frame of k_pyramid_bands */                                           \
+  X(KNOB_PYR_GMAX, "pyr_gmax")                /* k_pyramid_bands: 1 = one group of 4 pixels per thread, 2 = up to two */          \
   X(KNOB_PYR_STRIPS, "pyr_strips")            /* column strips per band of k_pyramid_bands */                                    \
   X(KNOB_BANDS_MIN_FRAMES, "bands_min_frames") /* k_pyramid_bands from this many frames per stream */                            \
   X(KNOB_DESC_NO_STAGED, "desc_no_staged")    /* small launches keep k_sel_compact */                                            \
