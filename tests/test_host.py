@@ -268,6 +268,21 @@ def test_bench_gpus_n_launches_its_ranks():
     assert "bench.py needs a GPU" in p.stdout and "launch with torch.distributed.run" not in p.stdout, p.stdout[-2000:]
 
 
+def test_libm_overload_probe():
+    """which libm function the reference's unqualified cos(angle) / pow(factor, float) call is decided by the
+    headers in the translation unit.  tools/pin_opencv/libm_probe.cpp lets the compiler say it (the type of cos(1.0f)); with a real
+    OpenCV it names the orbx_set_libm_variant to use.  Here, on this image's libstdc++: the reference's standard headers + <cmath>
+    give the DOUBLE reading, + <math.h> the FLOAT reading."""
+    import subprocess
+    src = os.path.join(ROOT, "tools", "pin_opencv", "libm_probe.cpp")
+    for flag, want in (("-DORBX_PROBE_CMATH", "ORBX_LIBM_DOUBLE"), ("-DORBX_PROBE_MATH_H", "ORBX_LIBM_FLOAT")):
+        exe = "/tmp/orbx_libm_probe%s" % flag[-6:]
+        p = subprocess.run(["g++", "-std=c++17", "-DORBX_PROBE_NO_OPENCV", flag, src, "-o", exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert p.returncode == 0, p.stdout
+        out = subprocess.run([exe], stdout=subprocess.PIPE, text=True).stdout
+        assert out.strip().splitlines()[-1] == "orbx_set_libm_variant: " + want, out
+
+
 def test_pin_kit_compiles():
     """tools/pin_opencv (the one-command diff of the oracle against a real OpenCV, for whoever has one) at least compiles: its only
     possible check in this image is the compile-check mock of the cv:: declarations it uses (tests/cpp/mock_opencv pins nothing)."""
