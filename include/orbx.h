@@ -101,10 +101,14 @@ int orbx_set_opencv_variant(orbx_ctx* ctx, int gaussian_variant, int gray_varian
  * (Features/ORBextractor.cpp:174) and pow(factor, (float)nlevels) of the constructor (cpp:536).  The file has no `using namespace
  * std` (cpp:69-71 import list / pair / vector only), so which function a call resolves to depends on the headers in the
  * translation unit (DESIGN.md section 2 derives it from the reference's includes):
- *   ORBX_LIBM_DOUBLE (default)  only ::cos(double) / ::pow(double, double) are visible in the global namespace (<cmath> alone):
- *                               the float is promoted, the double result converted back -- (float)cos((double)angle)
- *   ORBX_LIBM_FLOAT             libstdc++'s <math.h> wrapper is in the include chain (`using std::cos;` ...): std::cos(float) =
- *                               cosf, std::pow(float, float) = powf.  cosf / sinf = glibc >= 2.28's algorithm, restated in the
+ *   ORBX_LIBM_DOUBLE            only ::cos(double) / ::pow(double, double) are visible in the global namespace (<cmath> alone):
+ *                               the float is promoted, the double result converted back -- (float)cos((double)angle).  The
+ *                               default of rounds 1-4.
+ *   ORBX_LIBM_FLOAT (default)   libstdc++'s <math.h> wrapper is in the include chain (`using std::cos;` ...): std::cos(float) =
+ *                               cosf, std::pow(float, float) = powf.  The default since round 5: <opencv2/opencv.hpp>
+ *                               (Features/ORBextractor.hpp:24) brings <math.h> in through opencv2/flann/lsh_table.h [from knowledge of
+ *                               OpenCV 3.x / 4.x; tools/pin_opencv/libm_probe.cpp lets the compiler confirm it against a real one],
+ *                               and the ORB-SLAM sources this file descends from say `using namespace std`.  cosf / sinf = glibc >= 2.28's algorithm, restated in the
  *                               kernel operation for operation (it is not correctly rounded: of the 1,135,869,953 f32 angles
  *                               in [0, 360], 1,484,894 give a different (cos, sin) pair than ORBX_LIBM_DOUBLE, and for 96 of
  *                               them a rotated sample point lands on another pixel); powf = the host libm's.
@@ -113,6 +117,7 @@ int orbx_set_opencv_variant(orbx_ctx* ctx, int gaussian_variant, int gray_varian
  * nfeatures) combinations and never for a scale factor with two decimals), the context's buffers are re-planned. */
 #define ORBX_LIBM_DOUBLE 0
 #define ORBX_LIBM_FLOAT 1
+#define ORBX_LIBM_DEFAULT ORBX_LIBM_FLOAT
 int orbx_set_libm_variant(orbx_ctx* ctx, int libm_variant);
 const char* orbx_last_error(const orbx_ctx* ctx);
 

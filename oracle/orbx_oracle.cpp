@@ -434,7 +434,7 @@ float icAngle(const Image& im, float px, float py, const int* umax, int* m10_out
 // cosf / sinf.  The x86-64 multiarch build contracts the polynomials into FMAs on CPUs that have them, the baseline build does
 // not: both forms are compiled here (USE_FMA) and both agree with each other after the rounding to f32 for every angle of the
 // domain (same sweep), so one variant covers both.  The same reading decides pow(float, float) of the constructor (cpp:536).
-int gLibmVariant = 0;
+int gLibmVariant = 1;  // ORBX_LIBM_FLOAT: the default since round 5 (include/orbx.h says why)
 namespace glibc_sincosf {
 struct SinCosT { double sign[4]; double hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3; };
 const SinCosT kTab[2] = {

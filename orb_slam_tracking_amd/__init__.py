@@ -241,11 +241,11 @@ class ORBextractor:
         """The two OpenCV-release dependent constants of the path (include/orbx.h): Gaussian Q8 taps, BGR2GRAY coefficients."""
         self._check(self._L.orbx_set_opencv_variant(self._h, int(gaussian_variant), int(gray_variant)), "orbx_set_opencv_variant")
 
-    LIBM_DOUBLE, LIBM_FLOAT = 0, 1
+    LIBM_DOUBLE, LIBM_FLOAT, LIBM_DEFAULT = 0, 1, 1
 
-    def set_libm_variant(self, libm_variant: int = 0) -> None:
+    def set_libm_variant(self, libm_variant: int = 1) -> None:
         """The libm reading of the reference's unqualified cos / sin / pow on floats (include/orbx.h): 0 = through double,
-        1 = cosf / sinf / powf (glibc >= 2.28's algorithm)."""
+        1 = cosf / sinf / powf (glibc >= 2.28's algorithm; the default)."""
         self._check(self._L.orbx_set_libm_variant(self._h, int(libm_variant)), "orbx_set_libm_variant")
 
     def order_after(self, stream: Optional[int]) -> None:

@@ -90,7 +90,7 @@ struct orbx_ctx {
   std::vector<int> quota;
   int umax[16]{};
   int gaussVariant = 0, grayVariant = 0;  // orbx_set_opencv_variant
-  int libmVariant = 0;                    // orbx_set_libm_variant
+  int libmVariant = ORBX_LIBM_DEFAULT;    // orbx_set_libm_variant
   int selCap = 0;  // sum of the per-level quotas
 
   // geometry of the current frame size

@@ -159,7 +159,10 @@ def set_opencv_variant(gaussian_variant=0, gray_variant=0):
     L.orbo_set_opencv_variant(int(gaussian_variant), int(gray_variant))
 
 
-def set_libm_variant(libm_variant=0):
+LIBM_DEFAULT = 1  # ORBX_LIBM_FLOAT (include/orbx.h)
+
+
+def set_libm_variant(libm_variant=LIBM_DEFAULT):
     """Process-wide: the libm reading of cos / sin (cpp:174) and pow (cpp:536): 0 = through double, 1 = cosf / sinf / powf;
     mirrors the product's orbx_set_libm_variant.  Extractors built afterwards take the constructor's pow from it."""
     L = lib()

@@ -1285,8 +1285,9 @@ def test_sincos_matches_libm(orbx, ext640, oracle):
 
 
 def test_libm_float_variant(orbx, oracle):
-    """orbx_set_libm_variant(ORBX_LIBM_FLOAT): cos / sin of cpp:174 read as glibc's cosf / sinf (restated on the device) and the
-    constructor's pow as powf (cpp:536), against the oracle with the same reading: the (cos, sin) pairs for all multiples of
+    """orbx_set_libm_variant: ORBX_LIBM_FLOAT (the default since round 5) -- cos / sin of cpp:174 read as glibc's cosf / sinf
+    (restated on the device) and the constructor's pow as powf (cpp:536) -- and ORBX_LIBM_DOUBLE, each against the oracle with the
+    same reading: the (cos, sin) pairs for all multiples of
     1/128 degree, 3 million random angles and the known angles at which the two readings put a sample point on different pixels
     (bitwise; tools/sincos_exhaustive.py 1 sweeps every f32 angle); whole extractions; a scale factor whose quotas the reading
     changes (the context re-plans its buffers)."""
@@ -1302,7 +1303,12 @@ def test_libm_float_variant(orbx, oracle):
     e = orbx.ORBextractor(*CANON, max_width=640, max_height=480, max_batch=2)
     e2 = orbx.ORBextractor(500, exotic, 9, 20, 7, max_width=320, max_height=240, max_batch=2)
     try:
+        oracle.set_libm_variant(0)
+        e.set_libm_variant(0)
+        e2.set_libm_variant(0)
         c0, s0 = e.debug_sincos(a)
+        ec0, es0 = oracle.sincos_deg_batch(a)
+        assert np.array_equal(c0.view(np.uint32), ec0.view(np.uint32)) and np.array_equal(s0.view(np.uint32), es0.view(np.uint32))
         oracle.set_libm_variant(1)
         e.set_libm_variant(1)
         c, s = e.debug_sincos(a)
@@ -1335,7 +1341,7 @@ def test_libm_float_variant(orbx, oracle):
         with pytest.raises(Exception):
             e.set_libm_variant(2)
     finally:
-        oracle.set_libm_variant(0)
+        oracle.set_libm_variant(oracle.LIBM_DEFAULT)
         e.close()
         e2.close()
 

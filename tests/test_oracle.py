@@ -547,4 +547,4 @@ def test_libm_variants(oracle):
         assert np.array_equal(q[0][0], q[1][0]) and q[0][0].sum() == 1000
         assert not np.array_equal(q[0][1], q[1][1]) and q[0][1].sum() == q[1][1].sum() == 500
     finally:
-        oracle.set_libm_variant(0)
+        oracle.set_libm_variant(oracle.LIBM_DEFAULT)
