@@ -1110,41 +1110,33 @@ __device__ __forceinline__ void sincosTable(double x, double* sn, double* cs) {
 // rounded, repeated operation for operation in the FMA form of the x86-64 multiarch build.  Valid for 0 <= y < 120 (a keypoint
 // angle in radians is below 6.2832).  The oracle holds the same restatement and sweeps every f32 angle of [0, 360] against the
 // host's libm (tests/test_oracle.py); tests/test_gpu_parity.py::test_sincos_matches_libm compares this one with the oracle.
-__device__ __forceinline__ float sincosfGlibcPoly(double x, double x2, bool neg, bool cosine) {
-  // sinf_poly with __sincosf_table[neg]: the cosine coefficients change sign, the sine coefficients do not
-  if (!cosine) {
-    const double x3 = x * x2, s1 = fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7), x7 = x3 * x2;
-    const double s = fma(x3, -0x1.555545995a603p-3, x);
-    return (float)fma(x7, s1, s);
-  }
-  const double sg = neg ? -1.0 : 1.0;  // (exact: every coefficient of table 1 is the negated coefficient of table 0)
-  const double x4 = x2 * x2, c2 = fma(x2, sg * 0x1.99343027bf8c3p-16, sg * -0x1.6c087e89a359dp-10);
-  const double c1 = fma(x2, sg * -0x1.ffffffd0c621cp-2, sg * 0x1p0), x6 = x4 * x2;
-  const double c = fma(x4, sg * 0x1.55553e1068f19p-5, c1);
-  return (float)fma(x6, c2, c);
-}
+// Branch-free form (the keypoint's angle is one value per wave, but a branch costs the wave its scalar hops either way): every
+// call evaluates the sine polynomial on x * sign and the cosine polynomial on x^2 once and hands them out by the quadrant's parity.
+//   * glibc's first branch (|y| < pi / 4 by its top-12-bit test, i.e. y < 0.75) is the reduction with n = 0: x * (2 / pi) < 0.48
+//     rounds to quadrant 0, fma(-0, hpi, x) == x, sign[0] == 1, table 0 -- the same operations on the same values;
+//   * its shortcut for |y| < 2^-12 (sinf returns y, cosf 1.0f) is what the polynomials round to there: x^3 / 6 is below 2^-26.6 x
+//     and x^2 / 2 below 2^-25, less than half an ulp of the f32 results;
+//   * table 1 holds the negated cosine coefficients, so its cosine polynomial is the exact negative of table 0's.
+// tools/sincos_exhaustive.py 1 compares it with the oracle's literal restatement for EVERY f32 angle in [0, 360].
 __device__ __forceinline__ void sincosfGlibc(float y, float* sn, float* cs) {
-  const uint32_t top12 = (__float_as_uint(y) >> 20) & 0x7ffu;
   const double x = (double)y;
-  if (top12 < 0x3f4u) {             // abstop12(y) < abstop12(pi / 4)
-    if (top12 < 0x398u) {           // abstop12(y) < abstop12(0x1p-12f)
-      *sn = y; *cs = 1.0f;
-      return;
-    }
-    const double x2 = x * x;
-    *sn = sincosfGlibcPoly(x, x2, false, false);
-    *cs = sincosfGlibcPoly(x, x2, false, true);
-    return;
-  }
   // reduce_fast (!TOINT_INTRINSICS): hpi_inv is 2 / pi * 2^24, the quadrant ends up in bits 24..31
   const double r = x * 0x1.45F306DC9C883p+23;
   const int n = ((int)r + 0x800000) >> 24;
   const double xr = fma(-(double)n, 0x1.921FB54442D18p0, x);
-  const double sg = (n & 1) != ((n >> 1) & 1) ? -1.0 : 1.0;  // sign[n & 3] = {1, -1, -1, 1}
-  const bool neg = (n & 2) != 0;
+  const double sg = ((n ^ (n >> 1)) & 1) ? -1.0 : 1.0;  // sign[n & 3] = {1, -1, -1, 1}
   const double xs = xr * sg, x2 = xr * xr;
-  *sn = sincosfGlibcPoly(xs, x2, neg, (n & 1) != 0);
-  *cs = sincosfGlibcPoly(xs, x2, neg, ((n ^ 1) & 1) != 0);
+  // sinf_poly, even n: the sine polynomial (the same coefficients in both tables)
+  const double x3 = xs * x2, s1 = fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7), x7 = x3 * x2;
+  const double S = fma(x7, s1, fma(x3, -0x1.555545995a603p-3, xs));
+  // sinf_poly, odd n: the cosine polynomial of table 0; table 1 (n & 2) negates it
+  const double x4 = x2 * x2, c2 = fma(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);
+  const double c1 = fma(x2, -0x1.ffffffd0c621cp-2, 0x1p0), x6 = x4 * x2;
+  const double C0 = fma(x6, c2, fma(x4, 0x1.55553e1068f19p-5, c1));
+  const float Sf = (float)S, C0f = (float)C0;
+  const float Cf = (n & 2) ? -C0f : C0f;
+  *sn = (n & 1) ? Cf : Sf;   // sinf: sinf_poly(x * s, x * x, p, n)
+  *cs = (n & 1) ? Sf : Cf;   // cosf: sinf_poly(x * s, x * x, p, n ^ 1)
 }
 
 // cv::fastAtan2: plain f32 mul/add/div, no contraction
