@@ -811,6 +811,27 @@ def test_host_async_batches_equal_oracle(orbx, oracle):
     with pytest.raises(orbx.OrbxError):
         e.extract_match_batch_host_async(None, B, 640, 480, 640, 640 * 480, sets[0]["k"], sets[0]["d"], sets[0]["n"], first, first + 1,
                                          (0, 640, 0, 480), sets[0]["m"], sets[0]["nm"], None, 100, 0.9, True, cap)
+    # no pairs at all (extraction only), no stats array; a capacity below the extractor's quota sum and a stride below the width
+    host, fr, w, h, stride, fs, win, pin = cases[0]
+    o = outs(True)
+    none = np.zeros(0, np.int32)
+    e.set_pipeline_depth(2)
+    e.extract_match_batch_host_async(host, B, w, h, stride, fs, o["k"], o["d"], o["n"], none, none, (0, w, 0, h), None, None, None, win, 0.9, True, cap)
+    e.wait()
+    n = o["n"].numpy()
+    kk = o["k"].numpy().view(KP).reshape(B, cap)
+    dd = o["d"].numpy().reshape(B, cap, 32)
+    for f in (0, B - 1):
+        _, ko, do = oe(fr[f])
+        assert n[f] == len(ko)
+        _same(kk[f, :n[f]], dd[f, :n[f]], ko, do)
+    with pytest.raises(orbx.OrbxError) as ex:
+        e.extract_match_batch_host_async(host, B, w, h, stride, fs, o["k"], o["d"], o["n"], none, none, (0, w, 0, h), None, None, None, win, 0.9, True, 500)
+    assert ex.value.code == orbx.E_CAPACITY
+    with pytest.raises(orbx.OrbxError) as ex:
+        e.extract_match_batch_host_async(host, B, w, h, w - 4, fs, o["k"], o["d"], o["n"], none, none, (0, w, 0, h), None, None, None, win, 0.9, True, cap)
+    assert ex.value.code == orbx.E_BADARG
+    e.wait()
     e.close()
 
 
