@@ -64,17 +64,25 @@ def stateful(trials):
         depth = int(rng.choice([0, 0, 2, 3]))   # pipeline lanes for the stream-ordered calls of this context (two sets in flight at most)
         if depth:
             e.set_pipeline_depth(depth)
+        libm = int(rng.integers(0, 2))           # the libm reading of this context (round 5), the oracle set to the same
+        e.set_libm_variant(libm)
+        O.set_libm_variant(libm)
         oe = O.Extractor(*params)
         cap = params[0] + 64
         sets = [dict(k=torch.zeros(MB * cap * 28, dtype=torch.uint8, device="cuda"), d=torch.zeros(MB * cap * 32, dtype=torch.uint8, device="cuda"),
                      n=torch.zeros(MB, dtype=torch.int32, device="cuda"), m=torch.zeros((MB // 2) * cap, dtype=torch.int32, device="cuda"),
                      nm=torch.zeros(MB // 2, dtype=torch.int32, device="cuda"), st=torch.zeros(MB // 2 * 3, dtype=torch.int32, device="cuda"))
                 for _ in range(2)]
+        # the host-frame call (round 5) writes into page-locked host arrays of the same layout
+        hsets = [dict(k=torch.zeros(MB * cap * 28, dtype=torch.uint8).pin_memory(), d=torch.zeros(MB * cap * 32, dtype=torch.uint8).pin_memory(),
+                      n=torch.zeros(MB, dtype=torch.int32).pin_memory(), m=torch.zeros((MB // 2) * cap, dtype=torch.int32).pin_memory(),
+                      nm=torch.zeros(MB // 2, dtype=torch.int32).pin_memory(), st=torch.zeros(MB // 2 * 3, dtype=torch.int32).pin_memory())
+                 for _ in range(2)]
         pend = []  # (set index, frames, w, h, B, first, second, win, ratio, ori)
 
         def verify(item):
-            si, fr, w, h, B, first, second, win, ratio, ori = item
-            o = sets[si]
+            si, fr, w, h, B, first, second, win, ratio, ori = item[:10]
+            o = hsets[si] if len(item) > 10 and item[10] else sets[si]
             n = o["n"].cpu().numpy()
             kk = o["k"].cpu().numpy().view(KP).reshape(-1, cap)
             dd = o["d"].cpu().numpy().reshape(-1, cap, 32)
@@ -112,15 +120,18 @@ def stateful(trials):
             ratio = float(rng.choice([0.9, 0.7]))
             ori = bool(rng.integers(0, 2))
             use_async = bool(rng.integers(0, 2))
+            use_host = bool(rng.integers(0, 4) == 0)  # every fourth call: frames from and results to host memory, stream-ordered
+            if use_host:
+                use_async = True
             si = call & 1
             if len(pend) == 2 or (pend and not use_async) or any(it[0] == si for it in pend):  # check before the set is reused
                 e.wait()
                 for it in pend:
                     ok &= verify(it)
                 pend = []
-            d_img = torch.from_numpy(fr).cuda()
-            o = sets[si]
-            f = e.extract_match_batch_device_async if use_async else e.extract_match_batch_device
+            d_img = torch.from_numpy(fr).pin_memory() if use_host else torch.from_numpy(fr).cuda()
+            o = hsets[si] if use_host else sets[si]
+            f = e.extract_match_batch_host_async if use_host else (e.extract_match_batch_device_async if use_async else e.extract_match_batch_device)
             try:
                 f(d_img, B, w, h, w, w * h, o["k"], o["d"], o["n"], first, second, (0, w, 0, h), o["m"], o["nm"], o["st"], win, ratio, ori, cap)
             except orbx.OrbxError as err:
@@ -128,7 +139,7 @@ def stateful(trials):
                     continue
                 raise
             ncalls += 1
-            item = (si, fr, w, h, B, first, second, win, ratio, ori)
+            item = (si, fr, w, h, B, first, second, win, ratio, ori, use_host)
             if use_async:
                 pend.append(item)
                 item[1].flags.writeable = False
@@ -139,9 +150,10 @@ def stateful(trials):
         e.wait()
         for it in pend:
             ok &= verify(it)
-        print("context %d: params=%r, depth %d, %d calls ->" % (c, params, depth, ncalls), "ok" if ok else "MISMATCH", flush=True)
+        print("context %d: params=%r, depth %d, libm %d, %d calls ->" % (c, params, depth, libm, ncalls), "ok" if ok else "MISMATCH", flush=True)
         bad += not ok
         e.close()
+        O.set_libm_variant(O.LIBM_DEFAULT)
     print("FUZZ %s: %d contexts (stateful), %d mismatching, %.0f s" % ("OK" if bad == 0 else "FAILED", trials, bad, time.time() - t0))
     sys.exit(1 if bad else 0)
 
@@ -183,9 +195,12 @@ for t in range(trials):
     params = (nf, sf, nlev, ini, mn)
     # small launches take k_fast (a workgroup per cell), large ones k_fast_wave; every other trial forces the latter (diagnostic knob)
     orbx.debug_set("fast_wg_max_cells", 0 if t & 1 else None)
-    tag = "trial %d: %dx%d B=%d %s params=%r%s" % (t, w, h, B, kind, params, " wave-per-cell" if t & 1 else "")
+    libm = 0 if t % 3 == 0 else 1  # every third trial with the DOUBLE libm reading (round 5), the oracle set to the same
+    O.set_libm_variant(libm)
+    tag = "trial %d: %dx%d B=%d %s params=%r%s%s" % (t, w, h, B, kind, params, " wave-per-cell" if t & 1 else "", " libm-double" if libm == 0 else "")
     try:
         e = orbx.ORBextractor(*params, max_width=w, max_height=h, max_batch=B)
+        e.set_libm_variant(libm)
     except orbx.OrbxError as err:
         if err.code in (orbx.E_TOOSMALL, orbx.E_BADARG):
             skipped += 1
