@@ -1465,6 +1465,22 @@ int extractCore(orbx_ctx* ctx, int B, const uint8_t* dImg0, int w, int h, int st
 }  // namespace
 
 // =================================================================================================
+// the libm reading of a context (orbx_set_libm_variant; a new lane takes its parent's): the descriptor's cos / sin is a kernel
+// argument; the constructor's pow (cpp:536) feeds the per-level quotas -- recomputed, and in the rare case that they change (never
+// for a two-decimal scale factor) the buffers sized from them are re-planned
+namespace {
+int applyLibmVariant(orbx_ctx* c, int libm_variant) {
+  if (c->libmVariant == libm_variant) return ORBX_OK;
+  const std::vector<int> oldQuota = c->quota;
+  c->libmVariant = libm_variant;
+  computeTables(c);
+  if (c->quota == oldQuota) return ORBX_OK;
+  c->curW = c->curH = 0;
+  c->curStride0 = -1;
+  return growTo(c, c->maxW, c->maxH, c->maxB);
+}
+}  // namespace
+
 // C ABI
 // =================================================================================================
 extern "C" {
@@ -1566,21 +1582,9 @@ int orbx_set_libm_variant(orbx_ctx* ctx, int libm_variant) {
   if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
   const int w = waitAll(ctx);  // batches in flight keep the reading they were issued with
   if (w != ORBX_OK) return w;
-  if (libm_variant == ctx->libmVariant) return ORBX_OK;
-  // the descriptor's cos / sin is a kernel argument; the constructor's pow (cpp:536) feeds the per-level quotas: recomputed, and in
-  // the rare case that they change (never for a two-decimal scale factor) the buffers sized from them are re-planned
-  auto apply = [&](orbx_ctx* c) -> int {
-    const std::vector<int> oldQuota = c->quota;
-    c->libmVariant = libm_variant;
-    computeTables(c);
-    if (c->quota == oldQuota) return ORBX_OK;
-    c->curW = c->curH = 0;
-    c->curStride0 = -1;
-    return growTo(c, c->maxW, c->maxH, c->maxB);
-  };
-  int r = apply(ctx);
+  int r = applyLibmVariant(ctx, libm_variant);
   for (orbx_ctx* c : ctx->lanes) {
-    const int rl = apply(c);
+    const int rl = applyLibmVariant(c, libm_variant);
     if (r == ORBX_OK) r = rl;
   }
   return r;
@@ -2104,9 +2108,12 @@ int orbx_set_pipeline_depth(orbx_ctx* ctx, int depth) {
     c->eventOrdered = ctx->eventOrdered;
     c->gaussVariant = ctx->gaussVariant;
     c->grayVariant = ctx->grayVariant;
-    c->libmVariant = ctx->libmVariant;
     c->profMask = ctx->profMask;
     ctx->lanes.push_back(c);
+    {  // (the lane was created with the default reading: its quotas follow the parent's)
+      const int rl = applyLibmVariant(c, ctx->libmVariant);
+      if (rl != ORBX_OK) { ctx->err = c->err; return rl; }
+    }
   }
   return ORBX_OK;
 }

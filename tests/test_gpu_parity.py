@@ -1357,8 +1357,32 @@ def test_libm_float_variant(orbx, oracle):
         e2.set_libm_variant(0)
         assert np.array_equal(np.array(e2.GetNumFeaturesPerLevel()), q0)
         r, k, d = e2(fr)
-        orr, ok, od = oracle.Extractor(500, exotic, 9, 20, 7)(fr)
+        oe0 = oracle.Extractor(500, exotic, 9, 20, 7)
+        orr, ok, od = oe0(fr)
         _same(k, d, ok, od)
+        # lanes created AFTER the switch take the parent's reading (their own constructor ran with the default one): a stream-ordered
+        # batch on two lanes with the DOUBLE quotas
+        import torch
+        e2.set_pipeline_depth(2)
+        B2, cap2 = 2, 500
+        fr2 = synth.synth_frames(B2, 320, 240, 41)
+        d_img = torch.from_numpy(fr2).cuda()
+        outs2 = [dict(k=torch.zeros(B2 * cap2 * 28, dtype=torch.uint8, device="cuda"), d=torch.zeros(B2 * cap2 * 32, dtype=torch.uint8, device="cuda"),
+                      n=torch.zeros(B2, dtype=torch.int32, device="cuda"), m=torch.zeros(cap2, dtype=torch.int32, device="cuda"),
+                      nm=torch.zeros(1, dtype=torch.int32, device="cuda")) for _ in range(2)]
+        for o in outs2:
+            e2.extract_match_batch_device_async(d_img, B2, 320, 240, 320, 320 * 240, o["k"], o["d"], o["n"], np.array([0], np.int32), np.array([1], np.int32),
+                                                (0, 320, 0, 240), o["m"], o["nm"], None, 100, 0.9, True, cap2)
+        e2.wait()
+        for o in outs2:
+            n = o["n"].cpu().numpy()
+            kk = o["k"].cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B2, cap2)
+            dd = o["d"].cpu().numpy().reshape(B2, cap2, 32)
+            for f in range(B2):
+                _, ko, do = oe0(fr2[f])
+                assert n[f] == len(ko)
+                _same(kk[f, :n[f]], dd[f, :n[f]], ko, do)
+        e2.set_pipeline_depth(0)
         with pytest.raises(Exception):
             e.set_libm_variant(2)
     finally:
