@@ -1108,6 +1108,14 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
     int S = 1;
     if (n * K <= 128)
       while (S < ORBX_PYR_STRIPS_MAX && n * K * S < 384) S *= 2;
+    // rows of 512 groups or more (frames wider than 2457 pixels): strips of 100 .. 200 groups take the one-group-per-thread instance
+    // (four workgroups per CU); 768 workgroups for up to four frames, 512 for more (3840x2160 with the round's final kernel, bands x
+    // strips: four-frame halves 32 x 4 0.203 ms, 16 x 8 0.194, 24 x 8 0.180; eight frames on a lane 32 x 1 16.5 k frames/s,
+    // 16 x 4 17.3 k, 32 x 2 17.2 k; tools/exp_pyr_strips2.sh)
+    if ((g.L[1].w + 3) / 4 >= 512 && n * K <= 256 && bandsEnv <= 0) {
+      S = n <= 4 ? 8 : 4;
+      K = std::min(ORBX_PYR_BANDS_MAX, std::max((n <= 4 ? 768 : 512) / (n * S), std::min(rowBands, 16)));
+    }
     if (stripsEnv > 0) S = stripsEnv;
     pb = computePyrBands(ctx, K, S);
     while (pb.maxRows > 256 && K < ORBX_PYR_BANDS_MAX) pb = computePyrBands(ctx, K = std::min(2 * K, ORBX_PYR_BANDS_MAX), S);

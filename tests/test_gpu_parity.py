@@ -1501,7 +1501,7 @@ def test_banded_pyramid_column_strips(orbx, oracle):
     """k_pyramid_bands with column strips (round 5: few large frames; a workgroup = a row band x a column strip, each strip with the
     groups its share of the next level reads): every pyramid level of every frame byte for byte against the oracle, for 2 .. 8
     strips forced through the diagnostic knobs on frame sizes whose levels end in partial groups, at two scale factors; then the
-    library's own choice for the four-frame halves of a 3840x2160 batch (32 bands x 4 strips), whole extraction against the oracle."""
+    library's own choice for the four-frame halves of a 3840x2160 batch (24 bands x 8 strips), whole extraction against the oracle."""
     import torch
     from orb_slam_tracking_amd import synth
     try:
@@ -1546,7 +1546,7 @@ def test_banded_pyramid_column_strips(orbx, oracle):
     d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
     e.extract_batch_device(d_img, B, w, h, w, w * h, d_k, d_d, d_n, cap)  # synchronous: two halves of four frames
     info = e.debug_last_launch()
-    assert info["pyramid_banded"] == 1 and info["pyramid_bands"] == 32 * 4 and info["split"] == 1 and info["frames_per_launch"] == 4, info
+    assert info["pyramid_banded"] == 1 and info["pyramid_bands"] == 24 * 8 and info["split"] == 1 and info["frames_per_launch"] == 4, info
     n = d_n.cpu().numpy()
     kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, cap)
     dd = d_d.cpu().numpy().reshape(B, cap, 32)
@@ -1561,8 +1561,8 @@ def test_banded_pyramid_column_strips(orbx, oracle):
 
 def test_banded_pyramid_wide_levels(orbx, oracle):
     """k_pyramid_bands on 3840x2160 frames (BASELINE config 5's size; levels 1 .. 7 up to 3200 pixels wide: 400 thread-columns of two
-    4-pixel groups, one row per pass): eight frames on a lane take it in 32 bands (the four-frame halves of a synchronous call take
-    32 bands x 4 column strips: test_banded_pyramid_column_strips); the extraction results (keypoints of all eight levels, descriptors) equal the oracle."""
+    4-pixel groups, one row per pass): eight frames on a lane take it in 16 bands x 4 column strips (the four-frame halves of a
+    synchronous call in 24 x 8: test_banded_pyramid_column_strips); the extraction results (keypoints of all eight levels, descriptors) equal the oracle."""
     import torch
     from orb_slam_tracking_amd import synth
     w, h, B, cap = 3840, 2160, 8, 8000
