@@ -1108,13 +1108,15 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
     int S = 1;
     if (n * K <= 128)
       while (S < ORBX_PYR_STRIPS_MAX && n * K * S < 384) S *= 2;
-    // rows of 512 groups or more (frames wider than 2457 pixels): strips of 100 .. 200 groups take the one-group-per-thread instance
-    // (four workgroups per CU); 768 workgroups for up to four frames, 512 for more (3840x2160 with the round's final kernel, bands x
-    // strips: four-frame halves 32 x 4 0.203 ms, 16 x 8 0.194, 24 x 8 0.180; eight frames on a lane 32 x 1 16.5 k frames/s,
-    // 16 x 4 17.3 k, 32 x 2 17.2 k; tools/exp_pyr_strips2.sh)
-    if ((g.L[1].w + 3) / 4 >= 512 && n * K <= 256 && bandsEnv <= 0) {
-      S = n <= 4 ? 8 : 4;
-      K = std::min(ORBX_PYR_BANDS_MAX, std::max((n <= 4 ? 768 : 512) / (n * S), std::min(rowBands, 16)));
+    // rows of more than 256 groups (frames wider than 1228 pixels): strips of 100 .. 200 groups take the one-group-per-thread
+    // instance (56 VGPRs, four workgroups per CU), 768 workgroups for up to four frames, 512 or more otherwise.  With the round's
+    // final kernel, bands x strips (tools/exp_pyr_strips2.sh): 3840x2160 four-frame halves 32 x 4 0.203 ms, 16 x 8 0.194, 24 x 8
+    // 0.180; eight frames on a lane 32 x 1 16.5 k frames/s, 16 x 4 17.3 k; 1920x1080 sixteen-frame halves 16 x 1 0.244 ms / 46.3 k
+    // frames/s, 16 x 2 0.200 / 47.7 k, 8 x 4 0.195 / 48.4 k
+    const int ng1 = (g.L[1].w + 3) / 4;
+    if (ng1 > 256 && bandsEnv <= 0) {
+      S = ng1 > 512 && n <= 4 ? 8 : 4;
+      K = std::min(ORBX_PYR_BANDS_MAX, std::max((n <= 4 ? 768 : 512) / (n * S), 8));
     }
     if (stripsEnv > 0) S = stripsEnv;
     pb = computePyrBands(ctx, K, S);
