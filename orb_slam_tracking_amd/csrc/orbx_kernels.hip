@@ -720,6 +720,9 @@ __global__ __launch_bounds__(FAST_T) void k_fast(const uint8_t* __restrict__ img
 #ifndef FW_CPW
 #define FW_CPW 1      // consecutive cells per wave (measured per 256 frames: 1: 0.275 ms, 2: 0.288, 4: 0.316, 8: 0.361: the tail grows)
 #endif
+#ifndef ORBX_FAST_FLATSKIP
+#define ORBX_FAST_FLATSKIP 1  // 0 = comparison build: every cell without a survivor is swept again at minThFAST (tools/bench_real_images.py)
+#endif
 #ifndef FW_XK
 #define FW_XK 16      // groups of FW_CPW cells per run of the XCD-aware order (8 .. 64 measured equal)
 #endif
@@ -895,6 +898,14 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
     const int th = pass == 0 ? g.iniTh : g.minTh;
     const uint32_t th2 = (uint32_t)th * 0x00010001u;
     int head = 0, nList = 0, nCorn = 0;  // wave-uniform (SGPRs)
+    // A cell without a survivor at iniThFAST is swept again at minThFAST (cpp:1117-1123) -- on real images that is every second
+    // cell, and in a flat region the second sweep lists nothing either.  While the first sweep has not listed a pixel yet (`flat`,
+    // wave-uniform), it also keeps the minimum of its two test values e = (v + th) - max side and (min side + th) - v: a pixel
+    // passes the quick reject at minThFAST iff e < iniTh - minTh, so a cell whose sweep ends `flat` with every minimum at or above
+    // that difference could not list a single pixel at minThFAST and is not swept again.  Pixels beyond a row's end and idle lanes
+    // are not masked out of the minimum: a false "some pixel passes" only costs the second sweep, which then decides as before.
+    bool flat = pass == 0 && ORBX_FAST_FLATSKIP;
+    short2v looseMin = {0x7fff, 0x7fff};
     // evaluates the `cnt` oldest ring entries: exact strength; corners (s > th) enter the strength map and the corner list
     auto flush = [&](const int cnt) {
       __builtin_amdgcn_wave_barrier();
@@ -927,6 +938,7 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
         // v_cndmask on the vector port, which is the port this kernel is bound by)
         const uint32_t rlo = t32[wA + rOff], rhi = t32[wA + rOff + 1];
         uint32_t fl[2];
+        short2v em[2];
 #pragma unroll
         for (int hp = 0; hp < 2; hp++) {  // pixels (0, 1) and (2, 3) of the quad as u16 pairs
           const uint32_t V = __builtin_amdgcn_perm(c1, c0, hp ? selC1 : selC0);
@@ -941,6 +953,11 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
           const short2v e1 = __builtin_bit_cast(short2v, hi) - __builtin_bit_cast(short2v, mx);                      // < 0: mx > hi
           const short2v e2 = __builtin_bit_cast(short2v, mn) + __builtin_bit_cast(short2v, th2) - __builtin_bit_cast(short2v, vV);  // < 0: mn < lo
           fl[hp] = (__builtin_bit_cast(uint32_t, e1) | __builtin_bit_cast(uint32_t, e2)) & 0x80008000u;
+          em[hp] = __builtin_elementwise_min(e1, e2);
+        }
+        if (flat) {  // (uniform; the empty asm keeps it a branch -- as a select it would cost every step of every cell five instructions)
+          asm volatile("" ::: "memory");
+          looseMin = __builtin_elementwise_min(looseMin, __builtin_elementwise_min(em[0], em[1]));
         }
         // the quad's four verdicts as bits 0..3, cleared for pixels beyond the row's end and for idle lanes
         const int nv = live ? min(iw - 4 * qc, 4) : 0;
@@ -950,6 +967,7 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
         const uint32_t bits = (fx | (fx >> 15)) & ((1u << nv) - 1u);
         const int offP = offA + sh;  // tile offset of the quad's first pixel
         if (__ballot(bits != 0u) != 0ull) {  // (wave-uniform) a step without any survivor appends nothing
+        flat = false;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const bool cj = (bits >> j) & 1u;
@@ -1010,6 +1028,10 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
     FW_STAMP(3);
     // cpp:1109-1123: the cell is retried at minThFAST only if it yielded nothing at iniThFAST
     if (nOut > 0 || pass == 1 || g.minTh >= g.iniTh) break;
+    {  // no pixel was listed and none passes the quick reject at minThFAST either
+      const short2v dth = {(short)(g.iniTh - g.minTh), (short)(g.iniTh - g.minTh)};
+      if (flat && __ballot((__builtin_bit_cast(uint32_t, looseMin - dth) & 0x80008000u) != 0u) == 0ull) break;
+    }
   }
   if (lane == 0) *myCount = min(nOut, segCap);  // nOut <= segCap: NMS survivors are never 8-neighbours
   __builtin_amdgcn_wave_barrier();  // the next cell's staging stores come after this cell's last LDS reads

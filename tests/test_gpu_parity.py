@@ -177,6 +177,42 @@ def test_odd_sizes_and_fallback_cells(orbx, oracle):
         e.close()
 
 
+def test_fast_retry_threshold_boundaries(orbx, oracle):
+    """k_fast_wave sweeps a cell again at minThFAST only if a pixel can pass the quick reject there: patches whose contrast sits
+    exactly at, one below and one above each threshold (a bright / dark 3 x 3 block differs from the ground by d: d > th passes),
+    noise of every amplitude around minThFAST, flat ground, and all of it beside strong corners -- candidates per level and the
+    final result against the oracle, for two threshold pairs and through both FAST kernels."""
+    rng = np.random.default_rng(77)
+    w, h = 640, 480
+    for (ini, mn) in ((20, 7), (12, 3), (9, 8)):
+        img = np.full((h, w), 100, np.uint8)
+        tile = 40
+        amps = [0, mn - 1, mn, mn + 1, (ini + mn) // 2, ini - 1, ini, ini + 1, 60]
+        for ty in range(h // tile):
+            for tx in range(w // tile):
+                y0, x0 = ty * tile, tx * tile
+                kind = (ty * (w // tile) + tx) % 27
+                a = amps[kind % 9]
+                if kind < 9:  # isolated blocks of contrast +-a
+                    for _ in range(3):
+                        y, x = y0 + int(rng.integers(4, tile - 8)), x0 + int(rng.integers(4, tile - 8))
+                        img[y:y + 3, x:x + 3] = 100 + (a if rng.integers(0, 2) else -a)
+                elif kind < 18:  # uniform noise of amplitude a / 2 (largest difference a)
+                    lo = a // 2
+                    img[y0:y0 + tile, x0:x0 + tile] = 100 - lo + rng.integers(0, a + 1, (tile, tile))
+                else:  # a single pixel of contrast a (a ring of 16 darker pixels around it)
+                    img[y0 + tile // 2, x0 + tile // 2] = 100 + a
+        e = orbx.ORBextractor(600, 1.2, 5, ini, mn, max_width=w, max_height=h, max_batch=1)
+        oe = oracle.Extractor(600, 1.2, 5, ini, mn)
+        r, k, d = e(img)
+        ro, ko, do = oe(img)
+        assert r == ro
+        _same(k, d, ko, do)
+        for l in range(5):
+            assert np.array_equal(e.debug_candidates(0, l), oe.level_candidates(l)), (ini, mn, l)
+        e.close()
+
+
 def test_other_pyramid_parameters(orbx, oracle, images):
     for p in ((1250, 1.2, 8, 20, 7), (300, 1.5, 4, 30, 10), (700, 1.1, 10, 12, 12), (200, 1.2, 1, 20, 7)):
         e = orbx.ORBextractor(*p, max_width=640, max_height=480, max_batch=1)
