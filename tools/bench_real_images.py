@@ -5,7 +5,8 @@ that the cells differ), 128 consecutive-pair matches, four pipeline lanes, input
 synthetic scenes lack: large flat or faintly textured regions, where every second FAST cell finds nothing at iniThFAST and is
 swept again at minThFAST (k_fast_wave's flat-cell rule; docs/history.md, round 5).  Frames 0, 1, 101 and 255 of the last batch
 are compared with the CPU oracle.
-usage: bench_real_images.py [steps] [regions]      (ORBX_LIB selects the library build)"""
+usage: bench_real_images.py [steps] [regions] [lanes] [synthetic]     (ORBX_LIB selects the library build; lanes = 1 for kernel
+profiles: nothing overlaps; a fourth argument takes bench.py's synthetic input sets instead, for a comparison under one harness)"""
 import os
 import sys
 import time
@@ -19,7 +20,8 @@ import orb_slam_tracking_amd as orbx  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 regions = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-W, H, B, cap, depth = 640, 480, 256, 1000, 4
+W, H, B, cap = 640, 480, 256, 1000
+depth = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 z = np.load(os.path.join(ROOT, "tests", "golden", "images.npz"))
 src = [z["dbow%d" % i] for i in range(4)]
 sets = []
@@ -30,6 +32,9 @@ for s in range(4):
         k = i // 2
         fr[i] = np.roll(src[(k + s) % 4], ((k * 5 + s * 11) % 48 + (i & 1) * 2, (k * 7 + s * 13) % 64 + (i & 1) * 3), axis=(0, 1))
     sets.append(fr)
+if len(sys.argv) > 4:
+    from orb_slam_tracking_amd import synth
+    sets = synth.bench_input_sets(B, W, H, 1000, 4)
 dev = torch.device("cuda", 0)
 d_imgs = [torch.from_numpy(s).to(dev) for s in sets]
 outs = [dict(k=torch.zeros(B * cap * 28, dtype=torch.uint8, device=dev), d=torch.zeros(B * cap * 32, dtype=torch.uint8, device=dev),
@@ -81,6 +86,6 @@ try:
             and np.array_equal(ds[f, :n[f]], do)
 except ImportError:
     ok = None
-print("real images (DBoW2 demo, shifted): %d frames/s median of %s, mean keypoints %.1f, checked %s, lib %s" %
+print(("synthetic scenes" if len(sys.argv) > 4 else "real images (DBoW2 demo, shifted)") + ": %d frames/s median of %s, mean keypoints %.1f, checked %s, lib %s" %
       (round(float(np.median(vals))), [round(v) for v in vals], float(n.mean()), ok, os.path.basename(orbx.LIB_PATH) if hasattr(orbx, "LIB_PATH") else os.environ.get("ORBX_LIB", "liborbx.so")))
 sys.exit(0 if ok in (True, None) else 1)
