@@ -581,7 +581,8 @@ def main():
                 bf, bf_data = BC.measure_bf(steps=20, device=local_rank)
                 oc["bf_2000x2000"] = {"us_per_2000x2000": bf["ms_per_2000x2000"] * 1e3, "descriptor_pairs_per_s": bf["descriptor_pairs_per_s"],
                                       "frac_of_4.9T_popcount_bound": bf["frac_of_4.9T_pairs_per_s"],
-                                      "frac_of_3.3T_bcnt_issue_bound": bf["frac_of_3.3T_pairs_per_s"], "sets_per_call": bf["sets_per_call"],
+                                      "frac_of_3.3T_bcnt_issue_bound": bf["frac_of_3.3T_pairs_per_s"],
+                                      "frac_of_9.8T_mfma_i8_bound": bf["frac_of_9.8T_mfma_i8_pairs_per_s"], "sets_per_call": bf["sets_per_call"],
                                       "nmatches": bf["nmatches"], "checked": BC.check_bf(bf_data)}
                 out["other_configs"] = oc
                 if not all(v["checked"] for v in oc.values()):

@@ -63,6 +63,26 @@ def lib_path() -> str:
 _LIB = None
 
 
+def _one_hip_runtime() -> None:
+    """One HIP runtime per process.  liborbx.so needs `libamdhip64.so.7`; PyTorch-ROCm ships its own copy of that library and loads
+    it by path.  If torch is imported first, liborbx resolves to torch's copy (same SONAME) and both share devices, streams and
+    memory.  The other order used to give the process two runtimes -- the second one finds no device (`orbx_create` ->
+    ORBX_E_HIP).  So when torch is installed but not yet imported, its copy is loaded here, before liborbx, without importing torch."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+    except Exception:  # no torch, or an unusual layout: liborbx takes the system's runtime
+        pass
+
+
 def lib() -> ctypes.CDLL:
     """Loads liborbx.so (built in-tree by ``__graft_entry__.build()`` / ``make -C orb_slam_tracking_amd/csrc``)."""
     global _LIB
@@ -71,6 +91,7 @@ def lib() -> ctypes.CDLL:
     path = lib_path()
     if not os.path.exists(path):
         raise OrbxError(E_HIP, "liborbx.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+    _one_hip_runtime()
     L = ctypes.CDLL(path)
     vp, i32, f32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
     L.orbx_create.argtypes = [ctypes.POINTER(_Params), i32, i32, i32, i32, vp, ctypes.POINTER(vp)]
@@ -153,7 +174,7 @@ def lib() -> ctypes.CDLL:
 
 KNOBS = ("no_bands", "no_tiles", "tiles_max_frames", "tiles_max_pixels", "pyr_bands", "pyr_gmax", "pyr_strips", "bands_min_frames", "desc_no_staged",
          "desc_staged_max", "no_split", "lat_trace", "no_direct_out", "fast_wg", "fast_wg_max_cells", "fast_lds_pad", "fast_debug",
-         "desc_lds_pad", "match_no_general", "oct_no_small", "oct_key64", "oct_split_min", "oct_no_big", "oct_big_depth", "oct_big_no_fallback", "octb_no_512", "oct_inst",
+         "desc_lds_pad", "match_no_general", "match_no_mfma", "oct_no_small", "oct_key64", "oct_split_min", "oct_no_big", "oct_big_depth", "oct_big_no_fallback", "octb_no_512", "oct_inst",
          "oct_lds_pad", "multi_force_rccl")
 KNOB_UNSET = -(1 << 63)
 

@@ -1639,8 +1639,25 @@ struct MatchParams {
   int noGeneral;  // diagnostics: leave the pairs the parallel paths cannot take at MATCH_PENDING
   int pair0;  // first pair of this launch
   int dmax;   // the wide path lists only candidates with a smaller distance (launch_match)
+  int noMfma; // diagnostics: no k_match_bf_mfma -- the brute-force case stays on the vector ALU (k_match_wide_lists, xor / bcnt)
   orbx_bounds b;
 };
+
+// 16 descriptor bits (the low half of w) as 16 signed bytes, +1 for a clear bit and -1 for a set one: the operand form of
+// v_mfma_i32_32x32x32_i8 in which the dot product of two 256-bit descriptors is 256 - 2 x their Hamming distance.
+// nibble * 0x00204081 has bit j of the nibble at bit 8 j (its other copies are masked off); the 0 / 1 bytes then select byte 0
+// (0x01) or byte 1 (0xff) of a constant through v_perm_b32: four instructions per four bytes.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ v4i_t pm1Bytes16(const uint32_t w) {
+  v4i_t r;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t n = (w >> (4 * j)) & 0xfu;
+    r[j] = (int)__builtin_amdgcn_perm(0u, 0x0000ff01u, (n * 0x00204081u) & 0x01010101u);
+  }
+  return r;
+}
 
 __device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const uint32_t* __restrict__ b) {
   const uint4 b0 = reinterpret_cast<const uint4*>(b)[0], b1 = reinterpret_cast<const uint4*>(b)[1];
@@ -1762,6 +1779,7 @@ __device__ void matchWidePrep(const int pair, const int* __restrict__ pairFirst,
     S[2] = (sBaseQ > capl || sBaseT > capl || n2 > 0xfffff) ? 1 : 0;
     S[3] = 0;
     S[8] = byCol ? 1 : 0;
+    S[9] = 0; S[10] = 0;  // k_match_bf_mfma's mask of the 64-query blocks it has listed
   }
   if (!byCol) return;  // (uniform)
   // ---- counting sort by grid column: exclusive starts (one wave), then every staged record / query takes the next free slot of
@@ -2409,6 +2427,7 @@ __global__ __launch_bounds__(256) void k_match_wide_lists(const int* __restrict_
   const int nQ = S[0], nT = S[1];
   const int q0 = blockIdx.x * 64;
   if (q0 >= nQ) return;
+  if ((S[9 + (blockIdx.x >> 5)] >> (blockIdx.x & 31)) & 1) return;  // these 64 queries were listed by k_match_bf_mfma
   const uint4* trec = reinterpret_cast<const uint4*>(S + MW_HDR);
   const int* qIdx = S + MW_HDR + 4 * capl;
   int* W = scratchW + (long long)pair * scratchStride;        // write side: header [3], counts, lists
@@ -2570,6 +2589,203 @@ __global__ __launch_bounds__(256) void k_match_wide_lists(const int* __restrict_
     if (c > MW_CP) atomicOr(&W[3], 1);
     cntOut[q] = min(c, MW_CP) | (anyIn[t] << 16);
   }
+}
+
+// -------------------------------------------------------------------------------------------------
+// k_match_bf_mfma: the BRUTE-FORCE case of k_match_wide_lists on the matrix cores (round 5).  When the window of every query of a
+// block covers every train (BASELINE config 5's 2000 x 2000 match, config 3's all-pairs match), the work is all pairs of
+// 256-bit Hamming distances and one compare -- a dense contraction over the bits: with the bits as +-1 bytes (pm1Bytes16) the
+// dot product of two descriptors is 256 - 2 x distance, so "distance < dmax" is "accumulator > 256 - 2 dmax", one threshold.
+//   * workgroup = 256 queries, wave = 64 of them (two 32-row fragments x 8 k-steps = 64 registers, built once);
+//   * the trains go by in tiles of 32: thread (train t >> 3, dword t & 7) loads one dword of a train's descriptor (the record two
+//     tiles ahead, the dword one tile ahead) and expands it into the tile's LDS image (two 16-byte stores), laid out so that a
+//     wave reads the B fragment of k-step c as 64 consecutive 16-byte pieces; two images, one LDS-only barrier per tile;
+//   * per tile and wave 16 v_mfma_i32_32x32x32_i8 (64 x 32 distances), then the maxima of four consecutive query rows, their
+//     maximum and one compare;
+//   * a candidate -- about one per wave and tile in the synthetic sets, one in thousands of pairs -- is appended from the lane that
+//     holds its accumulator (column = train, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) to the lists k_match_wide_lists fills
+//     (slots through the queries' counters in LDS); only a group of four rows with a hit looks at its accumulators again;
+//   * both operands take their k order from the same function of (lane >> 5, byte), so the instruction's own k map is irrelevant.
+// The vector form costs 16 xor / bcnt per 64 pairs (1.1 cycles of a SIMD per pair), the matrix form 0.25 (16 MFMAs of 32 cycles
+// per 2048 pairs).  Measured per 64 sets of 2000 x 2000 (tools/exp_bf_parts.sh: timing-only builds without one part): the MFMAs
+// with their LDS reads and the barrier alone 31.5 us -- the int8 rate -- with the reduction 55, with the staging 65, with the
+// appends 100, against 160 for the vector form: the parts ADD, because the two workgroups of a CU fall into step (both in their
+// MFMA phase, then both in their vector phase).  Tried against that, none faster (docs/history.md): the MFMAs of tile i + 1 issued
+// before the vector work on tile i (two accumulator sets), per-wave hit buffers filled without atomics, lane masks instead of
+// maxima, a rolled hit loop over indexed registers, all B fragments read ahead, the vector work interleaved into the MFMAs by
+// sched_group_barrier (280 registers: one wave per SIMD).
+// A block whose queries do not all pass the brute-force test, and a launch with too few blocks to fill the chip, is left to
+// k_match_wide_lists (header [9..10]: one bit per 64 queries listed here).
+// -------------------------------------------------------------------------------------------------
+#ifndef ORBX_BF_EXP
+#define ORBX_BF_EXP 0  // diagnostic builds of k_match_bf_mfma without one of its parts (timing only; tools/exp_bf_parts.sh)
+#endif
+__global__ __launch_bounds__(256) void k_match_bf_mfma(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
+                                                      const orbx_keypoint* __restrict__ kps,
+                                                      const uint8_t* __restrict__ desc, const int* __restrict__ nkp,
+                                                      const MatchParams mp, const int* __restrict__ nmatchesOut,
+                                                      const int* __restrict__ scratchR, int* __restrict__ scratchW,
+                                                      long long scratchStride, int capl) {
+  // [image][k-step = dword][bit half][train]: 2 x 8 KB; rows of 33 pieces, so that the sixteen (train, dword) stores of a quarter
+  // wave fall into sixteen different groups of four banks (with 32 the eight dwords of a train share one)
+  __shared__ __attribute__((aligned(16))) v4i_t tileB[2][8][2][33];
+  __shared__ uint32_t qdS[256][9];
+  __shared__ int cnt[256];
+  __shared__ int sAll;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int pair = blockIdx.y + mp.pair0;
+  if (nmatchesOut[pair] != MATCH_PENDING) return;
+  const int* S = scratchR + (long long)pair * scratchStride;
+  if (S[2] || S[8]) return;  // (trains stored by grid column: the windows are narrow, no block can be brute force)
+  const int nQ = S[0], nT = S[1];
+  const int Q0 = blockIdx.x * 256;
+  if (Q0 >= nQ || nT <= 0) return;
+  // (a launch whose pairs have too few 256-query blocks to fill the chip with stays on k_match_wide_lists, 64 queries x a quarter of
+  // the trains per wave: 1080p frame pairs, 869 octave-0 queries each, matched four or eight pairs per call -- 0.24 ms there, 0.36 here)
+  if ((int)gridDim.y * ((nQ + 255) >> 8) < 128) return;
+  const int nTl = (nT + 31) >> 5;
+  const uint4* trec = reinterpret_cast<const uint4*>(S + MW_HDR);
+  const int* qIdx = S + MW_HDR + 4 * capl;
+  int* W = scratchW + (long long)pair * scratchStride;
+  int* cntOut = W + MW_HDR + 5 * capl;
+  uint32_t* lists = reinterpret_cast<uint32_t*>(W + MW_HDR + 6 * capl);
+  const int fa = pairFirst[pair], fb = pairSecond[pair];
+  const int cap = mp.capacity;
+  const orbx_keypoint* k1 = kps + (long long)fa * cap;
+  const uint32_t* d1 = reinterpret_cast<const uint32_t*>(desc + (long long)fa * cap * 32);
+  const uint32_t* d2 = reinterpret_cast<const uint32_t*>(desc + (long long)fb * cap * 32);
+  // ---- thread = query: the brute-force test of k_match_wide_lists (its comment there), for the whole block ----
+  const int q = Q0 + t;
+  const bool valid = q < nQ;
+  {
+    const float wInv = (float)ORBX_GRID_COLS / (float)(mp.b.max_x - mp.b.min_x);
+    const float hInv = (float)ORBX_GRID_ROWS / (float)(mp.b.max_y - mp.b.min_y);
+    const float fminX = (float)mp.b.min_x, fminY = (float)mp.b.min_y;
+    float qx = 0.f, qy = 0.f;
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+    if (valid) {
+      const int qi = qIdx[q];
+      qx = k1[qi].x; qy = k1[qi].y;
+      a0 = reinterpret_cast<const uint4*>(d1 + (long long)qi * 8)[0];
+      a1 = reinterpret_cast<const uint4*>(d1 + (long long)qi * 8)[1];
+    }
+    const float r = (float)mp.window;
+    const int minCX = max(0, (int)floorf((qx - fminX - r) * wInv));
+    const int maxCX = min(ORBX_GRID_COLS - 1, (int)ceilf((qx - fminX + r) * wInv));
+    const int minCY = max(0, (int)floorf((qy - fminY - r) * hInv));
+    const int maxCY = min(ORBX_GRID_ROWS - 1, (int)ceilf((qy - fminY + r) * hInv));
+    const float bbx0 = __uint_as_float((uint32_t)S[4]), bbx1 = __uint_as_float((uint32_t)S[5]);
+    const float bby0 = __uint_as_float((uint32_t)S[6]), bby1 = __uint_as_float((uint32_t)S[7]);
+    const bool lanePass = !valid || (minCX == 0 && maxCX == ORBX_GRID_COLS - 1 && minCY == 0 && maxCY == ORBX_GRID_ROWS - 1 &&
+                                     fabsf(bbx0 - qx) < r && fabsf(bbx1 - qx) < r && fabsf(bby0 - qy) < r && fabsf(bby1 - qy) < r);
+    if (t == 0) sAll = 1;
+    __syncthreads();
+    if (!lanePass) sAll = 0;
+    qdS[t][0] = a0.x; qdS[t][1] = a0.y; qdS[t][2] = a0.z; qdS[t][3] = a0.w;
+    qdS[t][4] = a1.x; qdS[t][5] = a1.y; qdS[t][6] = a1.z; qdS[t][7] = a1.w;
+    cnt[t] = 0;
+    __syncthreads();
+    if (!sAll) return;  // (uniform) k_match_wide_lists takes the block
+  }
+  // ---- the queries' fragments: rows = query 64 wv + 32 T + (lane & 31), k = the 16 bits (lane >> 5) of dword c ----
+  const int h = lane >> 5, n = lane & 31;
+  const bool waveLive = Q0 + 64 * wv < nQ;  // (uniform) a wave without a query only helps to stage the trains
+  v4i_t aq[2][8];
+#pragma unroll
+  for (int T = 0; T < 2; T++)
+#pragma unroll
+    for (int c = 0; c < 8; c++) aq[T][c] = pm1Bytes16(qdS[64 * wv + 32 * T + n][c] >> (16 * h));
+  const int thr = 256 - 2 * mp.dmax;
+  // ---- staging: thread = (train j of the tile, dword c).  A loaded value is first TOUCHED a tile later (the record word is masked
+  //      where it is used, not where it is loaded) and both loads are unconditional (a slot beyond the last train reads the last
+  //      train again; the appends mask it): a wait right behind a load, or the register copy a conditional load ends in, costs
+  //      every tile a memory round trip ----
+  const int sj = t >> 3, sc = t & 7;
+  auto loadIdx = [&](const int tile) -> uint32_t { return reinterpret_cast<const uint32_t*>(trec + min(32 * tile + sj, nT - 1))[3]; };
+  auto loadDw = [&](const uint32_t rec) -> uint32_t { return d2[(long long)(rec & 0xfffffu) * 8 + sc]; };
+  auto expand = [&](const int img, const uint32_t w) {
+    tileB[img][sc][0][sj] = pm1Bytes16(w);
+    tileB[img][sc][1][sj] = pm1Bytes16(w >> 16);
+  };
+  auto ldsBarrier = [&]() {  // (over the LDS images only: __syncthreads() would also wait for the global loads in flight)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  };
+  // image 0 = tile 0; wN = this thread's dword of tile 1, idxN its record of tile 2
+  uint32_t idxN = loadIdx(0);
+  uint32_t wN = loadDw(idxN);
+  idxN = loadIdx(1);
+  expand(0, wN);
+  wN = loadDw(idxN);
+  idxN = loadIdx(2);
+  ldsBarrier();
+  for (int i = 0; i < nTl; i++) {
+    const int img = i & 1;
+    if (waveLive) {
+      v16i_t acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+#if !(ORBX_BF_EXP & 2)  // (2: TIMING ONLY, no matrix instructions)
+        const v4i_t bt = tileB[img][c][h][n];
+        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[0][c], bt, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[1][c], bt, acc1, 0, 0, 0);
+#endif
+      }
+#if !(ORBX_BF_EXP & 8)  // (8: TIMING ONLY, no reduction)
+      int gm[2][4];
+#pragma unroll
+      for (int T = 0; T < 2; T++)
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+          const v16i_t& A = T ? acc1 : acc0;
+          gm[T][gq] = max(max(A[4 * gq], A[4 * gq + 1]), max(A[4 * gq + 2], A[4 * gq + 3]));
+        }
+      const int m = max(max(max(gm[0][0], gm[0][1]), max(gm[0][2], gm[0][3])), max(max(gm[1][0], gm[1][1]), max(gm[1][2], gm[1][3])));
+      const int e = 32 * i + n;
+      const bool tOk = e < nT;
+#if ORBX_BF_EXP & 1  // (1: TIMING ONLY, no appends)
+      if (m == 0x7fffffff)
+#endif
+      if (__ballot(tOk && m > thr) != 0ull) {  // (wave-uniform) some pair of the tile is nearer than dmax
+#pragma unroll
+        for (int T = 0; T < 2; T++)
+#pragma unroll
+          for (int gq = 0; gq < 4; gq++) {
+            if (__ballot(tOk && gm[T][gq] > thr) == 0ull) continue;  // (wave-uniform)
+            const v16i_t& A = T ? acc1 : acc0;
+#pragma unroll
+            for (int r = 4 * gq; r < 4 * gq + 4; r++) {
+              const int a = A[r];
+              const int ql = 64 * wv + 32 * T + (r & 3) + 8 * (r >> 2) + 4 * h;
+              if (tOk && a > thr && Q0 + ql < nQ) {
+                const int slot = atomicAdd(&cnt[ql], 1);
+                if (slot < MW_CP) lists[(size_t)slot * capl + Q0 + ql] = ((uint32_t)((256 - a) >> 1) << 16) | (uint32_t)e;
+              }
+            }
+          }
+      }
+#else
+      if (acc0[0] == 0x7fffffff) cnt[0] = 1;
+#endif
+    }
+#if !(ORBX_BF_EXP & 4)  // (4: TIMING ONLY, no staging)
+    if (i + 1 < nTl) {  // (uniform) the next tile into the other image: its last readers passed the barrier of the previous step
+      expand(img ^ 1, wN);
+      wN = loadDw(idxN);
+      idxN = loadIdx(i + 3);
+    }
+#endif
+    ldsBarrier();
+  }
+  __syncthreads();
+  if (valid) {
+    const int c = cnt[t];
+    if (c > MW_CP) atomicOr(&W[3], 1);
+    cntOut[q] = min(c, MW_CP) | (1 << 16);  // (bit 16: vIndices2 of the query is not empty -- nT > 0 here)
+  }
+  if (t < 4 && Q0 + 64 * t < nQ) atomicOr(&W[9 + ((4 * blockIdx.x + t) >> 5)], 1 << ((4 * blockIdx.x + t) & 31));
 }
 
 // k_match_wide_sort: every query's candidate list (k_match_wide_lists: at most MW_CP entries in no particular order) sorted by
@@ -3197,6 +3413,7 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
   MatchParams mp;
   mp.capacity = capacity; mp.window = window; mp.nnratio = nnratio; mp.checkOri = checkOri; mp.b = b;
   mp.noGeneral = knobOn(KNOB_MATCH_NO_GENERAL) ? 1 : 0;  // tests: see which pairs the parallel paths complete
+  mp.noMfma = knobOn(KNOB_MATCH_NO_MFMA) ? 1 : 0;
   mp.pair0 = pair0;
   // With bestDist <= TH_LOW required, a train at distance s can matter as best only if s <= TH_LOW and as second-best
   // only if nnratio * s < TH_LOW (ORBmatcher.cpp:84-87: accepted iff bestDist <= nnratio * bestDist2 in f32, and f32
@@ -3217,6 +3434,9 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
     hipLaunchKernelGGL(k_match_wide_prep, dim3(nPairs), dim3(MW_T), 0, st, dFirst, dSecond, kps, nkp, mp, matches12, nmatches,
                        scratch, stride, capl);
   if (wideMode != 0) {
+    if (!mp.noMfma)
+      hipLaunchKernelGGL(k_match_bf_mfma, dim3((capl + 255) / 256, nPairs), dim3(256), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
+                         nmatches, scratch, scratch, stride, capl);
     hipLaunchKernelGGL(k_match_wide_lists, dim3((capl + 63) / 64, nPairs), dim3(256), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
                        nmatches, scratch, scratch, stride, capl);
     hipLaunchKernelGGL(k_match_wide_sort, dim3((capl + 15) / 16, nPairs), dim3(256), 0, st, mp, nmatches, scratch, stride, capl);

@@ -29,6 +29,7 @@ namespace orbx {
   X(KNOB_FAST_DEBUG, "fast_debug")            /* print k_fast_wave's occupancy */                                                \
   X(KNOB_DESC_LDS_PAD, "desc_lds_pad")        /* unused dynamic LDS per k_describe_patch workgroup */                            \
   X(KNOB_MATCH_NO_GENERAL, "match_no_general") /* the matcher's sequential fallback is skipped (pairs it would take stay pending) */ \
+  X(KNOB_MATCH_NO_MFMA, "match_no_mfma")      /* brute-force matching on the vector ALU (xor / bcnt) instead of the matrix cores */ \
   X(KNOB_OCT_NO_SMALL, "oct_no_small")        /* selection: always the 2048-candidate LDS instance */                            \
   X(KNOB_OCT_KEY64, "oct_key64")              /* selection: always 64-bit sort keys */                                           \
   X(KNOB_OCT_SPLIT_MIN, "oct_split_min")      /* batch size from which every group of levels with one instance gets its own launch */ \

@@ -238,6 +238,73 @@ def test_brute_force_match_configs(orbx, ext640, oracle):
         assert (m12 >= 0).sum() > n // 4
 
 
+def test_brute_force_on_the_matrix_cores(orbx, oracle):
+    """k_match_bf_mfma takes the blocks of 256 queries whose windows cover every train, in launches with at least 128 such blocks
+    (fewer stay on k_match_wide_lists): 64 pairs of two to five blocks in one call, every pair different -- set sizes that are no multiple of 256, 64
+    or 32, descriptors from few prototypes (many candidates per query, lists that overflow and send the pair to the reference's
+    loop), other octaves mixed in -- against the oracle pair by pair, and the same call on the vector form (knob match_no_mfma).
+    Then a window that only the queries in the middle of the frame pass, with the queries sorted by x: the blocks in the middle
+    go to the matrix cores, the ones at the sides to k_match_wide_lists, in one pair."""
+    import torch
+    rng = np.random.default_rng(123)
+    dev = torch.device("cuda", 0)
+    KP = orbx.KEYPOINT_DTYPE
+    P, cap = 64, 1100
+    W, H = 3840, 2160
+    ext = orbx.ORBextractor(cap, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=1)
+
+    def run(sets, window, ratio, ori):
+        k_all = np.zeros((2 * P, cap), KP)
+        d_all = np.zeros((2 * P, cap, 32), np.uint8)
+        n_all = np.zeros(2 * P, np.int32)
+        for i, (k1, d1, k2, d2) in enumerate(sets):
+            for f, (k, d) in ((2 * i, (k1, d1)), (2 * i + 1, (k2, d2))):
+                k_all[f, :len(k)] = k
+                d_all[f, :len(k)] = d
+                n_all[f] = len(k)
+        d_k = torch.from_numpy(k_all.view(np.uint8).reshape(-1).copy()).to(dev)
+        d_d = torch.from_numpy(d_all.reshape(-1)).to(dev)
+        d_n = torch.from_numpy(n_all).to(dev)
+        first = np.arange(0, 2 * P, 2, dtype=np.int32)
+        out = []
+        for knob in (None, 1):
+            orbx.debug_set("match_no_mfma", knob)
+            d_m = torch.full((P * cap,), -7, dtype=torch.int32, device=dev)
+            d_nm = torch.zeros(P, dtype=torch.int32, device=dev)
+            d_st = torch.zeros(3 * P, dtype=torch.int32, device=dev)
+            ext.match_pairs_device(first, first + 1, d_k, d_d, d_n, (0, W, 0, H), d_m, d_nm, d_st, window, ratio, ori, cap)
+            torch.cuda.synchronize()
+            out.append((d_m.cpu().numpy().reshape(P, cap), d_nm.cpu().numpy(), d_st.cpu().numpy().reshape(P, 3)))
+        orbx.debug_set("match_no_mfma", None)
+        for i, (k1, d1, k2, d2) in enumerate(sets):
+            onm, om12, ost = oracle.match_init(k1, d1, k2, d2, (0, W, 0, H), window, ratio, ori)
+            for (m, nm, st) in out:
+                assert nm[i] == onm and np.array_equal(m[i, :len(k1)], om12) and st[i].tolist() == ost.tolist(), (i, len(k1), len(k2))
+        return out
+
+    try:
+        sets = []
+        for i in range(P):
+            n = int(rng.integers(530, cap - 8))  # more than 512: the wide path, three to five blocks of 256 queries
+            if i % 7 == 3:  # few prototypes: tens of candidates per query; the smallest prototype sets overflow the lists
+                protos = rng.integers(0, 256, (int(rng.choice([3, 40, 400])), 32), dtype=np.uint8)
+                sets.append(_clustered_desc_pair(orbx, rng, n, protos, 10, W, H, 0.85, 6))
+            else:
+                protos = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+                sets.append(_clustered_desc_pair(orbx, rng, n, protos, 40, W, H, 1.0 if i % 3 else 0.8, 4))
+        o1 = run(sets, 8192, 0.9, True)
+        assert sum(int((m >= 0).sum()) for m in o1[0][0]) > P * 100
+        # a window the middle of the frame passes: |x - bbx0| < r and |x - bbx1| < r need x in (W - r, r)
+        sets2 = []
+        for (k1, d1, k2, d2) in sets:
+            o = np.argsort(k1["x"], kind="stable")
+            sets2.append((k1[o], d1[o], k2, d2))
+        run(sets2, 2600, 0.8, False)
+    finally:
+        orbx.debug_set("match_no_mfma", None)
+        ext.close()
+
+
 def _flip_bits(rng, d, max_flips):
     for i in range(len(d)):
         for bit in rng.integers(0, 256, int(rng.integers(0, max_flips + 1))):

@@ -141,6 +141,9 @@ def measure_bf(steps=20, device=0):
     pairs = P * n * n
     out = {"sets_per_call": P, "descriptors": [n, n], "ms_per_call": dt * 1e3, "ms_per_2000x2000": dt * 1e3 / P,
            "descriptor_pairs_per_s": pairs / dt, "frac_of_4.9T_pairs_per_s": pairs / dt / 4.9e12, "frac_of_3.3T_pairs_per_s": pairs / dt / 3.3e12,
+           # round 5: the all-pairs distances run on the matrix cores (k_match_bf_mfma): 16 v_mfma_i32_32x32x32_i8 of 32 cycles per
+           # 2048 pairs = 0.25 cycles of a SIMD per pair -> 1024 SIMDs x 2.4 GHz / 0.25 = 9.8 T pairs/s
+           "frac_of_9.8T_mfma_i8_pairs_per_s": pairs / dt / 9.8e12,
            "device_ms_per_call": ext.profile_get()["match"][0] / steps, "nmatches": int(d_nm[0].item()),
            "algorithmic_bytes_per_2000x2000": 48 * 2 * n + 4 * n}
     got_m = d_m[:n].cpu().numpy()
