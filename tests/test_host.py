@@ -293,3 +293,17 @@ def test_pin_kit_compiles():
     p = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "pin_opencv", "export_fixtures.py"), "/tmp/orbx_pin_fixtures"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert p.returncode == 0 and os.path.exists("/tmp/orbx_pin_fixtures/manifest.txt"), p.stdout
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """liborbx.so loaded BEFORE torch must not leave the process with two HIP runtimes (torch loads its own libamdhip64.so by path; the
+    second runtime finds no device and orbx_create fails): the loader takes torch's copy first when torch is installed."""
+    import subprocess
+    import sys
+    code = ("import orb_slam_tracking_amd as o\no.lib()\nimport torch\n"
+            "print(sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l)))")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-500:]
+    libs = eval(r.stdout.strip().splitlines()[-1])
+    assert len(libs) == 1, libs
