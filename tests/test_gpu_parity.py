@@ -253,7 +253,7 @@ def test_brute_force_on_the_matrix_cores(orbx, oracle):
     W, H = 3840, 2160
     ext = orbx.ORBextractor(cap, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=1)
 
-    def run(sets, window, ratio, ori):
+    def run(sets, window, ratio, ori, reps=1):
         k_all = np.zeros((2 * P, cap), KP)
         d_all = np.zeros((2 * P, cap, 32), np.uint8)
         n_all = np.zeros(2 * P, np.int32)
@@ -265,21 +265,23 @@ def test_brute_force_on_the_matrix_cores(orbx, oracle):
         d_k = torch.from_numpy(k_all.view(np.uint8).reshape(-1).copy()).to(dev)
         d_d = torch.from_numpy(d_all.reshape(-1)).to(dev)
         d_n = torch.from_numpy(n_all).to(dev)
-        first = np.arange(0, 2 * P, 2, dtype=np.int32)
+        first = np.tile(np.arange(0, 2 * P, 2, dtype=np.int32), reps)  # (every pair `reps` times in the launch: more blocks)
+        NP = len(first)
         out = []
         for knob in (None, 1):
             orbx.debug_set("match_no_mfma", knob)
-            d_m = torch.full((P * cap,), -7, dtype=torch.int32, device=dev)
-            d_nm = torch.zeros(P, dtype=torch.int32, device=dev)
-            d_st = torch.zeros(3 * P, dtype=torch.int32, device=dev)
+            d_m = torch.full((NP * cap,), -7, dtype=torch.int32, device=dev)
+            d_nm = torch.zeros(NP, dtype=torch.int32, device=dev)
+            d_st = torch.zeros(3 * NP, dtype=torch.int32, device=dev)
             ext.match_pairs_device(first, first + 1, d_k, d_d, d_n, (0, W, 0, H), d_m, d_nm, d_st, window, ratio, ori, cap)
             torch.cuda.synchronize()
-            out.append((d_m.cpu().numpy().reshape(P, cap), d_nm.cpu().numpy(), d_st.cpu().numpy().reshape(P, 3)))
+            out.append((d_m.cpu().numpy().reshape(NP, cap), d_nm.cpu().numpy(), d_st.cpu().numpy().reshape(NP, 3)))
         orbx.debug_set("match_no_mfma", None)
         for i, (k1, d1, k2, d2) in enumerate(sets):
             onm, om12, ost = oracle.match_init(k1, d1, k2, d2, (0, W, 0, H), window, ratio, ori)
             for (m, nm, st) in out:
-                assert nm[i] == onm and np.array_equal(m[i, :len(k1)], om12) and st[i].tolist() == ost.tolist(), (i, len(k1), len(k2))
+                for j in range(i, NP, P):
+                    assert nm[j] == onm and np.array_equal(m[j, :len(k1)], om12) and st[j].tolist() == ost.tolist(), (j, len(k1), len(k2))
         return out
 
     try:
@@ -300,6 +302,11 @@ def test_brute_force_on_the_matrix_cores(orbx, oracle):
             o = np.argsort(k1["x"], kind="stable")
             sets2.append((k1[o], d1[o], k2, d2))
         run(sets2, 2600, 0.8, False)
+        # one block of fewer than 256 queries per pair (the last waves without a query), trains that are no multiple of 32, every
+        # pair three times in the launch so that it has its 128 blocks
+        sets3 = [(k1[:int(rng.integers(70, 250))], d1, k2, d2) for (k1, d1, k2, d2) in sets[:48]]
+        sets3 = [(k1, d1[:len(k1)], k2, d2) for (k1, d1, k2, d2) in sets3] + sets[48:]
+        run(sets3, 8192, 0.9, True, reps=3)
     finally:
         orbx.debug_set("match_no_mfma", None)
         ext.close()
