@@ -11,12 +11,15 @@
 //   k_match_jacobi / k_match_wide_lists / k_match_wide_resolve   SearchForInitialization: parallel fixpoint sweeps (one
 //                     workgroup per pair up to 256 queries; wide path up to 4096), the sequential loop for the rest
 //                                                    (ORBmatcher.cpp:11-183, Frame.cpp:89-99,163-206, FORB.cpp:77-101)
+//   k_match_bf_mfma   the wide path's brute-force case (windows that cover every train) when a launch holds enough pairs: all-pairs
+//                     Hamming distances as int8 matrix products (v_mfma_i32_32x32x32_i8 on +-1 bytes)
 //   k_undistort, k_to_gray, k_check_model     the steps around the path (Frame.cpp:101-161, Converter.cpp:5-19,
 //                                                     Initializer.cpp:268-438)
 //   (the quadtree selection lives in orbx_octree_kernel.hip)
 //
 // All arithmetic is integer or uncontracted IEEE f32/f64 (compile with -ffp-contract=off) so the results are
-// bit-identical to the CPU restatement in oracle/.  No MFMA: there is no dense contraction on this path.
+// bit-identical to the CPU restatement in oracle/.  The matrix cores serve k_match_bf_mfma only (exact int8 / int32 arithmetic): the
+// all-pairs distances of a brute-force match are the path's one dense contraction; everything else is byte and integer work.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Where k_match_bf_mfma loses: BASELINE config 3's frames (a synthetic scene that repeats its corners: about a hundred candidates per
+query) in batches of 128, i.e. 64 brute-force pairs per call -- enough blocks for the matrix-core kernel -- with and without it
+(knob match_no_mfma): matching stage per batch and frames/s (docs/history.md, round 5)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
