@@ -2629,6 +2629,29 @@ __global__ __launch_bounds__(256) void k_match_wide_lists(const int* __restrict_
 #ifndef ORBX_BF_EXP
 #define ORBX_BF_EXP 0  // diagnostic builds of k_match_bf_mfma without one of its parts (timing only; tools/exp_bf_parts.sh)
 #endif
+// Diagnostic build only (-DORBX_BF_STAMPS): per wave of k_match_bf_mfma, s_memtime deltas of a tile's phases summed over its tiles
+// (tools/bf_stamps.py prints the shares): 0 LDS reads + MFMA issue, 1 drain + reduction, 2 appends, 3 staging, 4 barrier.
+#ifdef ORBX_BF_STAMPS
+__device__ uint32_t g_bfStamps[4096 * 8];
+#define BF_STAMP(k)                                                        \
+  do {                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();          \
+    bfAcc_[k] += (uint32_t)(now_ - bfPrev_);                               \
+    bfPrev_ = now_;                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+  } while (0)
+extern "C" int orbx_diag_bf_stamps(uint32_t* out, int nWaves) {
+  if (nWaves < 0) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_bfStamps)) != hipSuccess) return -1;
+    return (int)hipMemset(p, 0, sizeof(uint32_t) * 8 * 4096);
+  }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bfStamps), sizeof(uint32_t) * 8 * (size_t)nWaves);
+}
+#else
+#define BF_STAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void k_match_bf_mfma(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
                                                       const orbx_keypoint* __restrict__ kps,
                                                       const uint8_t* __restrict__ desc, const int* __restrict__ nkp,
@@ -2730,6 +2753,10 @@ __global__ __launch_bounds__(256) void k_match_bf_mfma(const int* __restrict__ p
   wN = loadDw(idxN);
   idxN = loadIdx(2);
   ldsBarrier();
+#ifdef ORBX_BF_STAMPS
+  unsigned long long bfPrev_ = __builtin_amdgcn_s_memtime();
+  uint32_t bfAcc_[5] = {0u, 0u, 0u, 0u, 0u};
+#endif
   for (int i = 0; i < nTl; i++) {
     const int img = i & 1;
     if (waveLive) {
@@ -2742,6 +2769,7 @@ __global__ __launch_bounds__(256) void k_match_bf_mfma(const int* __restrict__ p
         acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[1][c], bt, acc1, 0, 0, 0);
 #endif
       }
+      BF_STAMP(0);
 #if !(ORBX_BF_EXP & 8)  // (8: TIMING ONLY, no reduction)
       int gm[2][4];
 #pragma unroll
@@ -2754,6 +2782,8 @@ __global__ __launch_bounds__(256) void k_match_bf_mfma(const int* __restrict__ p
       const int m = max(max(max(gm[0][0], gm[0][1]), max(gm[0][2], gm[0][3])), max(max(gm[1][0], gm[1][1]), max(gm[1][2], gm[1][3])));
       const int e = 32 * i + n;
       const bool tOk = e < nT;
+      asm volatile("" :: "v"(m));
+      BF_STAMP(1);
 #if ORBX_BF_EXP & 1  // (1: TIMING ONLY, no appends)
       if (m == 0x7fffffff)
 #endif
@@ -2778,6 +2808,7 @@ __global__ __launch_bounds__(256) void k_match_bf_mfma(const int* __restrict__ p
 #else
       if (acc0[0] == 0x7fffffff) cnt[0] = 1;
 #endif
+      BF_STAMP(2);
     }
 #if !(ORBX_BF_EXP & 4)  // (4: TIMING ONLY, no staging)
     if (i + 1 < nTl) {  // (uniform) the next tile into the other image: its last readers passed the barrier of the previous step
@@ -2786,8 +2817,19 @@ __global__ __launch_bounds__(256) void k_match_bf_mfma(const int* __restrict__ p
       idxN = loadIdx(i + 3);
     }
 #endif
+    BF_STAMP(3);
     ldsBarrier();
+    BF_STAMP(4);
   }
+#ifdef ORBX_BF_STAMPS
+  {
+    const unsigned wid_ = ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) & 4095u;
+    if (lane == 0) {
+      for (int j = 0; j < 5; j++) g_bfStamps[wid_ * 8 + j] = bfAcc_[j];
+      g_bfStamps[wid_ * 8 + 5] = (uint32_t)nTl;
+    }
+  }
+#endif
   __syncthreads();
   if (valid) {
     const int c = cnt[t];

@@ -107,7 +107,7 @@ def measure(config, steps=20, depth=3, batch=0, modes=("sync", "lanes"), device=
     return out
 
 
-def measure_bf(steps=20, device=0):
+def measure_bf(steps=20, device=0, sets=64):
     """BASELINE config 5's matcher: 2000 x 2000 descriptors, window covering the frame -> every (query, train) pair is a candidate."""
     import torch
     import orb_slam_tracking_amd as orbx
@@ -115,7 +115,7 @@ def measure_bf(steps=20, device=0):
     dev = torch.device("cuda", device)
     n = 2000
     kA, dA, kB, dB = synth.synth_desc(n, 5)
-    P = 64  # pairs of descriptor sets per call (the same two sets: what is timed is the matcher, not the data)
+    P = sets  # pairs of descriptor sets per call (the same two sets: what is timed is the matcher, not the data)
     k_all = np.concatenate([kA, kB])
     d_all = np.concatenate([dA, dB])
     d_k = torch.from_numpy(np.tile(k_all.view(np.uint8).reshape(2, n * 28), (P, 1)).reshape(-1).copy()).to(dev)
