@@ -2599,30 +2599,35 @@ __global__ __launch_bounds__(256) void k_match_wide_lists(const int* __restrict_
 // block covers every train (BASELINE config 5's 2000 x 2000 match, config 3's all-pairs match), the work is all pairs of
 // 256-bit Hamming distances and one compare -- a dense contraction over the bits: with the bits as +-1 bytes (pm1Bytes16) the
 // dot product of two descriptors is 256 - 2 x distance, so "distance < dmax" is "accumulator > 256 - 2 dmax", one threshold.
-//   * workgroup = 256 queries, wave = 64 of them (two 32-row fragments x 8 k-steps = 64 registers, built once);
+//   * workgroup = 256 queries, eight waves of 32 (one 32-row fragment x 8 k-steps = 32 registers, built once; BF_NT = 2: four waves
+//     of 64 -- half the waves per SIMD, 2.50 against 2.30 us per 2000 x 2000: the kernel is bound by a wave's own chain of LDS reads,
+//     MFMAs, reduction, appends and barrier, ~2800 cycles per tile, so more and lighter waves are what helps);
 //   * the trains go by in tiles of 32: thread (train t >> 3, dword t & 7) loads one dword of a train's descriptor (the record two
 //     tiles ahead, the dword one tile ahead) and expands it into the tile's LDS image (two 16-byte stores), laid out so that a
 //     wave reads the B fragment of k-step c as 64 consecutive 16-byte pieces; two images, one LDS-only barrier per tile;
-//   * per tile and wave 16 v_mfma_i32_32x32x32_i8 (64 x 32 distances), then the maxima of four consecutive query rows, their
+//   * per tile and wave 8 v_mfma_i32_32x32x32_i8 (32 x 32 distances), then the maxima of four consecutive query rows, their
 //     maximum and one compare;
 //   * a candidate -- about one per wave and tile in the synthetic sets, one in thousands of pairs -- is appended from the lane that
 //     holds its accumulator (column = train, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) to the lists k_match_wide_lists fills
 //     (slots through the queries' counters in LDS); only a group of four rows with a hit looks at its accumulators again;
 //   * both operands take their k order from the same function of (lane >> 5, byte), so the instruction's own k map is irrelevant.
 // The vector form costs 16 xor / bcnt per 64 pairs (1.1 cycles of a SIMD per pair), the matrix form 0.25 (16 MFMAs of 32 cycles
-// per 2048 pairs).  Measured per 64 sets of 2000 x 2000 (tools/exp_bf_parts.sh: timing-only builds without one part): the MFMAs
-// with their LDS reads and the barrier alone 31.5 us -- the int8 rate -- with the reduction 55, with the staging 65, with the
-// appends 100, against 160 for the vector form: the parts ADD, because the two workgroups of a CU fall into step (both in their
-// MFMA phase, then both in their vector phase).  Tried against that, none faster (docs/history.md): the MFMAs of tile i + 1 issued
-// before the vector work on tile i (two accumulator sets), per-wave hit buffers filled without atomics, lane masks instead of
-// maxima, a rolled hit loop over indexed registers, all B fragments read ahead, the vector work interleaved into the MFMAs by
-// sched_group_barrier (280 registers: one wave per SIMD).
+// per 2048 pairs).  Measured per 64 sets of 2000 x 2000: 81 us (with 64 queries per wave: 96) against 160 for the vector form; the
+// MFMAs with their LDS reads and the barrier alone would take 31.5 us -- the int8 rate (tools/exp_bf_parts.sh: timing-only builds
+// without one part; with the reduction 55, the staging 65, the appends 100 at 64 queries per wave).  Cycle stamps
+// (tools/bf_stamps.py) show why the parts add up: a wave needs ~2800 cycles per tile whatever shares its CU -- LDS reads + MFMA
+// issue 800, drain + reduction 290, appends 750 (a hit every second tile, 1400 cycles of compare -> scalar test -> branch round
+// trips), staging 420, barrier 670 (the wave that took the append path is waited for) -- so the kernel is bound by the number of
+// waves in flight: hence the light waves.  Tried against the chain itself, none faster (docs/history.md): the MFMAs of tile
+// i + 1 issued before the vector work on tile i (two accumulator sets), per-wave hit buffers filled without atomics, lane masks
+// instead of maxima, a rolled hit loop over indexed registers, scalar hit handling by v_readlane, all B fragments read ahead, the
+// vector work interleaved into the MFMAs by sched_group_barrier (280 registers: one wave per SIMD), unequal wave priorities.
 // A block whose queries do not all pass the brute-force test, and a launch with too few blocks to fill the chip, is left to
 // k_match_wide_lists (header [9..10]: one bit per 64 queries listed here).
 // Built for candidates that are one pair in thousands.  Where they come by the hundred per query (BASELINE config 3's synthetic
 // frames repeat their corners: every ninth pair is nearer than dmax) the appends dominate and the vector form is faster -- 64 such
 // pairs of 1080p frames in one call: 0.47 against 0.32 ms for the matching stage, 54.7 k against 56.2 k frames/s
-// (tools/exp_c3_dense.py; config 3 as benchmarked, 16 pairs per call, stays below the 128 blocks).  Giving such blocks back was tried
+// (tools/exp_c3_dense.py; config 3 as benchmarked, 16 pairs per call, stays below the 256 blocks).  Giving such blocks back was tried
 // (a wave counting its first tiles' candidates: the first tile says nothing, those frames' candidates sit further down the train
 // list; counting while listing cost the sparse case 7 %) and left out.
 // -------------------------------------------------------------------------------------------------
@@ -2652,7 +2657,16 @@ extern "C" int orbx_diag_bf_stamps(uint32_t* out, int nWaves) {
 #else
 #define BF_STAMP(k) do { } while (0)
 #endif
-__global__ __launch_bounds__(256) void k_match_bf_mfma(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
+#ifndef BF_NT
+#define BF_NT 1  // 32-row query fragments per wave: 1 = 32 queries per wave, eight waves per workgroup; 2 = 64 queries, four waves
+#endif
+#ifndef BF_WAVES
+#define BF_WAVES (8 / BF_NT)  // waves per workgroup
+#endif
+#define BF_T (64 * BF_WAVES)
+#define BF_QWG (32 * BF_NT * BF_WAVES)  // queries per workgroup (a multiple of 64)
+static_assert(BF_T == 256 || BF_T == 512, "k_match_bf_mfma: the staging maps 512 half dwords of a tile onto 256 or 512 threads");
+__global__ __launch_bounds__(BF_T) void k_match_bf_mfma(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
                                                       const orbx_keypoint* __restrict__ kps,
                                                       const uint8_t* __restrict__ desc, const int* __restrict__ nkp,
                                                       const MatchParams mp, const int* __restrict__ nmatchesOut,
@@ -2661,8 +2675,8 @@ __global__ __launch_bounds__(256) void k_match_bf_mfma(const int* __restrict__ p
   // [image][k-step = dword][bit half][train]: 2 x 8 KB; rows of 33 pieces, so that the sixteen (train, dword) stores of a quarter
   // wave fall into sixteen different groups of four banks (with 32 the eight dwords of a train share one)
   __shared__ __attribute__((aligned(16))) v4i_t tileB[2][8][2][33];
-  __shared__ uint32_t qdS[256][9];
-  __shared__ int cnt[256];
+  __shared__ uint32_t qdS[BF_QWG][9];
+  __shared__ int cnt[BF_QWG];
   __shared__ int sAll;
   const int t = threadIdx.x, lane = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -2671,11 +2685,12 @@ __global__ __launch_bounds__(256) void k_match_bf_mfma(const int* __restrict__ p
   const int* S = scratchR + (long long)pair * scratchStride;
   if (S[2] || S[8]) return;  // (trains stored by grid column: the windows are narrow, no block can be brute force)
   const int nQ = S[0], nT = S[1];
-  const int Q0 = blockIdx.x * 256;
+  const int Q0 = blockIdx.x * BF_QWG;
   if (Q0 >= nQ || nT <= 0) return;
   // (a launch whose pairs have too few 256-query blocks to fill the chip with stays on k_match_wide_lists, 64 queries x a quarter of
-  // the trains per wave: 1080p frame pairs, 869 octave-0 queries each, matched four or eight pairs per call -- 0.24 ms there, 0.36 here)
-  if ((int)gridDim.y * ((nQ + 255) >> 8) < 128) return;
+  // the trains per wave: 1080p frame pairs, 869 octave-0 queries each, matched four or eight pairs per call -- 0.24 ms there, 0.36 here;
+  // 2000 x 2000 sets: 16 per call 6.5 us per pair of sets there, 8.3 here; 32 per call 4.3 there, 3.8 here)
+  if ((int)gridDim.y * ((nQ + 255) >> 8) < 256) return;  // (counted in blocks of 256 queries whatever the workgroup's size)
   const int nTl = (nT + 31) >> 5;
   const uint4* trec = reinterpret_cast<const uint4*>(S + MW_HDR);
   const int* qIdx = S + MW_HDR + 4 * capl;
@@ -2689,7 +2704,7 @@ __global__ __launch_bounds__(256) void k_match_bf_mfma(const int* __restrict__ p
   const uint32_t* d2 = reinterpret_cast<const uint32_t*>(desc + (long long)fb * cap * 32);
   // ---- thread = query: the brute-force test of k_match_wide_lists (its comment there), for the whole block ----
   const int q = Q0 + t;
-  const bool valid = q < nQ;
+  const bool valid = t < BF_QWG && q < nQ;
   {
     const float wInv = (float)ORBX_GRID_COLS / (float)(mp.b.max_x - mp.b.min_x);
     const float hInv = (float)ORBX_GRID_ROWS / (float)(mp.b.max_y - mp.b.min_y);
@@ -2714,31 +2729,42 @@ __global__ __launch_bounds__(256) void k_match_bf_mfma(const int* __restrict__ p
     if (t == 0) sAll = 1;
     __syncthreads();
     if (!lanePass) sAll = 0;
-    qdS[t][0] = a0.x; qdS[t][1] = a0.y; qdS[t][2] = a0.z; qdS[t][3] = a0.w;
-    qdS[t][4] = a1.x; qdS[t][5] = a1.y; qdS[t][6] = a1.z; qdS[t][7] = a1.w;
-    cnt[t] = 0;
+    if (t < BF_QWG) {
+      qdS[t][0] = a0.x; qdS[t][1] = a0.y; qdS[t][2] = a0.z; qdS[t][3] = a0.w;
+      qdS[t][4] = a1.x; qdS[t][5] = a1.y; qdS[t][6] = a1.z; qdS[t][7] = a1.w;
+      cnt[t] = 0;
+    }
     __syncthreads();
     if (!sAll) return;  // (uniform) k_match_wide_lists takes the block
   }
   // ---- the queries' fragments: rows = query 64 wv + 32 T + (lane & 31), k = the 16 bits (lane >> 5) of dword c ----
   const int h = lane >> 5, n = lane & 31;
-  const bool waveLive = Q0 + 64 * wv < nQ;  // (uniform) a wave without a query only helps to stage the trains
-  v4i_t aq[2][8];
+  const int qw = 32 * BF_NT * wv;  // the wave's first query of the block
+  const bool waveLive = Q0 + qw < nQ;  // (uniform) a wave without a query only helps to stage the trains
+  v4i_t aq[BF_NT][8];
 #pragma unroll
-  for (int T = 0; T < 2; T++)
+  for (int T = 0; T < BF_NT; T++)
 #pragma unroll
-    for (int c = 0; c < 8; c++) aq[T][c] = pm1Bytes16(qdS[64 * wv + 32 * T + n][c] >> (16 * h));
+    for (int c = 0; c < 8; c++) aq[T][c] = pm1Bytes16(qdS[qw + 32 * T + n][c] >> (16 * h));
   const int thr = 256 - 2 * mp.dmax;
   // ---- staging: thread = (train j of the tile, dword c).  A loaded value is first TOUCHED a tile later (the record word is masked
   //      where it is used, not where it is loaded) and both loads are unconditional (a slot beyond the last train reads the last
   //      train again; the appends mask it): a wait right behind a load, or the register copy a conditional load ends in, costs
   //      every tile a memory round trip ----
+#if BF_T == 256
   const int sj = t >> 3, sc = t & 7;
+#else  // (eight waves: a thread expands one half of a dword)
+  const int sj = t >> 4, sc = (t >> 1) & 7, sh = t & 1;
+#endif
   auto loadIdx = [&](const int tile) -> uint32_t { return reinterpret_cast<const uint32_t*>(trec + min(32 * tile + sj, nT - 1))[3]; };
   auto loadDw = [&](const uint32_t rec) -> uint32_t { return d2[(long long)(rec & 0xfffffu) * 8 + sc]; };
   auto expand = [&](const int img, const uint32_t w) {
+#if BF_T == 256
     tileB[img][sc][0][sj] = pm1Bytes16(w);
     tileB[img][sc][1][sj] = pm1Bytes16(w >> 16);
+#else
+    tileB[img][sc][sh][sj] = pm1Bytes16(w >> (16 * sh));
+#endif
   };
   auto ldsBarrier = [&]() {  // (over the LDS images only: __syncthreads() would also wait for the global loads in flight)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -2766,7 +2792,9 @@ __global__ __launch_bounds__(256) void k_match_bf_mfma(const int* __restrict__ p
 #if !(ORBX_BF_EXP & 2)  // (2: TIMING ONLY, no matrix instructions)
         const v4i_t bt = tileB[img][c][h][n];
         acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[0][c], bt, acc0, 0, 0, 0);
+#if BF_NT == 2
         acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[1][c], bt, acc1, 0, 0, 0);
+#endif
 #endif
       }
       BF_STAMP(0);
@@ -2777,7 +2805,7 @@ __global__ __launch_bounds__(256) void k_match_bf_mfma(const int* __restrict__ p
 #pragma unroll
         for (int gq = 0; gq < 4; gq++) {
           const v16i_t& A = T ? acc1 : acc0;
-          gm[T][gq] = max(max(A[4 * gq], A[4 * gq + 1]), max(A[4 * gq + 2], A[4 * gq + 3]));
+          gm[T][gq] = T < BF_NT ? max(max(A[4 * gq], A[4 * gq + 1]), max(A[4 * gq + 2], A[4 * gq + 3])) : (int)0x80000000;
         }
       const int m = max(max(max(gm[0][0], gm[0][1]), max(gm[0][2], gm[0][3])), max(max(gm[1][0], gm[1][1]), max(gm[1][2], gm[1][3])));
       const int e = 32 * i + n;
@@ -2789,7 +2817,7 @@ __global__ __launch_bounds__(256) void k_match_bf_mfma(const int* __restrict__ p
 #endif
       if (__ballot(tOk && m > thr) != 0ull) {  // (wave-uniform) some pair of the tile is nearer than dmax
 #pragma unroll
-        for (int T = 0; T < 2; T++)
+        for (int T = 0; T < BF_NT; T++)
 #pragma unroll
           for (int gq = 0; gq < 4; gq++) {
             if (__ballot(tOk && gm[T][gq] > thr) == 0ull) continue;  // (wave-uniform)
@@ -2797,7 +2825,7 @@ __global__ __launch_bounds__(256) void k_match_bf_mfma(const int* __restrict__ p
 #pragma unroll
             for (int r = 4 * gq; r < 4 * gq + 4; r++) {
               const int a = A[r];
-              const int ql = 64 * wv + 32 * T + (r & 3) + 8 * (r >> 2) + 4 * h;
+              const int ql = qw + 32 * T + (r & 3) + 8 * (r >> 2) + 4 * h;
               if (tOk && a > thr && Q0 + ql < nQ) {
                 const int slot = atomicAdd(&cnt[ql], 1);
                 if (slot < MW_CP) lists[(size_t)slot * capl + Q0 + ql] = ((uint32_t)((256 - a) >> 1) << 16) | (uint32_t)e;
@@ -2836,7 +2864,10 @@ __global__ __launch_bounds__(256) void k_match_bf_mfma(const int* __restrict__ p
     if (c > MW_CP) atomicOr(&W[3], 1);
     cntOut[q] = min(c, MW_CP) | (1 << 16);  // (bit 16: vIndices2 of the query is not empty -- nT > 0 here)
   }
-  if (t < 4 && Q0 + 64 * t < nQ) atomicOr(&W[9 + ((4 * blockIdx.x + t) >> 5)], 1 << ((4 * blockIdx.x + t) & 31));
+  if (t < BF_QWG / 64 && Q0 + 64 * t < nQ) {
+    const int blk = (BF_QWG / 64) * (int)blockIdx.x + t;  // the 64-query block of k_match_wide_lists
+    atomicOr(&W[9 + (blk >> 5)], 1 << (blk & 31));
+  }
 }
 
 // k_match_wide_sort: every query's candidate list (k_match_wide_lists: at most MW_CP entries in no particular order) sorted by
@@ -3486,7 +3517,7 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
                        scratch, stride, capl);
   if (wideMode != 0) {
     if (!mp.noMfma)
-      hipLaunchKernelGGL(k_match_bf_mfma, dim3((capl + 255) / 256, nPairs), dim3(256), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
+      hipLaunchKernelGGL(k_match_bf_mfma, dim3((capl + BF_QWG - 1) / BF_QWG, nPairs), dim3(BF_T), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
                          nmatches, scratch, scratch, stride, capl);
     hipLaunchKernelGGL(k_match_wide_lists, dim3((capl + 63) / 64, nPairs), dim3(256), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
                        nmatches, scratch, scratch, stride, capl);

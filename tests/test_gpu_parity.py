@@ -239,7 +239,7 @@ def test_brute_force_match_configs(orbx, ext640, oracle):
 
 
 def test_brute_force_on_the_matrix_cores(orbx, oracle):
-    """k_match_bf_mfma takes the blocks of 256 queries whose windows cover every train, in launches with at least 128 such blocks
+    """k_match_bf_mfma takes the blocks of 256 queries whose windows cover every train, in launches with at least 256 such blocks
     (fewer stay on k_match_wide_lists): 64 pairs of two to five blocks in one call, every pair different -- set sizes that are no multiple of 256, 64
     or 32, descriptors from few prototypes (many candidates per query, lists that overflow and send the pair to the reference's
     loop), other octaves mixed in -- against the oracle pair by pair, and the same call on the vector form (knob match_no_mfma).
@@ -294,19 +294,19 @@ def test_brute_force_on_the_matrix_cores(orbx, oracle):
             else:
                 protos = rng.integers(0, 256, (n, 32), dtype=np.uint8)
                 sets.append(_clustered_desc_pair(orbx, rng, n, protos, 40, W, H, 1.0 if i % 3 else 0.8, 4))
-        o1 = run(sets, 8192, 0.9, True)
+        o1 = run(sets, 8192, 0.9, True, reps=2)  # (128 pairs of two to five blocks: the 256 blocks the kernel wants)
         assert sum(int((m >= 0).sum()) for m in o1[0][0]) > P * 100
         # a window the middle of the frame passes: |x - bbx0| < r and |x - bbx1| < r need x in (W - r, r)
         sets2 = []
         for (k1, d1, k2, d2) in sets:
             o = np.argsort(k1["x"], kind="stable")
             sets2.append((k1[o], d1[o], k2, d2))
-        run(sets2, 2600, 0.8, False)
+        run(sets2, 2600, 0.8, False, reps=2)
         # one block of fewer than 256 queries per pair (the last waves without a query), trains that are no multiple of 32, every
-        # pair three times in the launch so that it has its 128 blocks
+        # pair five times in the launch so that it has its 256 blocks
         sets3 = [(k1[:int(rng.integers(70, 250))], d1, k2, d2) for (k1, d1, k2, d2) in sets[:48]]
         sets3 = [(k1, d1[:len(k1)], k2, d2) for (k1, d1, k2, d2) in sets3] + sets[48:]
-        run(sets3, 8192, 0.9, True, reps=3)
+        run(sets3, 8192, 0.9, True, reps=5)
     finally:
         orbx.debug_set("match_no_mfma", None)
         ext.close()
