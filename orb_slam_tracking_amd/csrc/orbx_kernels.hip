@@ -2626,7 +2626,8 @@ __global__ __launch_bounds__(256) void k_match_wide_lists(const int* __restrict_
 // k_match_wide_lists (header [9..10]: one bit per 64 queries listed here).
 // Built for candidates that are one pair in thousands.  Where they come by the hundred per query (BASELINE config 3's synthetic
 // frames repeat their corners: every ninth pair is nearer than dmax) the appends dominate and the vector form is faster -- 64 such
-// pairs of 1080p frames in one call: 0.47 against 0.32 ms for the matching stage, 54.7 k against 56.2 k frames/s
+// pairs of 1080p frames in one launch (measured with four waves of 64 queries and the rule at 128 blocks): 0.47 against 0.32 ms for the
+// matching stage, 54.7 k against 56.2 k frames/s
 // (tools/exp_c3_dense.py; config 3 as benchmarked, 16 pairs per call, stays below the 256 blocks).  Giving such blocks back was tried
 // (a wave counting its first tiles' candidates: the first tile says nothing, those frames' candidates sit further down the train
 // list; counting while listing cost the sparse case 7 %) and left out.
