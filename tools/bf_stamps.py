@@ -13,7 +13,7 @@ sets = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 L = orbx.lib()
 bf, data = BC.measure_bf(steps=3, device=0, sets=sets)
 torch.cuda.synchronize()
-nw = min(4096, sets * 8 * 4)
+nw = 4096
 buf = np.zeros((nw, 8), np.uint32)
 L.orbx_diag_bf_stamps(ctypes.c_void_p(buf.ctypes.data), nw)
 ok = buf[:, 5] > 0
