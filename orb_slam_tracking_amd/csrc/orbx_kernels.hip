@@ -2879,7 +2879,7 @@ __global__ __launch_bounds__(BF_T) void k_match_bf_mfma(const int* __restrict__ 
 // -- 140 us for eight pairs on eight CUs).
 static_assert(MW_CP == 128, "k_match_wide_sort: two list entries per lane");
 __global__ __launch_bounds__(256) void k_match_wide_sort(const MatchParams mp, const int* __restrict__ nmatchesOut, int* __restrict__ scratch,
-                                                        long long scratchStride, int capl) {
+                                                        long long scratchStride, int capl, int qpw) {
   ORBX_SETPRIO();
   const int lane = threadIdx.x & 63;
   const int pair = blockIdx.y + mp.pair0;
@@ -2888,11 +2888,18 @@ __global__ __launch_bounds__(256) void k_match_wide_sort(const MatchParams mp, c
   if (S[2] | S[3]) return;  // (the reference's loop takes the pair: k_match_wide_resolve)
   const uint4* trec = reinterpret_cast<const uint4*>(S + MW_HDR);
   const int nQ = S[0];
-  for (int qi = 0; qi < 4; qi++) {  // (four queries per wave: a quarter of the workgroups, most of which find no query at all)
-  const int q = blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + qi;
-  if (q >= nQ) return;
-  const int nc = S[MW_HDR + 5 * capl + q] & 0xffff;
-  if (nc < 2) continue;
+  // qpw queries per wave (launch_match: 4, or 16 in a large launch -- sparse lists leave most waves nothing to sort, and 8000
+  // workgroups that only look and leave cost 12 us per 64 sets of 2000): the lanes look at the wave's counts together, the wave
+  // then visits the lists with two entries or more
+  const int qBase = ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * qpw;
+  if (qBase >= nQ) return;
+  const int ncMine = lane < qpw && qBase + lane < nQ ? (S[MW_HDR + 5 * capl + qBase + lane] & 0xffff) : 0;
+  unsigned long long todo = __ballot(ncMine >= 2);
+  while (todo != 0ull) {
+  const int qi = (int)__builtin_ctzll(todo);
+  todo &= todo - 1ull;
+  const int q = qBase + qi;
+  const int nc = __builtin_amdgcn_readlane(ncMine, qi);
   uint32_t* myList = reinterpret_cast<uint32_t*>(S + MW_HDR + 6 * capl) + q;
   unsigned long long v[2];
 #pragma unroll
@@ -3522,7 +3529,9 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
                          nmatches, scratch, scratch, stride, capl);
     hipLaunchKernelGGL(k_match_wide_lists, dim3((capl + 63) / 64, nPairs), dim3(256), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
                        nmatches, scratch, scratch, stride, capl);
-    hipLaunchKernelGGL(k_match_wide_sort, dim3((capl + 15) / 16, nPairs), dim3(256), 0, st, mp, nmatches, scratch, stride, capl);
+    const int qpw = (long long)nPairs * capl >= 100000 ? 16 : 4;  // queries per wave of k_match_wide_sort
+    hipLaunchKernelGGL(k_match_wide_sort, dim3((capl + 4 * qpw - 1) / (4 * qpw), nPairs), dim3(256), 0, st, mp, nmatches, scratch, stride,
+                       capl, qpw);
     hipLaunchKernelGGL(k_match_wide_resolve, dim3(nPairs), dim3(MW_T), lds, st, dFirst, dSecond, kps, desc, nkp, mp, matches12,
                        nmatches, stats, scratch, stride, capl);
   }
