@@ -706,19 +706,21 @@ __global__ __launch_bounds__(FAST_T) void k_fast(const uint8_t* __restrict__ img
 // (~400 workgroups per microsecond chip-wide), which is why nothing done inside that kernel ever moved its 0.34 ms.
 // Here a wave owns the cell:
 //   * prologue = one s_load_dwordx8 of the cell record the host precomputed (FastCell);
-//   * the cell image (<= 64 rows x 16 dwords) is staged with eight dword loads per lane in flight;
+//   * the cell image (<= 64 rows x 16 dwords) is staged lane = tile row, three 16-byte loads per lane in flight;
 //   * the quick reject works on quads of four horizontally adjacent pixels per lane (dword LDS reads, packed 16-bit
-//     arithmetic); its survivors go through a ring in LDS (ballot + mbcnt compaction, no atomics) and are evaluated 64 at a
+//     arithmetic); its survivors go onto a stack in LDS (ballot + mbcnt compaction, no atomics) and are evaluated 64 at a
 //     time as soon as a full wave of them is waiting, so no list of all pixels is kept;
 //   * corners enter the strength map and a corner list (<= 256; a fuller cell is scanned instead), in-cell NMS runs over
 //     that list, survivors are stored straight into the cell's segment;
-//   * list appends are unconditional stores (a lane with nothing to append writes its own dummy slot): no exec-mask
-//     juggling and no branches in the hot loops;
+//   * list appends are stores under exec = the ballot (round 6; before: unconditional stores, a lane with nothing to append
+//     writing its own dummy slot), so the hot loops select no addresses and rebuild no lane bits;
 //   * workgroup -> cell map is XCD-aware (see the kernel).
 // Same arithmetic and the same outputs (a cell's survivors in another order, which the selection stage does not see).
 // Preconditions (launch_fast): 4-byte aligned level-0 rows, every cell image <= 61 x 64 pixels; otherwise k_fast runs.
 // -------------------------------------------------------------------------------------------------
-#define FW_RING 128   // quick-reject ring, entries (u16 tile offsets): fewer than 64 waiting + at most 64 new ones per append
+#define FW_RING 192   // survivor stack, entries (u16 LDS addresses): fewer than 64 waiting + at most 128 new ones per half step
+                      // (LDS is granted in pieces of 1280 bytes on gfx950: at 640x480 the kernel's 6208 bytes are five of them, 25
+                      // waves per CU; with a stack of 320 entries it took six and ran 21)
 #define FW_CORN 256   // corner list, entries
 #ifndef FW_CPW
 #define FW_CPW 1      // consecutive cells per wave (measured per 256 frames: 1: 0.275 ms, 2: 0.288, 4: 0.316, 8: 0.361: the tail grows)
@@ -734,14 +736,53 @@ __device__ __forceinline__ int fwMbcnt(unsigned long long m) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// arc strength of the pixel at p (tile row stride TS): max over the 16 arcs of 9 contiguous ring pixels of the
-// smallest |difference| with one sign, as in k_fast
+// LDS through 32-bit addresses (round 6): k_fast_wave carries a pixel as the LDS ADDRESS of the top-left byte of the 7 x 7 block
+// around it, so that every read of the quick reject, of the arc strength and of the NMS is an immediate offset from one
+// register (the 16-bit offset field of the DS instructions is unsigned: with centre-relative offsets half of the ring reads
+// needed an address register each)
+typedef __attribute__((address_space(3))) uint8_t fw_lds_u8;
+typedef __attribute__((address_space(3))) uint16_t fw_lds_u16;
+typedef __attribute__((address_space(3))) uint32_t fw_lds_u32;
+__device__ __forceinline__ const fw_lds_u8* fwLds8(const uint32_t a) { return reinterpret_cast<const fw_lds_u8*>((size_t)a); }
+__device__ __forceinline__ const fw_lds_u16* fwLds16(const uint32_t a) { return reinterpret_cast<const fw_lds_u16*>((size_t)a); }
+__device__ __forceinline__ const fw_lds_u32* fwLds32(const uint32_t a) { return reinterpret_cast<const fw_lds_u32*>((size_t)a); }
+// store by the lanes of a SCALAR mask (a ballot, cut down by scalar masks): exec = m around one DS write -- no vector
+// instruction selects an address or rebuilds the lane's own bit (all 64 lanes are active where these are used)
+__device__ __forceinline__ void fwStoreB16(const uint32_t addr, const uint32_t val, const unsigned long long m) {
+  unsigned long long saved;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0"
+               : "=&s"(saved)
+               : "s"(m), "v"(addr), "v"(val)
+               : "memory");
+}
+__device__ __forceinline__ void fwStoreB8(const uint32_t addr, const uint32_t val, const unsigned long long m) {
+  unsigned long long saved;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b8 %2, %3\n\ts_mov_b64 exec, %0"
+               : "=&s"(saved)
+               : "s"(m), "v"(addr), "v"(val)
+               : "memory");
+}
+// ballots of the sign bits of a packed pair of 16-bit values: one compare each
+__device__ __forceinline__ unsigned long long fwNegLo(const uint32_t x) {
+  unsigned long long m;
+  asm("v_cmp_gt_i16_e64 %0, 0, %1" : "=s"(m) : "v"(x));
+  return m;
+}
+__device__ __forceinline__ unsigned long long fwNegHi(const uint32_t x) {
+  unsigned long long m;
+  asm("v_cmp_gt_i32_e64 %0, 0, %1" : "=s"(m) : "v"(x));
+  return m;
+}
+
+// arc strength of the pixel whose 7 x 7 block starts at LDS address e (tile row stride TS): max over the 16 arcs of 9
+// contiguous ring pixels of the smallest |difference| with one sign, as in k_fast
 template <int TS>
-__device__ __forceinline__ int fwStrength(const uint8_t* p) {
-  constexpr int RS = TS;
-  constexpr int ro[16] = {3 * RS,      3 * RS + 1,  2 * RS + 2,  RS + 3,  3,       -RS + 3,     -2 * RS + 2, -3 * RS + 1,
-                          -3 * RS,     -3 * RS - 1, -2 * RS - 2, -RS - 3, -3,      RS - 3,      2 * RS - 2,  3 * RS - 1};
-  const int v = p[0];
+__device__ __forceinline__ int fwStrength(const uint32_t e) {
+  constexpr int C = 3 * TS + 3;
+  constexpr int ro[16] = {C + 3 * TS,  C + 3 * TS + 1, C + 2 * TS + 2, C + TS + 3, C + 3,  C - TS + 3, C - 2 * TS + 2, C - 3 * TS + 1,
+                          C - 3 * TS,  C - 3 * TS - 1, C - 2 * TS - 2, C - TS - 3, C - 3,  C + TS - 3, C + 2 * TS - 2, C + 3 * TS - 1};
+  const fw_lds_u8* const p = fwLds8(e);
+  const int v = p[C];
   int d[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) d[k] = v - (int)p[ro[k]];
@@ -801,19 +842,35 @@ __device__ uint32_t g_fastStamps[FW_STAMP_WAVES * 12];
 // wide (cells of ~36 px: every frame size from VGA up), else 64.
 // One wave = one workgroup = FW_CPW consecutive cells: single-wave workgroups retire on their own (a 4-wave workgroup holds
 // its LDS until its slowest wave is done).
+//
+// Round 6 (the kernel is bound by vector-instruction issue, so only fewer instructions help; the sweep's step
+// went from ~100 vector instructions with survivors / 63 without to ~60 / 40, an evaluation of 64 survivors from ~155 to ~125):
+//   * a lane's position in the sweep is ONE register, quad column << 16 | LDS address: the step to the lane's next quad is an
+//     add, the wrap into the next tile row an add and an unsigned min (a position whose column has not passed the row's end
+//     underflows in the second add), nine vector instructions before;
+//   * the quick reject's nine dword reads and the strength's seventeen byte reads are immediate offsets from one address
+//     register each (a pixel is carried as the LDS address of the top-left byte of its 7 x 7 block);
+//   * the verdicts are not folded into four bits per lane any more: the four pixels' ballots are four sign compares of the two
+//     packed test words, and pixels beyond a row's end and the idle lanes of the last step are taken out of the BALLOTS by
+//     scalar masks (the last quad of a row is one compare per step that has survivors) instead of out of the lanes' bits;
+//   * survivors are appended by exec-masked stores (exec = the ballot: fwStoreB16) to a STACK of LDS addresses -- no ring index
+//     to wrap, no per-lane slot select -- and evaluated 64 from the top as soon as 64 are waiting, twice per step;
+//   * corners enter the strength map and the corner list the same way.
 template <int TS>
 __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ img0, long long img0FrameStride,
                                                   const uint8_t* __restrict__ pyr, const Geom g,
                                                   const FastCell* __restrict__ cells, uint32_t* __restrict__ cand,
                                                   int* __restrict__ cellCount, const int tileBytes, const int smapBytes) {
-  // tile[tileBytes] | strength map[smapBytes] | ring u16[FW_RING + 64] | corner list u16[FW_CORN + 64]
-  // (the 64 extra entries of the two lists are the per-lane dummy slots)
+  // 16 bytes (a lane's address may point one dword in front of the tile) | tile[tileBytes] | strength map[smapBytes] |
+  // survivor stack u16[FW_RING] | corner list u16[FW_CORN]
   extern __shared__ __attribute__((aligned(16))) uint8_t fwLds[];
   const int lane = threadIdx.x;
-  uint8_t* const tile = fwLds;
+  uint8_t* const tile = fwLds + 16;
   uint8_t* const smap = tile + tileBytes;
-  uint16_t* const ring = reinterpret_cast<uint16_t*>(smap + smapBytes);
-  uint16_t* const corn = ring + FW_RING + 64;
+  const uint32_t ldsBase = (uint32_t)(size_t)(fw_lds_u8*)fwLds;
+  const uint32_t tileAddr = ldsBase + 16u, smapAddr = tileAddr + (uint32_t)tileBytes;
+  const uint32_t ringAddr = smapAddr + (uint32_t)smapBytes, cornAddr = ringAddr + 2u * FW_RING;
+  const uint32_t ringLane = ringAddr + 2u * (uint32_t)lane;
   // XCD-aware group order.  Workgroups go round-robin to the 8 XCDs (the grid's x size is a multiple of 8 * FW_XK), so the
   // workgroups with equal (blockIdx.x & 7) share an L2.  Each XCD takes every eighth RUN of FW_XK consecutive groups (16
   // cells, about one cell row of the lowest level): horizontally adjacent cells, which overlap by 6 px and share cache lines,
@@ -871,36 +928,44 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
   FW_STAMP(0);
 
   constexpr int RS = TS;
-  // a pixel is carried as its byte offset in the tile: (py + 3) * TS + xoff + px + 3; its strength-map byte is at
-  // (py + 1) * TS + px + 1 = offset - smOff
-  const int smOff = 2 * TS + xoff + 2;
+  // a pixel's tile offset is o = (py + 3) * TS + xoff + px + 3; it is carried as e = tileAddr + o - (3 * TS + 3), the LDS address
+  // of the top-left byte of its 7 x 7 block; its strength-map byte is at smap + (py + 1) * TS + px + 1 = LDS address e + kS, the
+  // 3 x 3 block around that at e + kN + {0, 1, 2} + {0, TS, 2 TS}
+  const uint32_t kN = smapAddr - tileAddr - (uint32_t)xoff, kS = kN + (uint32_t)(TS + 1);
+  const uint32_t eIdle = tileAddr + (uint32_t)xoff;  // the first pixel: what idle lanes evaluate
   // The quick reject works on QUADS of four horizontally adjacent pixels per lane: the quad's rows come from LDS as dwords
   // (8 reads per 4 pixels instead of 20 byte reads) and the test runs on packed 16-bit pairs.  Item = (quad column, row);
   // idx += 64  <=>  (qc, qy) += (dqc, dqy) with one wrap at most.
   const int nqc = (iw + 3) >> 2, nItems = nqc * ih;
   const uint32_t inv = c_inv20.v[nqc];  // nqc <= 15
   const int qy0 = (int)(((uint32_t)lane * inv) >> 20), qc0 = lane - qy0 * nqc;
-  const int dqy = (int)((64u * inv) >> 20), dqc = 64 - dqy * nqc;
-  const int sh = (xoff + 3) & 3;                       // byte phase of a quad's first pixel inside its dword (wave-uniform)
-  const int offA0 = (qy0 + 3) * TS + xoff + 3 - sh + 4 * qc0;  // dword-aligned tile offset of the quad's first pixel
-  const int dOffA = dqy * TS + 4 * dqc;
-  const int offIdle = 3 * TS + xoff + 3 - sh;  // quad (0, 0): what idle lanes read
+  const int dqy = (int)((64u * inv) >> 20), dqc = 64 - dqy * nqc;  // dqc = 64 mod nqc < nqc
+  const int sh = (xoff + 3) & 3;  // byte phase of a quad's first pixel inside its dword (wave-uniform)
+  // a lane's position: quad column << 16 | LDS address a of the dword in front of the quad's first dword, three tile rows up (the
+  // reads below are a[1], a[2] (top), a[3 TS / 4 .. + 2] (centre row) and a[6 TS / 4 + 1, + 2] (bottom); the quad's first pixel is
+  // at a + 3 TS + 4 + sh).  Next item: += dPos; a column at or beyond nqc wraps into the next row: += wrapK -- for a column that
+  // has not passed the row's end that sum underflows into a huge value, so the unsigned minimum of the two keeps the right one.
+  const uint32_t pos0 = ((uint32_t)qc0 << 16) | (tileAddr + (uint32_t)(qy0 * TS + xoff + 3 - sh + 4 * qc0 - 4));
+  const uint32_t dPos = ((uint32_t)dqc << 16) | (uint32_t)(dqy * TS + 4 * dqc);
+  const uint32_t wrapK = (uint32_t)(TS - 4 * nqc) - ((uint32_t)nqc << 16);
+  const uint32_t lastThr = (uint32_t)(nqc - 1) << 16;          // positions at or above: the row's last quad
+  const int nvLast = iw - 4 * (nqc - 1);                        // pixels of a row's last quad that lie inside the row (1 .. 4)
+  const uint32_t aLast = tileAddr + (uint32_t)((ih - 1) * TS + xoff + 3 - sh + 4 * (nqc - 1) - 4);  // the last item's address
   // v_perm_b32 selectors (SGPRs): two tap bytes -> the halves of a u16 pair (0x0c = constant 0).  Centre / top / bottom bytes
   // sh + {0..3} of the dword pair at the quad; left compass bytes sh + 1 + {0..3} of the pair one dword to the left; right
   // compass bytes sh + 3 + {0..3} of the pair at the quad (sh <= 1) or sh - 1 + {0..3} of the pair one dword to the right
   const uint32_t selC0 = 0x0c000c00u + (uint32_t)sh * 0x00010001u + 0x00010000u, selC1 = selC0 + 0x00020002u;
   const uint32_t selL0 = selC0 + 0x00010001u, selL1 = selL0 + 0x00020002u;
   const bool rNear = sh <= 1;
-  const int rOff = rNear ? 0 : 1;
+  const uint32_t rOff4 = rNear ? 0u : 4u;
   const uint32_t selR0 = 0x0c000c00u + (uint32_t)(rNear ? sh + 3 : sh - 1) * 0x00010001u + 0x00010000u, selR1 = selR0 + 0x00020002u;
-  const int off0 = 3 * TS + xoff + 3;  // a valid pixel offset for idle lanes
   uint32_t* const dstc = cand + L.candOff + (long long)f * L.candCap + c.segOff;
   const int segCap = (int)c.segCap;
   int nOut = 0;
   for (int pass = 0; pass < 2; pass++) {
     const int th = pass == 0 ? g.iniTh : g.minTh;
     const uint32_t th2 = (uint32_t)th * 0x00010001u;
-    int head = 0, nList = 0, nCorn = 0;  // wave-uniform (SGPRs)
+    int nList = 0, nCorn = 0;  // wave-uniform (SGPRs)
     // A cell without a survivor at iniThFAST is swept again at minThFAST (cpp:1117-1123) -- on real images that is every second
     // cell, and in a flat region the second sweep lists nothing either.  While the first sweep has not listed a pixel yet (`flat`,
     // wave-uniform), it also keeps the minimum of its two test values e = (v + th) - max side and (min side + th) - v: a pixel
@@ -909,37 +974,46 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
     // are not masked out of the minimum: a false "some pixel passes" only costs the second sweep, which then decides as before.
     bool flat = pass == 0 && ORBX_FAST_FLATSKIP;
     short2v looseMin = {0x7fff, 0x7fff};
-    // evaluates the `cnt` oldest ring entries: exact strength; corners (s > th) enter the strength map and the corner list
+    // evaluates the `cnt` newest entries of the survivor stack (64, or what is left at the end): exact strength; corners
+    // (s > th) enter the strength map and the corner list
     auto flush = [&](const int cnt) {
       __builtin_amdgcn_wave_barrier();
-      const bool act = lane < cnt;
-      const int o = act ? (int)ring[(head + lane) & (FW_RING - 1)] : off0;
-      const int sv = fwStrength<TS>(tile + o);
-      const bool corner = act && sv > th;
-      // (a lane without a corner stores into its dummy slot behind the ring: unconditional store, no exec-mask juggling)
-      *(corner ? smap + (o - smOff) : reinterpret_cast<uint8_t*>(ring + FW_RING + lane)) = (uint8_t)sv;
-      const unsigned long long mc = __ballot(corner);
-      const int pos = nCorn + fwMbcnt(mc);
-      corn[(corner && pos < FW_CORN) ? pos : FW_CORN + lane] = (uint16_t)o;
-      nCorn += (int)__popcll(mc);
-      head = (head + cnt) & (FW_RING - 1);
-      nList -= cnt;
+      const int keepN = nList - cnt;
+      uint32_t e = (uint32_t)fwLds16(ringLane)[keepN];
+      unsigned long long act = ~0ull;
+      if (cnt < 64) {  // (uniform)
+        asm volatile("" ::: "memory");
+        act = (1ull << cnt) - 1ull;
+        e = lane < cnt ? e : eIdle;
+      }
+      const int sv = fwStrength<TS>(e);
+      const unsigned long long mc = __ballot(sv > th) & act;
+      if (mc != 0ull) {
+        fwStoreB8(e + kS, (uint32_t)sv, mc);
+        const int nc = (int)__popcll(mc);
+        if (nCorn + nc <= FW_CORN) fwStoreB16((cornAddr + 2u * (uint32_t)nCorn) + 2u * (uint32_t)fwMbcnt(mc), e, mc);
+        nCorn += nc;
+      }
+      nList = keepN;
     };
-    // ---- quick reject on the 4 compass pixels (an arc of 9 holds two adjacent ones), survivors into the ring ----
+    // ---- quick reject on the 4 compass pixels (an arc of 9 holds two adjacent ones), survivors onto the stack ----
     {
-      int qc = qc0, offA = offA0;
-      const uint32_t* const t32 = reinterpret_cast<const uint32_t*>(tile);
+      uint32_t pos = pos0;
       for (int idx0 = 0; idx0 < nItems; idx0 += 64) {
-        // (idle lanes of the last step would run up to 63 quads beyond the cell -- with one quad per row, beyond the LDS
-        // allocation: they read the cell's first quad instead, their verdicts are masked below)
-        const bool live = idx0 + lane < nItems;
-        const int wA = (live ? offA : offIdle) >> 2;  // dword index of the quad's first pixel's dword
-        const uint32_t cM = t32[wA - 1], c0 = t32[wA], c1 = t32[wA + 1];
-        const uint32_t t0 = t32[wA - 3 * (TS / 4)], t1 = t32[wA - 3 * (TS / 4) + 1];
-        const uint32_t b0 = t32[wA + 3 * (TS / 4)], b1 = t32[wA + 3 * (TS / 4) + 1];
+        uint32_t a = pos & 0xffffu;
+        const bool tail = idx0 + 64 > nItems;  // (uniform) the step with idle lanes: they read the last item again, masked below
+        if (tail) {
+          asm volatile("" ::: "memory");
+          a = min(a, aLast);
+        }
+        const fw_lds_u32* const pa = fwLds32(a);
+        const uint32_t t0 = pa[1], t1 = pa[2];
+        const uint32_t cM = pa[3 * (TS / 4)], c0 = pa[3 * (TS / 4) + 1], c1 = pa[3 * (TS / 4) + 2];
+        const uint32_t b0 = pa[6 * (TS / 4) + 1], b1 = pa[6 * (TS / 4) + 2];
         // the dword pair that holds the right compass pixels: read again at a wave-uniform offset (an LDS read instead of two
         // v_cndmask on the vector port, which is the port this kernel is bound by)
-        const uint32_t rlo = t32[wA + rOff], rhi = t32[wA + rOff + 1];
+        const fw_lds_u32* const pr = fwLds32(a + rOff4);
+        const uint32_t rlo = pr[3 * (TS / 4) + 1], rhi = pr[3 * (TS / 4) + 2];
         uint32_t fl[2];
         short2v em[2];
 #pragma unroll
@@ -955,36 +1029,35 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
           const ushort2v hi = vV + __builtin_bit_cast(ushort2v, th2);
           const short2v e1 = __builtin_bit_cast(short2v, hi) - __builtin_bit_cast(short2v, mx);                      // < 0: mx > hi
           const short2v e2 = __builtin_bit_cast(short2v, mn) + __builtin_bit_cast(short2v, th2) - __builtin_bit_cast(short2v, vV);  // < 0: mn < lo
-          fl[hp] = (__builtin_bit_cast(uint32_t, e1) | __builtin_bit_cast(uint32_t, e2)) & 0x80008000u;
+          fl[hp] = __builtin_bit_cast(uint32_t, e1) | __builtin_bit_cast(uint32_t, e2);  // sign bits: the two pixels' verdicts
           em[hp] = __builtin_elementwise_min(e1, e2);
         }
         if (flat) {  // (uniform; the empty asm keeps it a branch -- as a select it would cost every step of every cell five instructions)
           asm volatile("" ::: "memory");
           looseMin = __builtin_elementwise_min(looseMin, __builtin_elementwise_min(em[0], em[1]));
         }
-        // the quad's four verdicts as bits 0..3, cleared for pixels beyond the row's end and for idle lanes
-        const int nv = live ? min(iw - 4 * qc, 4) : 0;
-        // fl[hp] holds its two verdicts in bits 15 and 31: (fl0 >> 15) | (fl1 >> 13) has them in bits 0, 16 and 2, 18; folding the
-        // upper half down by 15 puts all four into bits 0 .. 3 (what lies above is masked off)
-        const uint32_t fx = (fl[0] >> 15) | (fl[1] >> 13);
-        const uint32_t bits = (fx | (fx >> 15)) & ((1u << nv) - 1u);
-        const int offP = offA + sh;  // tile offset of the quad's first pixel
-        if (__ballot(bits != 0u) != 0ull) {  // (wave-uniform) a step without any survivor appends nothing
-        flat = false;
+        if (__ballot(((fl[0] | fl[1]) & 0x80008000u) != 0u) != 0ull) {  // (wave-uniform) a step without any survivor appends nothing
+          flat = false;
+          // what the ballots must not count: pixels beyond the row's end (the last quad of a row holds nvLast pixels of it) and the
+          // idle lanes of the last step
+          unsigned long long keepEnd = ~0ull;
+          if (nvLast < 4) keepEnd = ~__ballot(pos >= lastThr);
+          const unsigned long long live = tail ? (1ull << (nItems - idx0)) - 1ull : ~0ull;
+          const uint32_t q0 = a + (uint32_t)(sh + 1);  // the quad's first pixel as a stack entry
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const bool cj = (bits >> j) & 1u;
-          const unsigned long long m = __ballot(cj);
-          if (m != 0ull) {  // (wave-uniform) most steps of a flat region have no survivor at all: nothing to append
-            ring[cj ? ((head + nList + fwMbcnt(m)) & (FW_RING - 1)) : FW_RING + lane] = (uint16_t)(offP + j);
-            nList += (int)__popcll(m);
-            if (nList >= 64) flush(64);
+          for (int j = 0; j < 4; j++) {
+            unsigned long long m = ((j & 1) ? fwNegHi(fl[j >> 1]) : fwNegLo(fl[j >> 1])) & live;
+            if (j >= nvLast) m &= keepEnd;
+            if (m != 0ull) {  // (wave-uniform)
+              fwStoreB16((ringAddr + 2u * (uint32_t)nList) + 2u * (uint32_t)fwMbcnt(m), q0 + (uint32_t)j, m);
+              nList += (int)__popcll(m);
+            }
+            if (j & 1)
+              while (nList >= 64) flush(64);
           }
         }
-        }
-        qc += dqc;
-        offA += dOffA;
-        if (qc >= nqc) { qc -= nqc; offA += TS - 4 * nqc; }
+        pos += dPos;
+        pos = min(pos, pos + wrapK);
       }
       FW_STAMP(1);
       if (nList > 0) flush(nList);
@@ -992,18 +1065,19 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
     __builtin_amdgcn_wave_barrier();
     FW_STAMP(2);
     // ---- in-cell NMS on the strength map; survivors are the cell's keypoints ----
-    auto nms = [&](const int oIn, const bool act) {
-      const int o = act ? oIn : off0;
-      const uint8_t* q = smap + (o - smOff);
+    auto nms = [&](const uint32_t eIn, const bool act) {
+      const uint32_t e = act ? eIn : eIdle;
+      const fw_lds_u8* const q = fwLds8(e + kN);  // top-left of the 3 x 3 block in the strength map
       // all nine reads are issued together (short-circuit tests would chain nine LDS round trips)
-      const int sv = q[0];
-      const int n0 = q[-RS - 1], n1 = q[-RS], n2 = q[-RS + 1], n3 = q[-1], n4 = q[1], n5 = q[RS - 1], n6 = q[RS], n7 = q[RS + 1];
+      const int sv = q[RS + 1];
+      const int n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[RS], n4 = q[RS + 2], n5 = q[2 * RS], n6 = q[2 * RS + 1], n7 = q[2 * RS + 2];
       const int nmax = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
       const bool keep = act && sv > 1 && sv > nmax;
       const unsigned long long mk = __ballot(keep);
       if (keep) {
         const int slot = nOut + fwMbcnt(mk);
         // tile row = y - oy, tile column = x - ox; o / TS by multiply-shift (exact for o < 2^12)
+        const int o = (int)(e - tileAddr) + 3 * TS + 3;
         const int row = TS == 64 ? (o >> 6) : (int)(((uint32_t)o * 43691u) >> 21);
         static_assert(TS == 64 || TS == 48, "row split of a tile offset");
         if (slot < segCap) dstc[slot] = packCand(o - row * TS + ox, row + oy, sv - 1);
@@ -1011,21 +1085,22 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
       nOut += (int)__popcll(mk);
     };
     if (nCorn <= FW_CORN) {
-      for (int e0 = 0; e0 < nCorn; e0 += 64) nms((int)corn[min(e0 + lane, FW_CORN - 1)], e0 + lane < nCorn);
+      for (int e0 = 0; e0 < nCorn; e0 += 64) nms((uint32_t)fwLds16(cornAddr)[min(e0 + lane, FW_CORN - 1)], e0 + lane < nCorn);
     } else {  // more corners than the list holds (noise at a low threshold): scan the strength map instead
       const uint32_t invw = c_inv20.v[iw];
       const int py0 = (int)(((uint32_t)lane * invw) >> 20), px0 = lane - py0 * iw;
       const int dpy = (int)((64u * invw) >> 20), dpx = 64 - dpy * iw;
-      int px = px0, off = (py0 + 3) * TS + xoff + px0 + 3;
+      int px = px0;
+      uint32_t e = eIdle + (uint32_t)(py0 * TS + px0);
       const int npix = iw * ih;
       for (int idx0 = 0; idx0 < npix; idx0 += 64) {
         const bool live = idx0 + lane < npix;
-        const int sv = live ? (int)smap[off - smOff] : 0;
+        const int sv = live ? (int)fwLds8(e + kS)[0] : 0;
         const unsigned long long any = __ballot(sv > 0);
-        if (any) nms(off, sv > 0);
+        if (any) nms(e, sv > 0);
         px += dpx;
-        off += dpy * TS + dpx;
-        if (px >= iw) { px -= iw; off += TS - iw; }
+        e += (uint32_t)(dpy * TS + dpx);
+        if (px >= iw) { px -= iw; e += (uint32_t)(TS - iw); }
       }
     }
     FW_STAMP(3);
@@ -3441,7 +3516,7 @@ hipError_t launch_fast(hipStream_t st, int nFrames, const uint8_t* img0, long lo
     // (+ 16: the quick reject's dword reads reach a few bytes beyond the last tile row)
     const int tileBytes = ch * ts + 16, smapBytes = (ch - 6 + 2) * ts;
     const int fastPad = (int)knob(KNOB_FAST_LDS_PAD, 0);  // diagnostics: fewer waves per CU
-    const size_t lds = (size_t)(tileBytes + smapBytes + (FW_RING + 64) * 2 + (FW_CORN + 64) * 2) + fastPad;
+    const size_t lds = (size_t)(16 + tileBytes + smapBytes + FW_RING * 2 + FW_CORN * 2) + fastPad;  // k_fast_wave's layout
     const bool dbg = knobOn(KNOB_FAST_DEBUG);
     if (dbg) {
       int nb48 = -1, nb64 = -1;
