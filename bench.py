@@ -146,7 +146,114 @@ def cpu_share():
     return max(1, min(n, 64))
 
 
+class Runner:
+    """The stream-ordered call sequence that is timed: one step = orbx_extract_match_batch_device_async on `B` resident frames and
+    their B / 2 consecutive pairs, `nout` batches in flight on as many output sets.  N > 1 (or --force-collective): the all_gather
+    of batch k's counts (RCCL over xGMI) is issued asynchronously from a snapshot of the counts once batch k has been waited for,
+    i.e. it runs under the kernels of batch k + 1; it is waited for before the next one is issued and before the clock stops."""
+
+    def __init__(self, ext, d_imgs, B, nout, world, coll, cdev, dev, dist, cap=1000):
+        import torch
+        self.ext, self.d_imgs, self.B, self.nout, self.world, self.coll, self.dist, self.cap = ext, d_imgs, B, nout, world, coll, dist, cap
+        # one set of output arrays per batch in flight: the batches are issued stream-ordered, and batches in flight together must
+        # not share their outputs
+        self.outs = [dict(k=torch.zeros(B * cap * 28, dtype=torch.uint8, device=dev), d=torch.zeros(B * cap * 32, dtype=torch.uint8, device=dev),
+                          n=torch.zeros(B, dtype=torch.int32, device=dev), m=torch.zeros((B // 2) * cap, dtype=torch.int32, device=dev),
+                          nm=torch.zeros(B // 2, dtype=torch.int32, device=dev)) for _ in range(nout)]
+        self.first = np.arange(0, B, 2, dtype=np.int32)
+        self.second = self.first + 1
+        self.counts_all = torch.zeros(B * world, dtype=torch.int32, device=cdev)
+        self.snaps = [torch.zeros(B, dtype=torch.int32, device=cdev) for _ in range(2)]
+        self.pending = None
+        self.nstep = 0
+        self.ngathered = 0      # batches whose counts have been gathered
+        self.ngather_calls = 0
+
+    def finish_gather(self):
+        if self.pending is not None:
+            self.pending.wait()
+            self.pending = None
+
+    def gather_counts(self, k):
+        self.finish_gather()
+        snap = self.snaps[k & 1]
+        snap.copy_(self.outs[k % self.nout]["n"])  # batch k has been waited for: its counts are final.  (The copy runs on torch's
+        # stream; the binding orders the context's streams behind it before the next batch rewrites that array: orbx_order_after.)
+        self.pending = self.dist.all_gather_into_tensor(self.counts_all, snap, async_op=True)
+        self.ngather_calls += 1
+
+    def step(self):
+        # one call = the whole hot path of the batch: extraction of B frames and SearchForInitialization of the B / 2
+        # consecutive pairs, issued behind the previous batches (at most `nout` in flight)
+        k, B = self.nstep, self.B
+        o = self.outs[k % self.nout]
+        self.ext.extract_match_batch_device_async(self.d_imgs[k % len(self.d_imgs)], B, W, H, W, W * H, o["k"], o["d"], o["n"], self.first,
+                                                  self.second, (0, W, 0, H), o["m"], o["nm"], None, 100, 0.9, True, self.cap)
+        self.nstep = k + 1
+        if self.coll and k + 1 - self.ngathered >= self.nout:  # as many in flight as there are output sets: wait for the oldest
+            self.ext.wait_one()                                    # (batch ngathered) and gather its counts
+            self.gather_counts(self.ngathered)
+            self.ngathered += 1
+
+    def barrier(self):
+        import torch
+        self.ext.wait()  # every batch issued so far is complete
+        while self.coll and self.ngathered < self.nstep:  # the counts of the last batches (the earlier ones were gathered in step())
+            self.gather_counts(self.ngathered)
+            self.ngathered += 1
+        self.finish_gather()
+        torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed_region(self, steps, cdev):
+        """Exactly `steps` steps between two barriers, the maximum over the ranks (the task contract's protocol)."""
+        import torch
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def release(self):
+        self.d_imgs = None
+        self.outs = None
+
+
+class Skipped(Exception):
+    """A side measurement that was not asked for (a flag, N > 1): recorded in the line, not a failure."""
+
+
+def run_side(out, name, fn, failures):
+    """One of the figures behind the headline (single_frame, host_pipeline, other_configs).  It never keeps the JSON line from being
+    printed -- but a figure that CRASHES is a failure of the run, not a footnote: its error goes into the line
+    and into `failures`, which makes `all_checked` false and the exit code non-zero (final_status)."""
+    try:
+        out[name] = fn()
+    except Skipped as ex:
+        out[name] = {"skipped": str(ex)[:300]}
+    except Exception as ex:
+        out[name] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+        failures.append(name)
+    return out[name]
+
+
+def final_status(check_ok, failures):
+    """(all_checked, exit code) of the run: a mismatch against the oracle anywhere, or a side measurement that raised, is exit 3."""
+    ok = (bool(check_ok) if check_ok is not None else False) and not failures
+    bad = check_ok is False or bool(failures)
+    return ok, (3 if bad else 0)
+
+
 def main():
+    exit_code = 0
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -220,72 +327,15 @@ def main():
     host_sets = synth.bench_input_sets(hi - lo, W, H, 1000 + lo // 2, args.input_sets)
     frames = host_sets[0]
     nsets = len(host_sets)
-    d_imgs = [torch.from_numpy(s).to(dev) for s in host_sets]
-    # one set of output arrays per batch in flight: the batches are issued stream-ordered
-    # (orbx_extract_match_batch_device_async), and batches in flight together must not share their outputs
     # pipeline depth: whole batches on `depth` lanes of the context (orbx_set_pipeline_depth); 0 = two half batches on two streams
     depth = args.depth
     nout = max(2, depth)
-    outs = []
-    for _ in range(nout):
-        outs.append(dict(k=torch.zeros(B * cap * 28, dtype=torch.uint8, device=dev),
-                         d=torch.zeros(B * cap * 32, dtype=torch.uint8, device=dev),
-                         n=torch.zeros(B, dtype=torch.int32, device=dev),
-                         m=torch.zeros((B // 2) * cap, dtype=torch.int32, device=dev),
-                         nm=torch.zeros(B // 2, dtype=torch.int32, device=dev)))
-    first = np.arange(0, B, 2, dtype=np.int32)
-    second = first + 1
-    counts_all = torch.zeros(B * world, dtype=torch.int32, device=cdev)
 
     ext = orbx.ORBextractor(*PARAMS, max_width=W, max_height=H, max_batch=B, device=local_rank)
     if depth > 0:
         ext.set_pipeline_depth(depth)
-
-    # N > 1: the all_gather of batch k's counts (RCCL over xGMI) is issued asynchronously from a snapshot of the counts once
-    # batch k has been waited for, i.e. it runs under the kernels of batch k + 1; it is waited for before the next one is
-    # issued and before the clock stops
-    snaps = [torch.zeros(B, dtype=torch.int32, device=cdev) for _ in range(2)]
-    pending = [None]
-    nstep = [0]
-    ngathered = [0]  # batches whose counts have been gathered
-    ngather_calls = [0]
-
-    def finish_gather():
-        if pending[0] is not None:
-            pending[0].wait()
-            pending[0] = None
-
-    def gather_counts(k):
-        finish_gather()
-        snap = snaps[k & 1]
-        snap.copy_(outs[k % nout]["n"])  # batch k has been waited for: its counts are final.  (The copy runs on torch's stream;
-        # the binding orders the context's streams behind it before the next batch rewrites that array: orbx_order_after.)
-        pending[0] = dist.all_gather_into_tensor(counts_all, snap, async_op=True)
-        ngather_calls[0] += 1
-
-    def step():
-        # one call = the whole hot path of the batch: extraction of B frames and SearchForInitialization of the B/2
-        # consecutive pairs, issued behind the previous batches (at most `nout` in flight)
-        k = nstep[0]
-        o = outs[k % nout]
-        ext.extract_match_batch_device_async(d_imgs[k % nsets], B, W, H, W, W * H, o["k"], o["d"], o["n"], first, second, (0, W, 0, H),
-                                             o["m"], o["nm"], None, 100, 0.9, True, cap)
-        nstep[0] = k + 1
-        if coll and k + 1 - ngathered[0] >= nout:  # as many in flight as there are output sets: wait for the oldest
-            ext.wait_one()                              # (batch ngathered) and gather its counts
-            gather_counts(ngathered[0])
-            ngathered[0] += 1
-
-    def barrier():
-        ext.wait()  # every batch issued so far is complete
-        while coll and ngathered[0] < nstep[0]:  # the counts of the last batches (the earlier ones were gathered in step())
-            gather_counts(ngathered[0])
-            ngathered[0] += 1
-        finish_gather()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    run = Runner(ext, [torch.from_numpy(s).to(dev) for s in host_sets], B, nout, world, coll, cdev, dev, dist if coll else None, cap)
+    step, barrier = run.step, run.barrier
 
     # context initialisation, before the contract's W warmup steps: every lane runs its first batches (tables, selection-instance
     # hint, matcher expectation, clocks) -- the driver's W = 5 would otherwise end before the fourth lane has seen its second batch
@@ -311,17 +361,7 @@ def main():
     ext.profile_reset()
 
     def timed_region():
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        return run.timed_region(args.steps, cdev)
 
     dt_first = timed_region()           # the contract's region: exactly --steps steps
     prof = ext.profile_get()
@@ -334,18 +374,18 @@ def main():
     ext.profile_enable(False)
     if stage_prof is None:
         stage_prof, stage_steps = prof, args.steps
-    last = nstep[0] - 1
-    d_n, d_nm = outs[last % nout]["n"], outs[last % nout]["nm"]
+    last = run.nstep - 1
+    d_n, d_nm = run.outs[last % nout]["n"], run.outs[last % nout]["nm"]
     gathered_ok = None
     if coll:  # the last all_gather's result: every rank's block holds the counts of that rank's last batch
-        ca = counts_all.cpu().numpy()
-        gathered_ok = bool(ngather_calls[0] > 0 and (ca > 0).all() and np.array_equal(ca[lo:hi], d_n.cpu().numpy()))
+        ca = run.counts_all.cpu().numpy()
+        gathered_ok = bool(run.ngather_calls > 0 and (ca > 0).all() and np.array_equal(ca[lo:hi], d_n.cpu().numpy()))
 
     # not timed: the last batch's complete output set against the CPU oracle -- every rank its own shard, the
     # verdict reduced to rank 0; a mismatch makes the process exit non-zero behind the JSON line
     check_ok, check_what = None, "skipped (--no-check)"
     if not args.no_check:
-        got = {k_: v.cpu().numpy() for k_, v in outs[last % nout].items()}
+        got = {k_: v.cpu().numpy() for k_, v in run.outs[last % nout].items()}
         try:  # (a rank whose checker cannot run must still reach the all_reduce below: ADVICE r04)
             check_ok, check_what = oracle_check(host_sets[last % nsets], got, max(1, cpu_share() // max(world, 1)))
         except Exception as ex:
@@ -357,6 +397,28 @@ def main():
                 check_ok, check_what = False, "MISMATCH on another rank"
             elif check_ok:
                 check_what = "every rank: " + check_what
+    # N > 1: BASELINE config 4 AS WRITTEN beside the weak-scaling `value` -- ONE batch of 256 frames over the N ranks, 256 / N frames
+    # (and their pairs) per rank and step, same protocol (barrier, exactly --steps steps, barrier, the maximum over the ranks; the
+    # median of three regions), counts all-gathered every step
+    c4w = None
+    if world > 1:
+        B4 = max(2, (256 // world) // 2 * 2)
+        run4 = Runner(ext, [t[:B4] for t in run.d_imgs], B4, nout, world, coll, cdev, dev, dist, cap)
+        for _ in range(2 * nout):
+            run4.step()
+        dt4 = sorted(run4.timed_region(args.steps, cdev) for _ in range(3))[1]
+        ca4 = run4.counts_all.cpu().numpy()
+        lo4, hi4 = sharding.shard_range(B4 * world, world, rank)
+        ok4 = bool(run4.ngather_calls > 0 and (ca4 > 0).all() and
+                   np.array_equal(ca4[lo4:hi4], run4.outs[(run4.nstep - 1) % nout]["n"].cpu().numpy()))
+        t = torch.tensor([1 if ok4 else 0], dtype=torch.int32, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        c4w = {"workload": "ONE batch of %d frames 640x480 / 1000 features over %d ranks: %d frames + %d consecutive-pair matches per rank "
+                           "and step, counts all-gathered" % (B4 * world, world, B4, B4 // 2),
+               "frames_per_step": B4 * world, "frames_per_rank": B4, "frames_per_s": B4 * world * args.steps / dt4,
+               "ms_per_step": dt4 / args.steps * 1e3, "steps": args.steps, "scaling": "strong (the batch is fixed, the ranks share it)",
+               "gathered_counts_ok": bool(int(t.item()) == 1)}
+        run4.release()
     if rank == 0:
         n_kp = float(d_n.float().mean().item())
         nm_mean = float(d_nm.float().mean().item())
@@ -430,7 +492,7 @@ def main():
                        "frames_per_gpu": B, "pairs_per_gpu": B // 2, "mean_keypoints": n_kp, "mean_nmatches": nm_mean,
                        "pipeline_depth": depth, "prime_steps": args.prime,
                        "rccl_ranks": (dist.get_world_size() if coll and args.backend == "nccl" else (0 if world > 1 else 1)),
-                       "collective": ({"backend": args.backend, "world_size": dist.get_world_size(), "all_gathers": ngather_calls[0],
+                       "collective": ({"backend": args.backend, "world_size": dist.get_world_size(), "all_gathers": run.ngather_calls,
                                        "gathered_counts_ok": gathered_ok} if coll else None),
                        "parallelism": "frames sharded per GPU (%d ranks), RCCL all_gather of keypoint counts" % world},
             "spread": {"regions": len(region_dts), "steps_per_region": args.steps, "median": rates[len(rates) // 2],
@@ -446,11 +508,16 @@ def main():
         }
         out["checked"] = bool(check_ok) if check_ok is not None else False
         out["check"] = check_what
+        if c4w is not None:
+            out["config4_as_written"] = c4w
+            if not c4w["gathered_counts_ok"]:
+                check_ok = False
+        failures = []  # side measurements that raised (run_side)
         # second figure: the call the reference actually makes -- one frame per call through the host API
         # (Frame.cpp:58-60: host image in, keypoints + descriptors back on the host), and one SearchForInitialization per call
-        try:
+        def single_frame():
             if args.no_single_frame or world > 1:
-                raise RuntimeError("skipped (--no-single-frame)" if args.no_single_frame else "skipped (N > 1: an N = 1 figure)")
+                raise Skipped("--no-single-frame" if args.no_single_frame else "N > 1: an N = 1 figure")
             e1 = orbx.ORBextractor(*PARAMS, max_width=W, max_height=H, max_batch=1, device=local_rank)
             fa, fb = orbx.Frame(frames[0], 0.0, e1), orbx.Frame(frames[1], 1.0, e1)
             mt = orbx.ORBmatcher(0.9, True)
@@ -464,131 +531,143 @@ def main():
             for _ in range(nrep):
                 mt.SearchForInitialization(fa, fb, 100)
             t2 = time.perf_counter()
-            out["single_frame"] = {"extract_ms_per_frame": (t1 - t0) / nrep * 1e3, "match_ms_per_pair": (t2 - t1) / nrep * 1e3,
-                                   "frames_per_s_extract_only": nrep / (t1 - t0),
-                                   "note": "synchronous host-buffer calls, one 640x480 frame (orbx_extract) / one pair (orbx_match_init) per call, "
-                                           "through the ctypes binding; cpp_shim: the same two calls as the reference makes them "
-                                           "(Frame.cpp:58-60, demo_initialization.cpp:105-108) through include/orbx_shim.hpp from C++ "
-                                           "(tests/cpp/shim_latency.cpp, medians of 300 calls)"}
+            sf = {"extract_ms_per_frame": (t1 - t0) / nrep * 1e3, "match_ms_per_pair": (t2 - t1) / nrep * 1e3,
+                  "frames_per_s_extract_only": nrep / (t1 - t0),
+                  "note": "synchronous host-buffer calls, one 640x480 frame (orbx_extract) / one pair (orbx_match_init) per call, "
+                          "through the ctypes binding; cpp_shim: the same two calls as the reference makes them "
+                          "(Frame.cpp:58-60, demo_initialization.cpp:105-108) through include/orbx_shim.hpp from C++ "
+                          "(tests/cpp/shim_latency.cpp, medians of 300 calls)"}
             e1.close()
-            try:  # the drop-in call from C++: g++ builds the small harness against liborbx.so
-                import subprocess
-                import tempfile
-                sys.path.insert(0, os.path.join(ROOT, "tests"))
-                from test_host import build_shim_latency
-                with tempfile.TemporaryDirectory() as td:
-                    exe = build_shim_latency(orbx.lib_path(), td)
-                    fa, fb = os.path.join(td, "a.raw"), os.path.join(td, "b.raw")
-                    frames[0].tofile(fa)
-                    frames[1].tofile(fb)
-                    r = subprocess.run([exe, str(W), str(H), fa, fb, "1000", "20", "7", "300"], stdout=subprocess.PIPE,
-                                       stderr=subprocess.PIPE, text=True, timeout=120)
-                    out["single_frame"]["cpp_shim"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-200:]}
-            except Exception as ex:
-                out["single_frame"]["cpp_shim"] = {"error": str(ex)[:200]}
-        except Exception as ex:  # never let the second figure break the line
-            out["single_frame"] = {"error": str(ex)[:200]}
+            # the drop-in call from C++: g++ builds the small harness against liborbx.so
+            import subprocess
+            import tempfile
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from test_host import build_shim_latency
+            with tempfile.TemporaryDirectory() as td:
+                exe = build_shim_latency(orbx.lib_path(), td)
+                pa, pb = os.path.join(td, "a.raw"), os.path.join(td, "b.raw")
+                frames[0].tofile(pa)
+                frames[1].tofile(pb)
+                r = subprocess.run([exe, str(W), str(H), pa, pb, "1000", "20", "7", "300"], stdout=subprocess.PIPE,
+                                   stderr=subprocess.PIPE, text=True, timeout=120)
+                if r.returncode != 0:
+                    raise RuntimeError("shim_latency exited %d: %s" % (r.returncode, r.stderr[-200:]))
+                sf["cpp_shim"] = json.loads(r.stdout.strip().splitlines()[-1])
+            return sf
+        run_side(out, "single_frame", single_frame, failures)
         # third figure (SURVEY 8(e) "report host-side time separately"): the same workload with the frames in HOST
         # memory -- what the reference's call site hands over (Frame.cpp:58-60) -- through the stream-ordered host call: page-locked
         # input sets, results into page-locked arrays, `depth` batches in flight; beside it the box's own H2D rate (the same
         # 78.6 MB through hipMemcpyAsync).  Never `value`.
-        if world == 1 and not args.no_host_pipeline and not args.no_other_configs:  # (the profiling passes run neither)
-            try:
-                hp_depth = max(depth, 2)
-                if hp_depth != depth:
-                    ext.set_pipeline_depth(hp_depth)
-                h_sets = [torch.from_numpy(s).pin_memory() for s in host_sets]
-                h_outs = [dict(k=torch.zeros(B * cap * 28, dtype=torch.uint8).pin_memory(), d=torch.zeros(B * cap * 32, dtype=torch.uint8).pin_memory(),
-                               n=torch.zeros(B, dtype=torch.int32).pin_memory(), m=torch.zeros((B // 2) * cap, dtype=torch.int32).pin_memory(),
-                               nm=torch.zeros(B // 2, dtype=torch.int32).pin_memory()) for _ in range(hp_depth)]
-                dst = torch.empty_like(d_imgs[0])
-                e0, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                for _ in range(3):
-                    dst.copy_(h_sets[0], non_blocking=True)
-                torch.cuda.synchronize()
-                ncopy = 20
-                e0.record()
-                for i in range(ncopy):
-                    dst.copy_(h_sets[i % nsets], non_blocking=True)
-                e1_.record()
-                torch.cuda.synchronize()
-                h2d_peak = ncopy * B * W * H / (e0.elapsed_time(e1_) * 1e-3) / 1e9
+        hp_state = {"ok": None}
 
-                def hstep(i):
-                    o = h_outs[i % hp_depth]
-                    ext.extract_match_batch_host_async(h_sets[i % nsets], B, W, H, W, W * H, o["k"], o["d"], o["n"], first, second,
-                                                       (0, W, 0, H), o["m"], o["nm"], None, 100, 0.9, True, cap)
-                for i in range(2 * hp_depth):
+        def host_pipeline():
+            if world > 1 or args.no_host_pipeline or args.no_other_configs:  # (the profiling passes run neither)
+                raise Skipped("N > 1" if world > 1 else "--no-host-pipeline / --no-other-configs")
+            hp_depth = max(depth, 2)
+            if hp_depth != depth:
+                ext.set_pipeline_depth(hp_depth)
+            h_sets = [torch.from_numpy(s).pin_memory() for s in host_sets]
+            h_outs = [dict(k=torch.zeros(B * cap * 28, dtype=torch.uint8).pin_memory(), d=torch.zeros(B * cap * 32, dtype=torch.uint8).pin_memory(),
+                           n=torch.zeros(B, dtype=torch.int32).pin_memory(), m=torch.zeros((B // 2) * cap, dtype=torch.int32).pin_memory(),
+                           nm=torch.zeros(B // 2, dtype=torch.int32).pin_memory()) for _ in range(hp_depth)]
+            dst = torch.empty_like(run.d_imgs[0])
+            e0, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(3):
+                dst.copy_(h_sets[0], non_blocking=True)
+            torch.cuda.synchronize()
+            ncopy = 20
+            e0.record()
+            for i in range(ncopy):
+                dst.copy_(h_sets[i % nsets], non_blocking=True)
+            e1_.record()
+            torch.cuda.synchronize()
+            h2d_peak = ncopy * B * W * H / (e0.elapsed_time(e1_) * 1e-3) / 1e9
+
+            def hstep(i):
+                o = h_outs[i % hp_depth]
+                ext.extract_match_batch_host_async(h_sets[i % nsets], B, W, H, W, W * H, o["k"], o["d"], o["n"], run.first, run.second,
+                                                   (0, W, 0, H), o["m"], o["nm"], None, 100, 0.9, True, cap)
+            for i in range(2 * hp_depth):
+                hstep(i)
+            ext.wait()
+            nh = max(80, 8 * hp_depth)
+            ths = []
+            for _ in range(3):  # (three regions of ~0.1 s, the median: this pool's GPUs pause ~10 ms every ~100 ms)
+                t0 = time.perf_counter()
+                for i in range(nh):
                     hstep(i)
                 ext.wait()
-                nh = max(80, 8 * hp_depth)
-                ths = []
-                for _ in range(3):  # (three regions of ~0.1 s, the median: this pool's GPUs pause ~10 ms every ~100 ms)
-                    t0 = time.perf_counter()
-                    for i in range(nh):
-                        hstep(i)
-                    ext.wait()
-                    ths.append(time.perf_counter() - t0)
-                th = sorted(ths)[1]
-                hp_ok, hp_what = None, "skipped (--no-check)"
-                if not args.no_check:
-                    lasth = nh - 1
-                    hp_ok, hp_what = oracle_check(host_sets[lasth % nsets], {k_: v.numpy() for k_, v in h_outs[lasth % hp_depth].items()}, cpu_share())
-                    if not hp_ok:
-                        check_ok = False
-                fps = nh * B / th
-                out["host_pipeline"] = {"frames_per_s": fps, "ms_per_batch": th / nh * 1e3, "h2d_GBs": fps * W * H / 1e9,
-                                        "d2h_GBs": fps * (cap * 60 + 4 + (cap * 4 + 4) / 2) / 1e9,
-                                        "measured_pcie_h2d_peak_GBs": h2d_peak, "frac_of_measured_pcie_peak": fps * W * H / 1e9 / h2d_peak,
-                                        "batches_in_flight": hp_depth, "checked": bool(hp_ok) if hp_ok is not None else False, "check": hp_what,
-                                        "note": "orbx_extract_match_batch_host_async: %d page-locked 640x480 frames up, the kernels, every "
-                                                "result array (15.5 MB) back per batch, stream-ordered on %d lanes; peak = the same frames "
-                                                "through hipMemcpyAsync alone on this box" % (B, hp_depth)}
-                del h_sets, h_outs, dst
-            except Exception as ex:  # never let it break the line
-                out["host_pipeline"] = {"error": str(ex)[:300]}
+                ths.append(time.perf_counter() - t0)
+            th = sorted(ths)[1]
+            hp_ok, hp_what = None, "skipped (--no-check)"
+            if not args.no_check:
+                lasth = nh - 1
+                hp_ok, hp_what = oracle_check(host_sets[lasth % nsets], {k_: v.numpy() for k_, v in h_outs[lasth % hp_depth].items()}, cpu_share())
+            fps = nh * B / th
+            res = {"frames_per_s": fps, "ms_per_batch": th / nh * 1e3, "h2d_GBs": fps * W * H / 1e9,
+                                    "d2h_GBs": fps * (cap * 60 + 4 + (cap * 4 + 4) / 2) / 1e9,
+                                    "measured_pcie_h2d_peak_GBs": h2d_peak, "frac_of_measured_pcie_peak": fps * W * H / 1e9 / h2d_peak,
+                                    "batches_in_flight": hp_depth, "checked": bool(hp_ok) if hp_ok is not None else False, "check": hp_what,
+                                    "note": "orbx_extract_match_batch_host_async: %d page-locked 640x480 frames up, the kernels, every "
+                                            "result array (15.5 MB) back per batch, stream-ordered on %d lanes; peak = the same frames "
+                                            "through hipMemcpyAsync alone on this box" % (B, hp_depth)}
+            del h_sets, h_outs, dst
+            hp_state["ok"] = hp_ok
+            return res
+        run_side(out, "host_pipeline", host_pipeline, failures)
+        if hp_state["ok"] is False:
+            check_ok = False
         # BASELINE configurations 3 and 5 and config 5's 2000 x 2000 brute-force match: rates of the same
         # library right behind the headline (before the CPU legs: a GPU that has idled through them starts its next kernels at low
         # clocks), outside the timed regions, each compared with the CPU oracle on one pair (not timed)
-        if world == 1 and not args.no_other_configs:
-            try:
-                ext.close()
-                del d_imgs, outs
-                torch.cuda.empty_cache()
-                sys.path.insert(0, os.path.join(ROOT, "tools"))
-                import bench_config as BC
-                oc = {}
-                for cfg in ("c3", "c5"):
-                    r = BC.measure(cfg, steps=20, depth=3, device=local_rank)
-                    oc[cfg] = {"workload": "%d frames %dx%d / %d features + %d consecutive-pair matches (window %d) per call" % (
-                                   r["batch"], r["frame"][0], r["frame"][1], r["nfeatures"], r["batch"] // 2, r["window"]),
-                               "frames_per_s_synchronous": r["sync"]["frames_per_s"], "frames_per_s_on_lanes": r["lanes"]["frames_per_s"],
-                               "lanes": r["lanes"]["depth"], "ms_per_batch_synchronous": r["sync"]["ms_per_batch"],
-                               "stage_ms": r["sync"]["stage_ms"], "dominant_stage": r["sync"]["dominant_stage"],
-                               "hbm_algorithmic_frac_synchronous": r["sync"]["algorithmic_frac_of_8TBs"],
-                               "hbm_algorithmic_frac_on_lanes": r["lanes"]["algorithmic_frac_of_8TBs"],
-                               "mean_keypoints": r["sync"]["mean_keypoints"], "mean_nmatches": r["sync"]["mean_nmatches"],
-                               "checked": BC.check(cfg, device=local_rank)}
-                # BASELINE config 4 as written: 256 frames over 8 GPUs = 32 frames + 16 pairs per GPU and step (the
-                # headline's weak scaling keeps 256 frames PER GPU)
-                r4 = BC.measure("c2", steps=200, depth=4, batch=32, modes=("sync", "lanes"), device=local_rank)
-                oc["c4_per_gpu"] = {"workload": "32 frames 640x480 / 1000 features + 16 consecutive-pair matches per call: one GPU's share of "
-                                                "BASELINE config 4's 256-frame batch over 8 GPUs",
-                                    "frames_per_s_synchronous": r4["sync"]["frames_per_s"], "frames_per_s_on_lanes": r4["lanes"]["frames_per_s"],
-                                    "lanes": r4["lanes"]["depth"], "ms_per_batch_synchronous": r4["sync"]["ms_per_batch"],
-                                    "ms_per_batch_on_lanes": 32e3 / r4["lanes"]["frames_per_s"], "stage_ms": r4["sync"]["stage_ms"],
-                                    "checked": BC.check("c2", device=local_rank)}
-                bf, bf_data = BC.measure_bf(steps=20, device=local_rank)
-                oc["bf_2000x2000"] = {"us_per_2000x2000": bf["ms_per_2000x2000"] * 1e3, "descriptor_pairs_per_s": bf["descriptor_pairs_per_s"],
-                                      "frac_of_4.9T_popcount_bound": bf["frac_of_4.9T_pairs_per_s"],
-                                      "frac_of_3.3T_bcnt_issue_bound": bf["frac_of_3.3T_pairs_per_s"],
-                                      "frac_of_9.8T_mfma_i8_bound": bf["frac_of_9.8T_mfma_i8_pairs_per_s"], "sets_per_call": bf["sets_per_call"],
-                                      "nmatches": bf["nmatches"], "checked": BC.check_bf(bf_data)}
-                out["other_configs"] = oc
-                if not all(v["checked"] for v in oc.values()):
-                    check_ok = False
-            except Exception as ex:  # never let them break the line
-                out["other_configs"] = {"error": str(ex)[:300]}
+        def other_configs():
+            if world > 1 or args.no_other_configs:
+                raise Skipped("N > 1" if world > 1 else "--no-other-configs")
+            ext.close()
+            run.release()
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_config as BC
+            oc = {}
+            for cfg in ("c3", "c5"):
+                r = BC.measure(cfg, steps=20, depth=3, device=local_rank)
+                oc[cfg] = {"workload": "%d frames %dx%d / %d features + %d consecutive-pair matches (window %d) per call" % (
+                               r["batch"], r["frame"][0], r["frame"][1], r["nfeatures"], r["batch"] // 2, r["window"]),
+                           "frames_per_s_synchronous": r["sync"]["frames_per_s"], "frames_per_s_on_lanes": r["lanes"]["frames_per_s"],
+                           "lanes": r["lanes"]["depth"], "ms_per_batch_synchronous": r["sync"]["ms_per_batch"],
+                           "stage_ms": r["sync"]["stage_ms"], "dominant_stage": r["sync"]["dominant_stage"],
+                           "hbm_algorithmic_frac_synchronous": r["sync"]["algorithmic_frac_of_8TBs"],
+                           "hbm_algorithmic_frac_on_lanes": r["lanes"]["algorithmic_frac_of_8TBs"],
+                           "mean_keypoints": r["sync"]["mean_keypoints"], "mean_nmatches": r["sync"]["mean_nmatches"],
+                           "checked": BC.check(cfg, device=local_rank)}
+            # BASELINE config 4 as written: 256 frames over 8 GPUs = 32 frames + 16 pairs per GPU and step (the
+            # headline's weak scaling keeps 256 frames PER GPU)
+            r4 = BC.measure("c2", steps=200, depth=4, batch=32, modes=("sync", "lanes"), device=local_rank)
+            oc["c4_per_gpu"] = {"workload": "32 frames 640x480 / 1000 features + 16 consecutive-pair matches per call: one GPU's share of "
+                                            "BASELINE config 4's 256-frame batch over 8 GPUs",
+                                "frames_per_s_synchronous": r4["sync"]["frames_per_s"], "frames_per_s_on_lanes": r4["lanes"]["frames_per_s"],
+                                "lanes": r4["lanes"]["depth"], "ms_per_batch_synchronous": r4["sync"]["ms_per_batch"],
+                                "ms_per_batch_on_lanes": 32e3 / r4["lanes"]["frames_per_s"], "stage_ms": r4["sync"]["stage_ms"],
+                                "checked": BC.check("c2", device=local_rank)}
+            bf, bf_data = BC.measure_bf(steps=20, device=local_rank)
+            oc["bf_2000x2000"] = {"us_per_2000x2000": bf["ms_per_2000x2000"] * 1e3, "descriptor_pairs_per_s": bf["descriptor_pairs_per_s"],
+                                  "frac_of_4.9T_popcount_bound": bf["frac_of_4.9T_pairs_per_s"],
+                                  "frac_of_3.3T_bcnt_issue_bound": bf["frac_of_3.3T_pairs_per_s"],
+                                  "frac_of_9.8T_mfma_i8_bound": bf["frac_of_9.8T_mfma_i8_pairs_per_s"], "sets_per_call": bf["sets_per_call"],
+                                  "nmatches": bf["nmatches"], "checked": BC.check_bf(bf_data)}
+            # the call BASELINE config 5 literally names: ONE 2000 x 2000 match per call, its result waited for (too few blocks for
+            # the matrix-core kernel: the vector form), and sixteen per call
+            bf1, bf1_data = BC.measure_bf(steps=100, device=local_rank, sets=1, sync_each=True)
+            bf16, _ = BC.measure_bf(steps=20, device=local_rank, sets=16)
+            oc["bf_2000x2000"]["single_call_us"] = bf1["ms_per_call"] * 1e3
+            oc["bf_2000x2000"]["single_call_device_us"] = bf1["device_ms_per_call"] * 1e3
+            oc["bf_2000x2000"]["us_per_2000x2000_at_16_per_call"] = bf16["ms_per_2000x2000"] * 1e3
+            oc["bf_2000x2000"]["checked"] = bool(oc["bf_2000x2000"]["checked"] and BC.check_bf(bf1_data))
+            return oc
+        oc_ = run_side(out, "other_configs", other_configs, failures)
+        if "error" not in oc_ and "skipped" not in oc_ and not all(v["checked"] for v in oc_.values()):
+            check_ok = False
         if not args.no_cpu_baseline and world == 1:  # (the CPU baseline is an N = 1 figure: rank 0's host cores, one GPU beside it)
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O
@@ -614,13 +693,17 @@ def main():
                                              % reps,
                                    "all_cores": allc, "one_core": one, "all_cores_march_native": alln}
             out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["value"]
-        # (the exit code mirrors this field: `checked` is the headline batch alone)
-        out["all_checked"] = False if check_ok is False else (bool(check_ok) if check_ok is not None else False)
+        # (the exit code mirrors this field: `checked` is the headline batch alone; a side measurement that raised makes
+        # it false as well)
+        out["all_checked"], exit_code = final_status(check_ok, failures)
+        out["side_failures"] = failures
         print(json.dumps(out))
     if coll:
         dist.destroy_process_group()
+    if rank == 0 and exit_code:
+        raise SystemExit(exit_code)  # (the line above says what differed or failed)
     if check_ok is False:
-        raise SystemExit(3)  # (the line above says what differed)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -417,6 +417,12 @@ int orbx_debug_sincos(orbx_ctx* ctx, const float* angle_deg, int n, float* cos_o
  * halves on two streams, bit 1: the descriptor kernel took the selection's staging lists itself (small launches: no k_sel_compact); [5] frames per kernel launch; [6] 1 = the wide matcher kernels went with the batch; [7] lane the batch
  * went to (1-based; 0 = the context itself) }. */
 int orbx_debug_last_launch(const orbx_ctx* ctx, int32_t* info8);
+/* Which matcher kernels did the work (cumulative since orbx_create, for the context itself -- a lane has its own): info4 = { [0] blocks
+ * of 256 queries whose candidate lists k_match_bf_mfma built on the matrix cores (a brute-force block of a launch with at least 256
+ * such blocks; everything else is listed by k_match_wide_lists on the vector ALU), [1..3] reserved (0) }.  Waits for the context's
+ * batches in flight.  Tests take the difference around a call to see that the matrix path ran (or, under the knob match_no_mfma,
+ * did not). */
+int orbx_debug_match_counters(orbx_ctx* ctx, uint32_t* info4);
 /* Diagnostic knobs (process-wide; the library itself reads NO environment variable): a named integer that makes the launches that
  * follow take a particular kernel or launch shape -- e.g. "fast_wg_max_cells" = 0 sends the FAST cells of small batches through
  * k_fast_wave, "no_split" = 1 keeps a synchronous call on one stream.  None changes a result; tests use them to run one input

@@ -160,6 +160,7 @@ def lib() -> ctypes.CDLL:
     L.orbx_debug_sincos.argtypes = [vp, vp, i32, vp, vp]
     L.orbx_debug_set.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
     L.orbx_debug_last_launch.argtypes = [vp, vp]
+    L.orbx_debug_match_counters.argtypes = [vp, vp]
     L.orbx_debug_selection_units.argtypes = [vp, i32, vp, vp]
     L.orbx_debug_path_codes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
     _LIB = L
@@ -604,6 +605,12 @@ class ORBextractor:
         return dict(pyramid_banded=int(v[0]), pyramid_bands=int(v[1]), fast_wave=int(v[2]), octree_instance=int(v[3]),
                     split=int(v[4]) & 1, staged_lists=(int(v[4]) >> 1) & 1, frames_per_launch=int(v[5]), wide_with_batch=int(v[6]),
                     lane=int(v[7]))
+
+    def debug_match_counters(self) -> dict:
+        """Which matcher kernels did the work, cumulative for this context (include/orbx.h: orbx_debug_match_counters)."""
+        v = np.zeros(4, np.uint32)
+        self._check(self._L.orbx_debug_match_counters(self._h, _ptr(v)), "orbx_debug_match_counters")
+        return dict(bf_mfma_blocks=int(v[0]))
 
     def debug_selection_units(self, frame: int = 0):
         """(counts, redone) per pyramid level of one frame of the last batch (include/orbx.h: orbx_debug_selection_units)."""

@@ -46,7 +46,8 @@ hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const 
                                  const DescStage* staged);
 hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int* dSecond, const orbx_keypoint* kps,
                         const uint8_t* desc, const int* nkp, int capacity, orbx_bounds b, int window, float nnratio, int checkOri,
-                        int* matches12, int* nmatches, int* stats, int* scratch, int pair0, int wideMode, int* hostWide);
+                        int* matches12, int* nmatches, int* stats, int* scratch, int pair0, int wideMode, int* hostWide,
+                        unsigned int* diag);
 hipError_t launch_octree(hipStream_t st, int nFrames, const uint32_t* cand, const int* cellCount, const OctLaunch& P,
                          SelKp* selStage, int* nselLevel, uint8_t* scratch, int* maxN, const int* hintL, int force, int* usedInstance);
 hipError_t launch_sel_compact(hipStream_t st, int nFrames, const SelKp* selStage, const int* nselLevel, const OctLaunch& P,
@@ -178,6 +179,7 @@ struct orbx_ctx {
   int pinFrames = 0;
   // matcher
   int* dMatchScratch = nullptr;
+  unsigned int* dMatchDiag = nullptr;  // orbx_debug_match_counters: [0] blocks of 256 queries listed by k_match_bf_mfma since orbx_create
   size_t matchScratchInts = 0;
   int* dPairs = nullptr;
   size_t pairsCap = 0;
@@ -1218,7 +1220,7 @@ int issueMatch(orbx_ctx* ctx, int si, hipStream_t st, int pair0, int n, const Ma
   StageTimer tm(ctx, ORBX_STAGE_MATCH, si, st);
   const int wide = ctx->wideLaunched[ctx->parity] ? 1 : 0;
   HIPCHK(launch_match(st, n, ctx->dPairs, ctx->dPairs + m.nPairs, dKps, dDesc, dN, capacity, m.b, m.window, m.nnratio, m.checkOri,
-                      m.dMatches12, m.dNmatches, m.dStats, ctx->dMatchScratch, pair0, wide, ctx->hWideDev + ctx->parity));
+                      m.dMatches12, m.dNmatches, m.dStats, ctx->dMatchScratch, pair0, wide, ctx->hWideDev + ctx->parity, ctx->dMatchDiag));
   tm.stop(wide ? 3 : 1);  // k_match_jacobi (+ k_match_wide_lists + k_match_wide_resolve, for pending pairs only)
   return ORBX_OK;
 }
@@ -1247,7 +1249,7 @@ int settleMatch(orbx_ctx* ctx, int parity) {
     HIPCHK(hipStreamSynchronize(ctx->st));
     if (ctx->st2) HIPCHK(hipStreamSynchronize(ctx->st2));
     HIPCHK(launch_match(ctx->st, L.nPairs, ctx->dPairs, ctx->dPairs + L.nPairs, L.dKps, L.dDesc, L.dN, L.capacity, L.b, L.window,
-                        L.nnratio, L.checkOri, L.dMatches12, L.dNmatches, L.dStats, ctx->dMatchScratch, 0, 2, ctx->hWideDev + parity));
+                        L.nnratio, L.checkOri, L.dMatches12, L.dNmatches, L.dStats, ctx->dMatchScratch, 0, 2, ctx->hWideDev + parity, ctx->dMatchDiag));
     HIPCHK(hipStreamSynchronize(ctx->st));
   }
   if (needed) {
@@ -1551,7 +1553,7 @@ void orbx_destroy(orbx_ctx* ctx) {
   if (ctx->st) (void)hipStreamSynchronize(ctx->st);
   if (ctx->st2) (void)hipStreamSynchronize(ctx->st2);
   freeAll(ctx);
-  void* dev[] = {ctx->dMatchScratch, ctx->dPairs, ctx->dMblk, ctx->dMi, ctx->dColor, ctx->dScore};
+  void* dev[] = {ctx->dMatchScratch, ctx->dMatchDiag, ctx->dPairs, ctx->dMblk, ctx->dMi, ctx->dColor, ctx->dScore};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (ctx->hMblk) (void)hipHostFree(ctx->hMblk);
@@ -1803,6 +1805,10 @@ int ensureMatchScratch(orbx_ctx* ctx, int nPairs, int capacity) {
   // stride argument use; the kernels index a pair's area with [pair * stride, (pair + 1) * stride) and clamp their own
   // counts to the capacities the layout was computed from (queries / trains to matchWideCap(capacity), list entries per
   // query to MW_CP, per-frame counts to `capacity`)
+  if (!ctx->dMatchDiag) {  // (diagnostic counters, orbx_debug_match_counters: 64 bytes, zero at first use)
+    HIPCHK(hipMalloc((void**)&ctx->dMatchDiag, 64));
+    HIPCHK(hipMemset(ctx->dMatchDiag, 0, 64));
+  }
   const size_t need = (size_t)nPairs * (size_t)matchScratchStride(capacity);
   if (need > ctx->matchScratchInts) {
     if (ctx->dMatchScratch) (void)hipFree(ctx->dMatchScratch);
@@ -2704,6 +2710,18 @@ int orbx_debug_set(const char* key, long long value) {
 int orbx_debug_last_launch(const orbx_ctx* ctx, int32_t* info8) {
   if (!ctx || !info8) return ORBX_E_BADARG;
   for (int i = 0; i < 8; i++) info8[i] = ctx->lastLaunch[i];
+  return ORBX_OK;
+}
+
+int orbx_debug_match_counters(orbx_ctx* ctx, uint32_t* info4) {
+  if (!ctx || !info4) return ORBX_E_BADARG;
+  for (int i = 0; i < 4; i++) info4[i] = 0;
+  if (!ctx->dMatchDiag) return ORBX_OK;  // no match has run on this context yet
+  if (hipSetDevice(ctx->device) != hipSuccess) return ORBX_E_HIP;
+  const int w = waitAll(ctx);  // (the counters of every batch issued so far)
+  if (w != ORBX_OK) return w;
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  HIPCHK(hipMemcpy(info4, ctx->dMatchDiag, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return ORBX_OK;
 }
 

@@ -2747,7 +2747,7 @@ __global__ __launch_bounds__(BF_T) void k_match_bf_mfma(const int* __restrict__ 
                                                       const uint8_t* __restrict__ desc, const int* __restrict__ nkp,
                                                       const MatchParams mp, const int* __restrict__ nmatchesOut,
                                                       const int* __restrict__ scratchR, int* __restrict__ scratchW,
-                                                      long long scratchStride, int capl) {
+                                                      long long scratchStride, int capl, unsigned int* __restrict__ diag) {
   // [image][k-step = dword][bit half][train]: 2 x 8 KB; rows of 33 pieces, so that the sixteen (train, dword) stores of a quarter
   // wave fall into sixteen different groups of four banks (with 32 the eight dwords of a train share one)
   __shared__ __attribute__((aligned(16))) v4i_t tileB[2][8][2][33];
@@ -2813,6 +2813,7 @@ __global__ __launch_bounds__(BF_T) void k_match_bf_mfma(const int* __restrict__ 
     __syncthreads();
     if (!sAll) return;  // (uniform) k_match_wide_lists takes the block
   }
+  if (t == 0 && diag) atomicAdd(diag, 1u);  // orbx_debug_match_counters: blocks of 256 queries this kernel has listed
   // ---- the queries' fragments: rows = query 64 wv + 32 T + (lane & 31), k = the 16 bits (lane >> 5) of dword c ----
   const int h = lane >> 5, n = lane & 31;
   const int qw = 32 * BF_NT * wv;  // the wave's first query of the block
@@ -3571,7 +3572,8 @@ hipError_t launch_describe_patch(hipStream_t st, int nFrames, int maxSel, const 
 
 hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int* dSecond, const orbx_keypoint* kps,
                         const uint8_t* desc, const int* nkp, int capacity, orbx_bounds b, int window, float nnratio, int checkOri,
-                        int* matches12, int* nmatches, int* stats, int* scratch, int pair0, int wideMode, int* hostWide) {
+                        int* matches12, int* nmatches, int* stats, int* scratch, int pair0, int wideMode, int* hostWide,
+                        unsigned int* diag) {
   // wideMode 1: k_match_jacobi and the wide kernels behind it; 0: k_match_jacobi only (the caller expects no pair to need the
   // wide path and checks *hostWide afterwards); 2: the wide path alone, prep included, for the pairs still pending
   if (nPairs <= 0) return hipSuccess;
@@ -3601,7 +3603,7 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
   if (wideMode != 0) {
     if (!mp.noMfma)
       hipLaunchKernelGGL(k_match_bf_mfma, dim3((capl + BF_QWG - 1) / BF_QWG, nPairs), dim3(BF_T), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
-                         nmatches, scratch, scratch, stride, capl);
+                         nmatches, scratch, scratch, stride, capl, diag);
     hipLaunchKernelGGL(k_match_wide_lists, dim3((capl + 63) / 64, nPairs), dim3(256), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
                        nmatches, scratch, scratch, stride, capl);
     const int qpw = (long long)nPairs * capl >= 100000 ? 16 : 4;  // queries per wave of k_match_wide_sort

@@ -122,6 +122,22 @@ def test_bench_starts_its_own_ranks(orbx):
     assert d["config"]["rccl_ranks"] == 0  # gloo rehearsal: RCCL did not run, and the line says so
 
 
+def test_bench_four_ranks_config4_as_written(orbx):
+    """The launcher, the shard ranges and the all-gather at world size 4 (gloo rehearsal, every rank on cuda:0, small batches), and
+    the N > 1 line's second figure: BASELINE config 4 AS WRITTEN -- one batch of 256 frames over the ranks, 64 per rank and step --
+    beside the weak-scaling `value`.  (VERDICT r05 item 7 asked for 8 children on the one GPU; this pool's process guard allows six
+    processes on a card, and the test process is one of them: four fresh children is what a one-GPU box can hold.)"""
+    out = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--one-device", "--batch", "16",
+                "--steps", "4", "--warmup", "2", "--prime", "4", "--regions", "1", "--no-cpu-baseline", "--no-single-frame"])
+    d = _bench_line(out)
+    assert d["n_gpus"] == 4 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["checked"] is True and d["all_checked"] is True and d["side_failures"] == [], d["check"]
+    c = d["config"]["collective"]
+    assert c["world_size"] == 4 and c["all_gathers"] >= 4 and c["gathered_counts_ok"] is True
+    c4 = d["config4_as_written"]
+    assert c4["frames_per_step"] == 256 and c4["frames_per_rank"] == 64 and c4["gathered_counts_ok"] is True and c4["frames_per_s"] > 0
+
+
 def test_bench_rccl_ranks(orbx):
     """The same over RCCL, one rank per GPU, whenever the box has more than one."""
     import torch

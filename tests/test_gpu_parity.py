@@ -253,7 +253,7 @@ def test_brute_force_on_the_matrix_cores(orbx, oracle):
     W, H = 3840, 2160
     ext = orbx.ORBextractor(cap, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=1)
 
-    def run(sets, window, ratio, ori, reps=1):
+    def run(sets, window, ratio, ori, reps=1, min_mfma_blocks=1):
         k_all = np.zeros((2 * P, cap), KP)
         d_all = np.zeros((2 * P, cap, 32), np.uint8)
         n_all = np.zeros(2 * P, np.int32)
@@ -273,8 +273,16 @@ def test_brute_force_on_the_matrix_cores(orbx, oracle):
             d_m = torch.full((NP * cap,), -7, dtype=torch.int32, device=dev)
             d_nm = torch.zeros(NP, dtype=torch.int32, device=dev)
             d_st = torch.zeros(3 * NP, dtype=torch.int32, device=dev)
+            before = ext.debug_match_counters()["bf_mfma_blocks"]
             ext.match_pairs_device(first, first + 1, d_k, d_d, d_n, (0, W, 0, H), d_m, d_nm, d_st, window, ratio, ori, cap)
             torch.cuda.synchronize()
+            took = ext.debug_match_counters()["bf_mfma_blocks"] - before
+            # the matrix kernel really listed blocks of this launch (a changed launch rule must not leave the
+            # test green on the vector form alone) -- and under the knob it listed none
+            if knob is None:
+                assert took >= min_mfma_blocks, (took, min_mfma_blocks)
+            else:
+                assert took == 0, took
             out.append((d_m.cpu().numpy().reshape(NP, cap), d_nm.cpu().numpy(), d_st.cpu().numpy().reshape(NP, 3)))
         orbx.debug_set("match_no_mfma", None)
         for i, (k1, d1, k2, d2) in enumerate(sets):
@@ -294,7 +302,8 @@ def test_brute_force_on_the_matrix_cores(orbx, oracle):
             else:
                 protos = rng.integers(0, 256, (n, 32), dtype=np.uint8)
                 sets.append(_clustered_desc_pair(orbx, rng, n, protos, 40, W, H, 1.0 if i % 3 else 0.8, 4))
-        o1 = run(sets, 8192, 0.9, True, reps=2)  # (128 pairs of two to five blocks: the 256 blocks the kernel wants)
+        # (128 pairs of two to five blocks: the 256 blocks the kernel wants -- every block passes the brute-force test, all are its)
+        o1 = run(sets, 8192, 0.9, True, reps=2, min_mfma_blocks=256)
         assert sum(int((m >= 0).sum()) for m in o1[0][0]) > P * 100
         # a window the middle of the frame passes: |x - bbx0| < r and |x - bbx1| < r need x in (W - r, r)
         sets2 = []

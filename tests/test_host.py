@@ -307,3 +307,41 @@ def test_one_hip_runtime_whatever_the_import_order():
     assert r.returncode == 0, r.stderr[-500:]
     libs = eval(r.stdout.strip().splitlines()[-1])
     assert len(libs) == 1, libs
+
+
+def test_bench_side_measurements_fail_loudly():
+    import sys
+    """VERDICT r05 item 8: a figure behind the headline (host_pipeline, other_configs, single_frame) that RAISES must not read like
+    a success.  bench.py runs every one of them through run_side(): the line is still printed, the error is in it, `all_checked`
+    becomes false and the exit code non-zero.  Here: a failing bench_config.measure injected into the helper bench.py uses, no GPU."""
+    import importlib
+    bench = importlib.import_module("bench")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_config as BC
+
+    def failing_measure(*a, **k):
+        raise RuntimeError("injected: hipErrorLaunchFailure")
+    saved = BC.measure
+    BC.measure = failing_measure
+    try:
+        out, failures = {}, []
+        r = bench.run_side(out, "other_configs", lambda: {"c3": BC.measure("c3", steps=20, depth=3, device=0)}, failures)
+    finally:
+        BC.measure = saved
+    assert failures == ["other_configs"] and "injected" in out["other_configs"]["error"] and r is out["other_configs"]
+    assert bench.final_status(True, failures) == (False, 3)      # the headline batch matched, a side figure crashed: still a failure
+    assert bench.final_status(True, []) == (True, 0)
+    assert bench.final_status(False, []) == (False, 3)            # a mismatch against the oracle
+    assert bench.final_status(None, []) == (False, 0)             # --no-check: nothing claimed, nothing failed
+    # a figure that was not asked for is recorded as skipped and is no failure
+    out, failures = {}, []
+
+    def skipped():
+        raise bench.Skipped("--no-other-configs")
+    bench.run_side(out, "other_configs", skipped, failures)
+    assert failures == [] and out["other_configs"] == {"skipped": "--no-other-configs"}
+    # and main() really routes the three figures through the helper and takes its exit code from final_status
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for name in ("single_frame", "host_pipeline", "other_configs"):
+        assert 'run_side(out, "%s"' % name in src, name
+    assert "final_status(check_ok, failures)" in src and "never let them break the line" not in src

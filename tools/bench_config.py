@@ -107,8 +107,10 @@ def measure(config, steps=20, depth=3, batch=0, modes=("sync", "lanes"), device=
     return out
 
 
-def measure_bf(steps=20, device=0, sets=64):
-    """BASELINE config 5's matcher: 2000 x 2000 descriptors, window covering the frame -> every (query, train) pair is a candidate."""
+def measure_bf(steps=20, device=0, sets=64, sync_each=False):
+    """BASELINE config 5's matcher: 2000 x 2000 descriptors, window covering the frame -> every (query, train) pair is a candidate.
+    sync_each: the caller waits for every call's result before the next (the reference's own use: one SearchForInitialization, its
+    result, the next) instead of queueing the calls back to back."""
     import torch
     import orb_slam_tracking_amd as orbx
     from orb_slam_tracking_amd import synth
@@ -136,6 +138,8 @@ def measure_bf(steps=20, device=0, sets=64):
     t0 = time.perf_counter()
     for _ in range(steps):
         match()
+        if sync_each:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     pairs = P * n * n
