@@ -112,6 +112,15 @@ int orbx_set_opencv_variant(orbx_ctx* ctx, int gaussian_variant, int gray_varian
  *                               kernel operation for operation (it is not correctly rounded: of the 1,135,869,953 f32 angles
  *                               in [0, 360], 1,484,894 give a different (cos, sin) pair than ORBX_LIBM_DOUBLE, and for 96 of
  *                               them a rotated sample point lands on another pixel); powf = the host libm's.
+ *                               SCOPE OF THE CLAIM: "FLOAT" means the sinf / cosf of glibc >= 2.28 (2018; the
+ *                               s_sincosf.h algorithm) on an x86-64 host -- with or without FMA contraction, both forms were
+ *                               checked against the host's libm for every angle.  A reference built on an OLDER glibc (Ubuntu
+ *                               16.04 / 18.04: 2.23 / 2.27) ran another sinf / cosf, which NEITHER reading reproduces exactly;
+ *                               and powf(factor, nlevels) in the constructor is the DEPLOY host's libm, so for the rare
+ *                               (factor, nlevels, nfeatures) combinations above two hosts may plan different per-level quotas.
+ *                               The default stays a reasoned choice, not a measured one, until tools/pin_opencv/libm_probe has
+ *                               been compiled against a real OpenCV (neither this image nor the GPU
+ *                               box has one).
  * Takes effect for the calls that follow (batches in flight are waited for; an earlier batch's error is returned as by
  * orbx_set_opencv_variant).  If the constructor's pow changes a per-level quota (it does for 138 of 8e8 tried (factor, nlevels,
  * nfeatures) combinations and never for a scale factor with two decimals), the context's buffers are re-planned. */

@@ -83,6 +83,16 @@ def _one_hip_runtime() -> None:
         pass
 
 
+def hip_runtimes_mapped() -> list:
+    """The distinct libamdhip64 files mapped into this process (Linux).  More than one means two HIP runtimes: the pre-load above
+    only helps when torch's copy carries the SONAME liborbx.so was linked against (libamdhip64.so.7) -- a torch wheel built against
+    another ROCm major leaves the process with both, and the second one finds no device."""
+    try:
+        return sorted(set(ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln))
+    except OSError:
+        return []
+
+
 def lib() -> ctypes.CDLL:
     """Loads liborbx.so (built in-tree by ``__graft_entry__.build()`` / ``make -C orb_slam_tracking_amd/csrc``)."""
     global _LIB
@@ -238,7 +248,15 @@ class ORBextractor:
                                 ctypes.c_void_p(stream or 0), ctypes.byref(self._h))
         if r != 0:
             self._h = ctypes.c_void_p(0)
-            raise OrbxError(r, "orbx_create failed (no usable HIP device / kernel image?)" if r == E_HIP else "orbx_create")
+            what = "orbx_create"
+            if r == E_HIP:
+                what = "orbx_create failed (no usable HIP device / kernel image?)"
+                rts = hip_runtimes_mapped()
+                if len(rts) > 1:  # the diagnosis that used to take a debugger (gpurun_out/r05/create2.log)
+                    what += ("; TWO HIP runtimes are mapped into this process (%s): liborbx.so and PyTorch each brought their own "
+                             "libamdhip64 -- import torch before orb_slam_tracking_amd, or build liborbx.so against the ROCm that "
+                             "torch ships" % ", ".join(rts))
+            raise OrbxError(r, what)
         self.nfeatures, self.nlevels, self.device, self.max_batch = int(nfeatures), int(nlevels), int(device), int(max_batch)
         q = np.zeros(self.nlevels, np.int32)
         self._L.orbx_get_tables(self._h, None, None, None, None, _ptr(q))

@@ -1991,7 +1991,9 @@ int hostBatchIssue(orbx_ctx* c, int n_frames, const uint8_t* h_imgs, int width, 
     c->pipeOutBytes = total;
   }
   for (int par = 0; par < 2; par++)
-    if (!c->evOut[par]) HIPCHK(hipEventCreateWithFlags(&c->evOut[par], hipEventDisableTiming));
+    // (release to SYSTEM scope: k_copy_out's stores into the caller's page-locked arrays must be visible to the host when the
+    // event has completed, also for arrays allocated non-coherent -- ADVICE r05)
+    if (!c->evOut[par]) HIPCHK(hipEventCreateWithFlags(&c->evOut[par], hipEventDisableTiming | hipEventReleaseToSystem));
   // nothing of a batch may be left to the host-side wait (the copies back run behind the kernels): the wide matcher kernels travel
   // with every batch of this context from now on, as after orbx_order_before
   c->eventOrdered = true;
@@ -2023,15 +2025,22 @@ int hostBatchIssue(orbx_ctx* c, int n_frames, const uint8_t* h_imgs, int width, 
   // Page-locked result arrays are filled by a KERNEL storing over the link (k_copy_out): a copy command behind the kernels would sit
   // at the head of its DMA queue until they have finished and hold up the next batches' uploads queued behind it.  Pageable
   // arrays (no device mapping) take copy commands.
-  auto mapped = [&](void* h) -> void* {
-    void* d = nullptr;
-    if (!h) return nullptr;
+  // (the WHOLE array must be mapped, not just its first byte: a caller may have registered part of a buffer, and the kernel's stores
+  // beyond a mapped range would be a GPU memory fault where the copy command returns an error -- ADVICE r05)
+  auto mapped = [&](void* h, size_t bytes) -> void* {
+    void *d = nullptr, *dLast = nullptr;
+    if (!h || bytes == 0) return nullptr;
     if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipHostGetDevicePointer(&dLast, (char*)h + bytes - 1, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if ((char*)dLast - (char*)d != (ptrdiff_t)(bytes - 1)) return nullptr;  // (two registrations that happen to be adjacent on the host)
     return d;
   };
-  void* mK = mapped(h_kps); void* mD = mapped(h_desc32); void* mN = mapped(h_n_out);
-  void* mM = n_pairs > 0 ? mapped(h_matches12) : nullptr; void* mNm = n_pairs > 0 ? mapped(h_nmatches) : nullptr;
-  void* mSt = n_pairs > 0 && h_stats ? mapped(h_stats) : nullptr;
+  const size_t nF = (size_t)n_frames, nP = (size_t)n_pairs, capz = (size_t)capacity;
+  void* mK = mapped(h_kps, sizeof(orbx_keypoint) * capz * nF); void* mD = mapped(h_desc32, 32 * capz * nF);
+  void* mN = mapped(h_n_out, sizeof(int32_t) * nF);
+  void* mM = n_pairs > 0 ? mapped(h_matches12, sizeof(int32_t) * capz * nP) : nullptr;
+  void* mNm = n_pairs > 0 ? mapped(h_nmatches, sizeof(int32_t) * nP) : nullptr;
+  void* mSt = n_pairs > 0 && h_stats ? mapped(h_stats, sizeof(int32_t) * 3 * nP) : nullptr;
   const bool allMapped = mK && mD && mN && (n_pairs == 0 || (mM && mNm && (!h_stats || mSt)));
   if (allMapped) {
     CopyOut co{};

@@ -301,7 +301,7 @@ def test_one_hip_runtime_whatever_the_import_order():
     import subprocess
     import sys
     code = ("import orb_slam_tracking_amd as o\no.lib()\nimport torch\n"
-            "print(sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l)))")
+            "print(o.hip_runtimes_mapped())")  # (the helper the loader's error text uses when orbx_create finds no device)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stderr[-500:]
