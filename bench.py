@@ -77,6 +77,57 @@ def load_pmc():
     return None, None
 
 
+def config_roofline(cfg, w, h, stage_ms, launch, n_kp):
+    """The roofline object of one of the other BASELINE configurations (other_configs.<cfg>.roofline): the
+    dominant stage of the SYNCHRONOUS call (live stage events), its kernel, the launch duration (a synchronous call of >= 16 frames is
+    two half batches: two launches per stage), and against it the VALU issue cycles and the HBM bytes per launch from the committed
+    counter passes of that configuration (profiles/r*_<cfg>_pmc.json, tools/prof_config.sh) and the algorithmic bytes of the stage."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.json" % cfg)))
+    pmc = json.load(open(files[-1])) if files else None
+    dom = max(("pyramid", "fast", "describe"), key=lambda s_: stage_ms[s_])
+    kname = KERNEL_OF[dom]
+    nl = 2 if launch.get("split") else 1
+    ms = stage_ms[dom] / nl
+    fpl = launch.get("frames_per_launch") or 0
+    roof = {"bound": "valu", "kernel": kname, "stage": dom, "unit": "T SIMD-issue-cycles/s", "peak": VALU_PEAK_SIMD_CYCLES / 1e12,
+            "avg_launch_ms": ms, "launches_per_call": nl, "frames_per_launch": fpl, "pmc_file": os.path.basename(files[-1]) if files else None,
+            "pmc_stale": None if not pmc else (pmc.get("kernel_sources_sha16") != kernel_sources_sha16()),
+            "achieved": None, "frac": None, "traffic": None}
+    pk = None
+    for k_, v_ in ((pmc or {}).get("per_launch") or {}).items():
+        if k_.startswith(kname):
+            pk = v_
+    ab = algorithmic_bytes(w, h, n_kp)[dom] * fpl
+    if pk and ms > 0 and pmc.get("frames_per_launch") == fpl:
+        roof["achieved"] = pk["valu_issue_cycles"] / (ms * 1e-3) / 1e12
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = pk["fetch_bytes"] + pk["write_bytes"]
+        roof["alone_in_the_profile"] = {"avg_launch_ms": pk["avg_us"] / 1e3, "frac": pk["valu_issue_cycles"] / (pk["avg_us"] * 1e-6) / VALU_PEAK_SIMD_CYCLES}
+    roof["hbm"] = {"algorithmic_bytes_per_launch": ab, "algorithmic_frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None,
+                   "counter_frac": roof["traffic"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if roof["traffic"] and ms > 0 else None, "peak_GBs": HBM_PEAK_GBS}
+    return roof
+
+
+def bf_roofline(bf):
+    """The matrix-core view of the 2000 x 2000 brute-force match: descriptor pairs per second of the whole call (live) and of
+    k_match_bf_mfma alone (its average launch in the committed rocprofv3 stats of the same call) against the int8 rate, 16
+    v_mfma_i32_32x32x32_i8 of 32 cycles per 2048 pairs on 1024 SIMDs at 2.4 GHz = 9.8 T pairs/s."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c5_pmc.json")))
+    pmc = json.load(open(files[-1])) if files else None
+    roof = {"bound": "mfma", "kernel": "k_match_bf_mfma", "unit": "T descriptor pairs/s", "peak": 9.8,
+            "achieved": bf["descriptor_pairs_per_s"] / 1e12, "frac": bf["descriptor_pairs_per_s"] / 9.8e12,
+            "what": "the whole match call (prep, lists on the matrix cores, sort, resolve), live",
+            "pmc_file": os.path.basename(files[-1]) if files else None,
+            "pmc_stale": None if not pmc else (pmc.get("kernel_sources_sha16") != kernel_sources_sha16())}
+    pk = ((pmc or {}).get("per_launch_bf_match") or {}).get("k_match_bf_mfma")
+    if pk:
+        pairs = bf["sets_per_call"] * bf["descriptors"][0] * bf["descriptors"][1]
+        roof["kernel_alone_in_the_profile"] = {"avg_launch_us": pk["avg_us"], "pairs_per_launch": pairs,
+                                               "frac": pairs / (pk["avg_us"] * 1e-6) / 9.8e12,
+                                               "traffic": pk["fetch_bytes"] + pk["write_bytes"]}
+    return roof
+
+
 def kernel_sources_sha16():
     """Hash of the device + host sources liborbx.so is built from: tools/pmc_to_json.py records it in profiles/r*_pmc.json, and the
     roofline object says whether the counters were collected from the code under test (`pmc_stale`)."""
@@ -642,6 +693,8 @@ def main():
                            "hbm_algorithmic_frac_synchronous": r["sync"]["algorithmic_frac_of_8TBs"],
                            "hbm_algorithmic_frac_on_lanes": r["lanes"]["algorithmic_frac_of_8TBs"],
                            "mean_keypoints": r["sync"]["mean_keypoints"], "mean_nmatches": r["sync"]["mean_nmatches"],
+                           "roofline": config_roofline(cfg, r["frame"][0], r["frame"][1], r["sync"]["stage_ms"], r["sync"]["launch"],
+                                                       r["sync"]["mean_keypoints"]),
                            "checked": BC.check(cfg, device=local_rank)}
             # BASELINE config 4 as written: 256 frames over 8 GPUs = 32 frames + 16 pairs per GPU and step (the
             # headline's weak scaling keeps 256 frames PER GPU)
@@ -662,6 +715,7 @@ def main():
             # the matrix-core kernel: the vector form), and sixteen per call
             bf1, bf1_data = BC.measure_bf(steps=100, device=local_rank, sets=1, sync_each=True)
             bf16, _ = BC.measure_bf(steps=20, device=local_rank, sets=16)
+            oc["bf_2000x2000"]["roofline"] = bf_roofline(bf)
             oc["bf_2000x2000"]["single_call_us"] = bf1["ms_per_call"] * 1e3
             oc["bf_2000x2000"]["single_call_device_us"] = bf1["device_ms_per_call"] * 1e3
             oc["bf_2000x2000"]["us_per_2000x2000_at_16_per_call"] = bf16["ms_per_2000x2000"] * 1e3

@@ -246,7 +246,8 @@ def _need_batch(imgs, n_frames, width, height, stride, frame_stride, kps, desc, 
     if first is not None and len(first):
         if len(second) != len(first):
             raise ValueError("first / second: %d and %d pairs" % (len(first), len(second)))
-        if n_frames > 0 and (int(first.max()) >= n_frames or int(second.max()) >= n_frames or int(first.min()) < 0 or int(second.min()) < 0):
+        # (one pass over both: as unsigned, a negative index is a huge one)
+        if n_frames > 0 and int(np.maximum(first.view(np.uint32), second.view(np.uint32)).max()) >= n_frames:
             raise ValueError("a pair names a frame outside the batch of %d" % n_frames)
         _need("matches12", matches12, len(first) * capacity * 4)
         _need("nmatches", nmatches, len(first) * 4)

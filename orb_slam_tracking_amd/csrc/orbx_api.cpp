@@ -1091,11 +1091,15 @@ int issueExtract(orbx_ctx* ctx, int si, hipStream_t st, int f0, int n, const Ext
   const int bandsEnv = (int)knob(KNOB_PYR_BANDS, 0);  // diagnostics
   const int bandsMin = (int)knob(KNOB_BANDS_MIN_FRAMES, 0);  // diagnostics
   const int stripsEnv = (int)knob(KNOB_PYR_STRIPS, 0);       // diagnostics
-  // from 32 frames per stream, or from 8 when the frames are large (16 frames 1080p: 0.43 -> 0.30 ms; 16 frames 640x480 are
-  // better off with the per-level launches: 0.252 vs 0.263 ms per 32-frame call)
+  // rounds 2 - 5: from 32 frames per stream, or from 8 when the frames are large (16 frames 1080p: 0.43 -> 0.30 ms; 16 frames 640x480
+  // were better off with the per-level launches then: 0.252 vs 0.263 ms per 32-frame call)
   // (round 5: with column strips also few large frames -- the four-frame halves of a 3840x2160 batch in 32 bands x 4 strips: 0.227 ms
   // per batch against 0.352 level by level and 0.456 in 32 bands without strips; tools/exp_pyr_strips.sh)
-  const bool enough = bandsMin > 0 ? n >= bandsMin : (n >= 32 || (n >= 2 && (long long)n * g.L[0].w * g.L[0].h >= (16ll << 20)));
+  // (round 6, with round 5's kernel -- row pairs, one group per thread, strips: from 9 frames, i.e. wherever the levels used to be
+  // launched one by one.  Per synchronous call of 32 frames 640x480 = two halves of 16: pyramid stage 0.096 -> 0.068 ms, 136.5 k ->
+  // 162.4 k frames/s; 24 frames: 107.6 k -> 128.9 k; 12 frames on one stream: 66.3 k -> 69.8 k, on four lanes 143 k -> 154 k;
+  // up to 8 frames k_pyramid_tiles stays (8: 53.0 k against 53.8 k, level; tools/exp_c4_small.py))
+  const bool enough = bandsMin > 0 ? n >= bandsMin : (n >= 9 || (n >= 2 && (long long)n * g.L[0].w * g.L[0].h >= (16ll << 20)));
   bool banded = nl > 1 && ctx->pyrInfo.ok && a.aligned0 && enough && !noBands;  // (dword loads: level 0 rows 4-byte aligned)
   PyrBands pb{};
   if (banded) {  // a band's rows of one level are staged by one pass of the workgroup: at most 256

@@ -1582,13 +1582,18 @@ def test_tiled_pyramid_small_batches(orbx, oracle, params):
     """Batches of up to 8 frames build the pyramid with k_pyramid_tiles (one launch, a workgroup per tile of a frame, the level chain
     through LDS, every tile with a halo of the pixels its higher levels read): every level image equals the oracle's cv::resize chain
     (Features/ORBextractor.cpp:1660-1713) for frame sizes with ragged tile grids, a scale of 2 and scales close to 1, a strided
-    caller image; 9 frames take one launch per level."""
+    caller image; 9 frames take k_pyramid_bands where the geometry allows it (round 6; one launch per level before) and, under the
+    knob no_bands, one launch per level."""
     import torch
     from orb_slam_tracking_amd import synth
     nlev, cap = params[2], params[0]
-    for (w, h, B, pad) in ((640, 480, 1, 0), (641, 479, 3, 0), (322, 243, 8, 0), (173, 131, 2, 0), (752, 480, 5, 16), (1280, 720, 1, 0), (640, 480, 9, 0)):
+    for (w, h, B, pad) in ((640, 480, 1, 0), (641, 479, 3, 0), (322, 243, 8, 0), (173, 131, 2, 0), (752, 480, 5, 16), (1280, 720, 1, 0), (640, 480, 9, 0),
+                           (640, 480, 9, -1)):
         if min(w, h) / params[1] ** (nlev - 1) < 70:  # the smallest level must hold a FAST cell grid (ORBX_E_TOOSMALL otherwise)
             continue
+        level_by_level = pad < 0  # (the last case: the per-level launches, which no default batch size takes any more)
+        pad = max(pad, 0)
+        orbx.debug_set("no_bands", 1 if level_by_level else None)
         frames = synth.synth_frames(B, w, h, 6100 + w)
         stride = w + pad
         buf = np.zeros((B, h, stride), np.uint8)
@@ -1601,7 +1606,10 @@ def test_tiled_pyramid_small_batches(orbx, oracle, params):
         d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
         e.extract_batch_device(d_img, B, w, h, stride, stride * h, d_k, d_d, d_n, cap)
         info = e.debug_last_launch()
-        assert info["pyramid_banded"] == (2 if B <= 8 else 0), (w, h, B, info)
+        orbx.debug_set("no_bands", None)
+        assert (info["pyramid_banded"] == 2) if B <= 8 else (info["pyramid_banded"] == 0 if level_by_level else info["pyramid_banded"] in (0, 1)), (w, h, B, info)
+        if B > 8 and not level_by_level and params[1] == 1.2:
+            assert info["pyramid_banded"] == 1, info  # (scale 1.2 on aligned 640x480 frames: nothing keeps the banded kernel away)
         # launches of up to 256 (frame, level) units: k_describe_patch indexes the selection's staging lists itself (no k_sel_compact)
         assert info["staged_lists"] == (1 if B * nlev <= 256 else 0), (w, h, B, info)
         n = d_n.cpu().numpy()

@@ -20,7 +20,7 @@ if [ "$CFG" = "c5" ]; then
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_bf -- $P --mode bf --steps 3 > $OUT/fetch_bf.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write_bf -- $P --mode bf --steps 3 > $OUT/write_bf.log 2>&1
 fi
-python3 tools/prof_config_summary.py $OUT $CFG > $R/profiles/${TAG}_${CFG}_summary.txt
+python3 tools/prof_config_summary.py $OUT $CFG $R/profiles/${TAG}_${CFG}_pmc.json > $R/profiles/${TAG}_${CFG}_summary.txt
 cp $OUT/rate.json $R/profiles/${TAG}_${CFG}_rate.json
 cp $OUT/stats/*/*kernel_stats.csv $R/profiles/${TAG}_${CFG}_kernel_stats_sync.csv
 cp $OUT/stats_lanes/*/*kernel_stats.csv $R/profiles/${TAG}_${CFG}_kernel_stats_lanes.csv

@@ -5,7 +5,9 @@ issue capacity over the launch, and the HBM bytes of the FETCH_SIZE / WRITE_SIZE
 import collections, csv, glob, json, re, sys
 
 out, cfg = sys.argv[1], sys.argv[2]
+json_out = sys.argv[3] if len(sys.argv) > 3 else None  # profiles/<tag>_<cfg>_pmc.json: what bench.py's other_configs.<cfg>.roofline reads
 PEAK = 256 * 4 * 2.4e9
+per_launch = {}
 
 
 def short(n):
@@ -64,6 +66,22 @@ for title, st, subs in (("synchronous call", "stats", ("sq", "sq4", "fetch", "wr
         d = merged.get(k, {})
         issue = 4.0 * (d.get('SQ_ACTIVE_INST_VALU', 0) - d.get('SQ_ACTIVE_INST_VALU2', 0))
         byts = (d.get('FETCH_SIZE', 0) + d.get('WRITE_SIZE', 0)) * 1024.0
+        per_launch.setdefault(title, {})[k] = {"avg_us": us, "calls": calls, "avg_us_on_lanes": lanes[k][0] if k in lanes else None,
+                                               "valu_issue_cycles": issue, "valu_instr": d.get('SQ_INSTS_VALU'),
+                                               "fetch_bytes": d.get('FETCH_SIZE', 0) * 1024.0, "write_bytes": d.get('WRITE_SIZE', 0) * 1024.0}
         print("  %-28s %9.1f us (%4.1f %%, %4d calls) | %9s | %12.0f cycles, valu_frac %.2f | %7.1f MB, %6.0f GB/s, %.3f"
               % (k, us, pct, calls, ("%.1f" % lanes[k][0]) if k in lanes else "-", issue, issue / (us * 1e-6) / PEAK if us else 0,
                  byts / 1e6, byts / (us * 1e-6) / 1e9 if us else 0, byts / (us * 1e-6) / 8e12 if us else 0))
+
+if json_out:
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_sources_sha16
+    launch = rate.get("sync", {}).get("launch", {})
+    json.dump({"workload": "bench_config %s: %s" % (cfg, json.dumps({k: rate[k] for k in ("frame", "nfeatures", "batch", "window")})),
+               "source": "tools/prof_config.sh: rocprofv3 --kernel-trace --stats (durations) and separate --pmc passes (SQ counters, "
+                         "SQ_ACTIVE_INST_VALU / VALU2, FETCH_SIZE, WRITE_SIZE) of `python3 tools/bench_config.py --config %s --mode sync`; "
+                         "per LAUNCH (a synchronous call issues every kernel once per half batch)" % cfg,
+               "kernel_sources_sha16": kernel_sources_sha16(), "frames_per_launch": launch.get("frames_per_launch"),
+               "per_launch": per_launch.get("synchronous call", {}), "per_launch_bf_match": per_launch.get("brute-force match", {})},
+              open(json_out, "w"), indent=1)
