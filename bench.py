@@ -102,7 +102,7 @@ def config_roofline(cfg, w, h, stage_ms, launch, n_kp):
         roof["achieved"] = pk["valu_issue_cycles"] / (ms * 1e-3) / 1e12
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["traffic"] = pk["fetch_bytes"] + pk["write_bytes"]
-        roof["alone_in_the_profile"] = {"avg_launch_ms": pk["avg_us"] / 1e3, "frac": pk["valu_issue_cycles"] / (pk["avg_us"] * 1e-6) / VALU_PEAK_SIMD_CYCLES}
+        roof["in_the_profile"] = {"avg_launch_ms": pk["avg_us"] / 1e3, "frac": pk["valu_issue_cycles"] / (pk["avg_us"] * 1e-6) / VALU_PEAK_SIMD_CYCLES}
     roof["hbm"] = {"algorithmic_bytes_per_launch": ab, "algorithmic_frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None,
                    "counter_frac": roof["traffic"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if roof["traffic"] and ms > 0 else None, "peak_GBs": HBM_PEAK_GBS}
     return roof
