@@ -3601,7 +3601,15 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
     hipLaunchKernelGGL(k_match_wide_prep, dim3(nPairs), dim3(MW_T), 0, st, dFirst, dSecond, kps, nkp, mp, matches12, nmatches,
                        scratch, stride, capl);
   if (wideMode != 0) {
-    if (!mp.noMfma)
+    // (the kernel takes brute-force blocks only in a launch with at least 256 blocks of 256 queries, and a block is brute force only
+    // if its queries' windows reach across the whole bounds: where the launch shape or the window rules that out for every pair --
+    // 16 pairs of 1080p frames, a window of 100 pixels -- the launch would be 5.6 us of workgroups that look and leave)
+    // (a query's window reaches grid column 0 and the last one only if 2 r > (COLS - 3) cell widths, rows alike: what is not launched
+    // here is listed by k_match_wide_lists, so this is a matter of time only)
+    const long long w2 = 2ll * window, ex = b.max_x - b.min_x, ey = b.max_y - b.min_y;
+    const bool bfPossible = (long long)nPairs * ((capl + 255) >> 8) >= 256 && w2 * ORBX_GRID_COLS > (ORBX_GRID_COLS - 3) * ex &&
+                            w2 * ORBX_GRID_ROWS > (ORBX_GRID_ROWS - 3) * ey;
+    if (!mp.noMfma && bfPossible)
       hipLaunchKernelGGL(k_match_bf_mfma, dim3((capl + BF_QWG - 1) / BF_QWG, nPairs), dim3(BF_T), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
                          nmatches, scratch, scratch, stride, capl, diag);
     hipLaunchKernelGGL(k_match_wide_lists, dim3((capl + 63) / 64, nPairs), dim3(256), 0, st, dFirst, dSecond, kps, desc, nkp, mp,

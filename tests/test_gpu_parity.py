@@ -213,6 +213,77 @@ def test_fast_retry_threshold_boundaries(orbx, oracle):
         e.close()
 
 
+def test_fast_retry_cells_on_the_cell_grid(orbx, oracle):
+    """The retry rule cell by cell (cpp:1109-1123): on the FAST cell grid of level 0 (36 x 38 pixel cells from
+    (16, 16)) a chessboard of cells that are EMPTY at iniThFAST and NON-EMPTY at minThFAST (one 3 x 3 block of contrast between the
+    thresholds: swept twice, the second sweep lists it), cells empty at BOTH (flat: k_fast_wave's flat-cell rule skips their second
+    sweep; noise whose largest difference stays below minThFAST: the same; noise that passes the quick reject at minThFAST but
+    holds no arc of 9: swept twice for nothing) and cells with a strong corner (one sweep) -- every kind beside every other,
+    peaks also right at a cell's first and last detected pixel.  Candidates per level and the final result against the oracle,
+    as one frame (k_fast, or k_fast_wave under the module's knob) and as a batch of 12 copies with different noise (k_fast_wave)."""
+    import torch
+    rng = np.random.default_rng(2026)
+    w, h = 640, 480
+    wc, hc = 36, 38  # ceil((640 - 32) / 17), ceil((480 - 32) / 12)
+    for (ini, mn) in ((20, 7), (15, 5)):
+        frames = []
+        for rep in range(12):
+            img = np.full((h, w), 120, np.uint8)
+            for ci in range(12):
+                for cj in range(17):
+                    y0, x0 = 16 + ci * hc, 16 + cj * wc
+                    kind = (ci * 5 + cj * 3 + rep) % 6
+                    # where the block sits inside the cell: anywhere, or in a corner of the cell's own detection area
+                    py, px = (3, 3) if (ci + cj) % 5 == 0 else (hc - 1, wc - 1) if (ci + cj) % 5 == 1 else (int(rng.integers(6, hc - 8)), int(rng.integers(6, wc - 8)))
+                    if kind == 0:      # flat: empty at both
+                        pass
+                    elif kind == 1:    # a peak between the thresholds: empty at iniTh, one corner at minTh (a lone pixel: its ring is the
+                        a = int(rng.integers(mn + 1, ini + 1))  # ground, its strength the contrast; a flat 3 x 3 block ties with itself in the NMS)
+                        img[y0 + py + 1, x0 + px + 1] = 120 + (a if rng.integers(0, 2) else -a)
+                    elif kind == 2:    # a strong peak: listed in the first sweep
+                        img[y0 + py + 1, x0 + px + 1] = 120 + (3 * ini if rng.integers(0, 2) else -3 * ini)
+                    elif kind == 3:    # noise below minTh: no pixel passes the quick reject there
+                        img[y0 + 3:y0 + hc, x0 + 3:x0 + wc] = 120 + rng.integers(0, mn, (hc - 3, wc - 3))
+                    elif kind == 4:    # sparse single pixels of contrast just above minTh: they pass the quick reject of their neighbours' rings
+                        for _ in range(6):
+                            img[y0 + int(rng.integers(4, hc - 4)), x0 + int(rng.integers(4, wc - 4))] = 120 + mn + 2
+                    else:              # a peak exactly AT minTh (strength == minTh: no corner; the cell is swept twice for nothing)
+                        img[y0 + py + 1, x0 + px + 1] = 120 + mn
+            frames.append(img)
+        frames = np.stack(frames)
+        oe = oracle.Extractor(700, 1.2, 4, ini, mn)
+        e1 = orbx.ORBextractor(700, 1.2, 4, ini, mn, max_width=w, max_height=h, max_batch=1)
+        r, k, d = e1(frames[0])
+        ro, ko, do = oe(frames[0])
+        assert r == ro
+        _same(k, d, ko, do)
+        cands = [oe.level_candidates(l) for l in range(4)]
+        for l in range(4):
+            assert np.array_equal(e1.debug_candidates(0, l), cands[l]), (ini, mn, l)
+        # the chessboard really holds cells of every kind at level 0: some corners only below iniTh, none in the flat cells
+        c0 = cands[0]
+        assert len(c0) > 30 and (c0[:, 2] < ini).any() and (c0[:, 2] >= ini).any(), (len(c0), c0[:, 2].min(), c0[:, 2].max())
+        e1.close()
+        B, cap = len(frames), 700
+        eb = orbx.ORBextractor(700, 1.2, 4, ini, mn, max_width=w, max_height=h, max_batch=B)
+        d_img = torch.from_numpy(frames).cuda()
+        d_k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+        d_d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+        d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+        eb.extract_batch_device(d_img, B, w, h, w, w * h, d_k, d_d, d_n, cap)
+        assert eb.debug_last_launch()["fast_wave"] == 1  # (12 x 381 cells: beyond k_fast's launch size)
+        n = d_n.cpu().numpy()
+        kk = d_k.cpu().numpy().view(orbx.KEYPOINT_DTYPE).reshape(B, cap)
+        dd = d_d.cpu().numpy().reshape(B, cap, 32)
+        for f in range(B):
+            _, ko, do = oe(frames[f], cap=cap)
+            assert n[f] == len(ko), (ini, mn, f, n[f], len(ko))
+            _same(kk[f, :n[f]], dd[f, :n[f]], ko, do)
+            for l in (0, 3):
+                assert np.array_equal(eb.debug_candidates(f, l), oe.level_candidates(l)), (ini, mn, f, l)
+        eb.close()
+
+
 def test_other_pyramid_parameters(orbx, oracle, images):
     for p in ((1250, 1.2, 8, 20, 7), (300, 1.5, 4, 30, 10), (700, 1.1, 10, 12, 12), (200, 1.2, 1, 20, 7)):
         e = orbx.ORBextractor(*p, max_width=640, max_height=480, max_batch=1)
