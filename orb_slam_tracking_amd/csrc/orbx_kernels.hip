@@ -2489,7 +2489,11 @@ __global__ __launch_bounds__(MW_T) void k_match_wide_prep(const int* __restrict_
   matchWidePrep<MW_T>(pair, pairFirst, pairSecond, kps, nkp, mp, matches12, scratch, scratchStride, capl);
 }
 
-__global__ __launch_bounds__(256) void k_match_wide_lists(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
+// NW = waves per workgroup that share the trains of the workgroup's 64 queries: 4 when the launch has workgroups enough to fill the
+// chip (64 sets of 2000 x 2000: 2048), 8 when it has not (round 6: sixteen 1080p pairs are 112 workgroups, ONE 2000 x 2000
+// match is 32 -- with four waves each the list kernel ran on a fraction of the CUs for 38 and ~16 us)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_match_wide_lists(const int* __restrict__ pairFirst, const int* __restrict__ pairSecond,
                                                          const orbx_keypoint* __restrict__ kps,
                                                          const uint8_t* __restrict__ desc, const int* __restrict__ nkp,
                                                          const MatchParams mp, const int* __restrict__ nmatchesOut,
@@ -2542,7 +2546,7 @@ __global__ __launch_bounds__(256) void k_match_wide_lists(const int* __restrict_
   const int minCY = max(0, (int)floorf((qy - fminY - r) * hInv));
   const int maxCY = min(ORBX_GRID_ROWS - 1, (int)ceilf((qy - fminY + r) * hInv));
   // the trains lie sorted by grid column: only the columns some window of this workgroup's queries reaches are walked (the cell
-  // test of every query stays as it is), a quarter of that range per wave
+  // test of every query stays as it is), an NW-th of that range per wave
   int cLo = valid ? minCX : ORBX_GRID_COLS, cHi = valid ? maxCX : -1;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { cLo = min(cLo, __shfl_xor(cLo, o)); cHi = max(cHi, __shfl_xor(cHi, o)); }
@@ -2550,7 +2554,7 @@ __global__ __launch_bounds__(256) void k_match_wide_lists(const int* __restrict_
   cHi = __builtin_amdgcn_readfirstlane(cHi);
   const int rLo = !byCol || cHi < cLo ? 0 : cxStart[min(max(cLo, 0), ORBX_GRID_COLS)];
   const int rHi = !byCol ? nT : (cHi < cLo ? 0 : min(nT, cxStart[min(max(cHi + 1, 0), ORBX_GRID_COLS)]));
-  const int chunk = (rHi - rLo + 3) >> 2;
+  const int chunk = (rHi - rLo + NW - 1) / NW;
   // (the walk's bounds in scalar registers: the train records and descriptors below must stay wave-uniform scalar loads)
   const int e0 = __builtin_amdgcn_readfirstlane(rLo + part * chunk), e1 = __builtin_amdgcn_readfirstlane(min(rHi, rLo + part * chunk + chunk));
   bool any = false;
@@ -2598,7 +2602,7 @@ __global__ __launch_bounds__(256) void k_match_wide_lists(const int* __restrict_
   // in flight while this one is matched) and every query lane then reads a train's 256 bits as two LDS broadcasts -- the scalar
   // loads of the general path left the wave waiting for every group of four trains (0.55 of the issue cycles; 217 us per
   // 64 x 2000^2 pairs).  The loop is the 16 xor / bcnt operations, a compare and, rarely, an append.
-  __shared__ uint4 stageD[4][2][64][2];  // [wave][buffer][train][half]
+  __shared__ uint4 stageD[NW][2][64][2];  // [wave][buffer][train][half]
   auto scanAllLds = [&]() {
     uint4 (*st)[64][2] = stageD[part];
     auto fetch = [&](const int eb, uint4& a, uint4& b) {
@@ -3612,8 +3616,15 @@ hipError_t launch_match(hipStream_t st, int nPairs, const int* dFirst, const int
     if (!mp.noMfma && bfPossible)
       hipLaunchKernelGGL(k_match_bf_mfma, dim3((capl + BF_QWG - 1) / BF_QWG, nPairs), dim3(BF_T), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
                          nmatches, scratch, scratch, stride, capl, diag);
-    hipLaunchKernelGGL(k_match_wide_lists, dim3((capl + 63) / 64, nPairs), dim3(256), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
-                       nmatches, scratch, scratch, stride, capl);
+    {
+      const long long wgs = (long long)nPairs * ((capl + 63) / 64);
+      if (wgs <= 512)
+        hipLaunchKernelGGL(k_match_wide_lists<8>, dim3((capl + 63) / 64, nPairs), dim3(512), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
+                           nmatches, scratch, scratch, stride, capl);
+      else
+        hipLaunchKernelGGL(k_match_wide_lists<4>, dim3((capl + 63) / 64, nPairs), dim3(256), 0, st, dFirst, dSecond, kps, desc, nkp, mp,
+                           nmatches, scratch, scratch, stride, capl);
+    }
     const int qpw = (long long)nPairs * capl >= 100000 ? 16 : 4;  // queries per wave of k_match_wide_sort
     hipLaunchKernelGGL(k_match_wide_sort, dim3((capl + 4 * qpw - 1) / (4 * qpw), nPairs), dim3(256), 0, st, mp, nmatches, scratch, stride,
                        capl, qpw);
