@@ -905,21 +905,11 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
     typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
     constexpr int NQ = TS / 16;
     const int stride = (int)c.stride;
-    const uint8_t* p = base + (unsigned)(lane * stride);
-    u32x4_a4 q[NQ];
-#pragma unroll
-    for (int j = 0; j < NQ; j++) q[j] = u32x4_a4{0u, 0u, 0u, 0u};
     if (lane < ch) {
+      const uint8_t* p = base + (unsigned)(lane * stride);
+      u32x4_a4 q[NQ];
 #pragma unroll
       for (int j = 0; j < NQ; j++) q[j] = *reinterpret_cast<const u32x4_a4*>(p + 16 * j);
-    }
-    // (the strength map is cleared while the rows are on their way: rows 0 .. ih + 1)
-    {
-      const int ihc = (int)(c.iw_ih >> 16);
-      uint4* const s128 = reinterpret_cast<uint4*>(smap);
-      for (int i = lane; i < (ihc + 2) * (TS / 16); i += 64) s128[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    if (lane < ch) {
       uint4* const dst = reinterpret_cast<uint4*>(tile + lane * TS);
 #pragma unroll
       for (int j = 0; j < NQ; j++) dst[j] = make_uint4(q[j].x, q[j].y, q[j].z, q[j].w);
@@ -927,6 +917,10 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
   }
   const int iw = (int)(c.iw_ih & 0xffffu), ih = (int)(c.iw_ih >> 16), xoff = (int)(c.xoff_level & 0xffffu);
   const int ox = (int)(int16_t)(c.ox_oy & 0xffffu), oy = (int)(c.ox_oy >> 16);
+  {  // strength map rows 0 .. ih + 1
+    uint4* const s128 = reinterpret_cast<uint4*>(smap);
+    for (int i = lane; i < (ih + 2) * (TS / 16); i += 64) s128[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
   __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order; this only pins the compiler's order)
 #ifdef ORBX_FAST_STAMPS
   __builtin_amdgcn_s_waitcnt(0);  // charge the staging phase with its loads
