@@ -783,32 +783,6 @@ __device__ __forceinline__ int fwStrength(const uint32_t e) {
                           C - 3 * TS,  C - 3 * TS - 1, C - 2 * TS - 2, C - TS - 3, C - 3,  C + TS - 3, C + 2 * TS - 2, C + 3 * TS - 1};
   const fw_lds_u8* const p = fwLds8(e);
   const int v = p[C];
-#if FW_CPW > 1
-  // (register-lean form for the prefetching kernel: one side after the other, the ring read again for the second -- sixteen more LDS
-  // reads and subtractions per evaluation instead of sixteen more registers)
-  int smn = -256, smx = 256;
-  {
-    int d[16], mn3[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = v - (int)p[ro[k]];
-#pragma unroll
-    for (int k = 0; k < 16; k++) mn3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) smn = max(smn, min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]));
-  }
-  asm volatile("" : "+v"(smn) :: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  {
-    int d[16], mx3[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = v - (int)p[ro[k]];
-#pragma unroll
-    for (int k = 0; k < 16; k++) mx3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) smx = min(smx, max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]));
-  }
-  return max(smn, -smx);
-#else
   int d[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) d[k] = v - (int)p[ro[k]];
@@ -825,7 +799,6 @@ __device__ __forceinline__ int fwStrength(const uint32_t e) {
     smx = min(smx, max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]));
   }
   return max(smn, -smx);
-#endif
 }
 
 typedef short short2v __attribute__((ext_vector_type(2)));
@@ -911,64 +884,37 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
   const int f = blockIdx.y + g.frame0;
   const int cid0 = grp * FW_CPW, cid1 = min(cid0 + FW_CPW, g.nCellsTotal);
   FW_STAMP_INIT();
-  // ---- the image rows of a cell: LANE = TILE ROW (a cell image has at most 64 rows), the row's TS bytes as TS / 16 16-byte loads
+  for (int cid = cid0; cid < cid1; cid++) {
+  const FastCell c = cells[cid];  // wave-uniform: one s_load_dwordx8
+  int* const myCount = cellCount + (long long)f * g.nCellsTotal + cid;
+  const int ch = (int)(c.nw_ch >> 16);
+  if (ch == 0) {  // every cell writes its counter (also 0), so the counters need no clearing between batches
+    if (lane == 0) *myCount = 0;
+    continue;
+  }
+  const int level = (int)(c.xoff_level >> 16);
+  const LevelGeom& L = g.L[level];
+  const uint8_t* const base =
+      (level == 0 ? img0 + (long long)f * img0FrameStride : pyr + L.imgOff + (long long)f * L.frameStride) + c.imgOff;
+  // ---- stage the cell image: LANE = TILE ROW (a cell image has at most 64 rows), the row's TS bytes as TS / 16 16-byte loads
   //      (4-byte aligned global_load_dwordx4) and as many ds_write_b128 -- 3 + 3 instructions per cell instead of 9 + 9 with
   //      lane = (row mod 5, dword) (round 5: the CU's vector-memory path charges per instruction and lane, k_describe_patch).
   //      Dwords beyond the cell's own nw hold the pixels to its right (inside the level's row or its padding: a cell image ends at
   //      least ten bytes before the row does, and thirteen rows before the level does); nothing reads them unmasked ----
-  typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-  constexpr int NQ = TS / 16;
-  u32x4_a4 q[NQ];
-#pragma unroll
-  for (int j = 0; j < NQ; j++) q[j] = u32x4_a4{0u, 0u, 0u, 0u};
-  auto loadRows = [&](const FastCell& c) {
-    const int ch = (int)(c.nw_ch >> 16), level = (int)(c.xoff_level >> 16);
-    const LevelGeom& L = g.L[level];
-    const uint8_t* const base =
-        (level == 0 ? img0 + (long long)f * img0FrameStride : pyr + L.imgOff + (long long)f * L.frameStride) + c.imgOff;
+  {
+    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    constexpr int NQ = TS / 16;
+    const int stride = (int)c.stride;
     if (lane < ch) {
-      const uint8_t* p = base + (unsigned)(lane * (int)c.stride);
+      const uint8_t* p = base + (unsigned)(lane * stride);
+      u32x4_a4 q[NQ];
 #pragma unroll
       for (int j = 0; j < NQ; j++) q[j] = *reinterpret_cast<const u32x4_a4*>(p + 16 * j);
-    }
-  };
-  // ---- FW_CPW > 1 (round 6): while a wave works on a cell, the NEXT cell's rows are on their way, and the cell's own candidates are
-  //      written out only after the next cell's rows have been waited for and staged.  (The wait for loads that sit BEHIND stores in
-  //      gfx950's one vector-memory counter is a wait for those stores too.)  The candidates of up to four NMS rounds (256 corners,
-  //      the corner list's capacity) wait in four registers; a cell that takes the scan path below stores directly ----
-  constexpr uint32_t FW_NONE = 0xffffffffu;
-  uint32_t outv[4] = {FW_NONE, FW_NONE, FW_NONE, FW_NONE};
-  uint32_t* outDst = nullptr;
-  int* outCountPtr = nullptr;
-  int outCount = 0, outSegCap = 0;
-  bool outPending = false;
-  auto flushOut = [&]() {
-    if (!outPending) return;  // (uniform)
-    int slot0 = 0;
+      uint4* const dst = reinterpret_cast<uint4*>(tile + lane * TS);
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const bool have = outv[r] != FW_NONE;
-      const unsigned long long mk = __ballot(have);
-      if (mk != 0ull) {
-        const int slot = slot0 + fwMbcnt(mk);
-        if (have && slot < outSegCap) outDst[slot] = outv[r];
-        slot0 += (int)__popcll(mk);
-      }
-      outv[r] = FW_NONE;
+      for (int j = 0; j < NQ; j++) dst[j] = make_uint4(q[j].x, q[j].y, q[j].z, q[j].w);
     }
-    if (lane == 0) *outCountPtr = min(outCount, outSegCap);  // nOut <= segCap: NMS survivors are never 8-neighbours
-    outPending = false;
-  };
-  // one cell, its image rows staged in the tile
-  auto doCell = [&](const FastCell& c, const int cid) {
-  int* const myCount = cellCount + (long long)f * g.nCellsTotal + cid;
-  const int ch = (int)(c.nw_ch >> 16);
-  if (ch == 0) {  // every cell writes its counter (also 0), so the counters need no clearing between batches
-    outDst = nullptr; outCountPtr = myCount; outCount = 0; outSegCap = 0; outPending = true;
-    return;
   }
-  const int level = (int)(c.xoff_level >> 16);
-  const LevelGeom& L = g.L[level];
   const int iw = (int)(c.iw_ih & 0xffffu), ih = (int)(c.iw_ih >> 16), xoff = (int)(c.xoff_level & 0xffffu);
   const int ox = (int)(int16_t)(c.ox_oy & 0xffffu), oy = (int)(c.ox_oy >> 16);
   {  // strength map rows 0 .. ih + 1
@@ -1119,7 +1065,7 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
     __builtin_amdgcn_wave_barrier();
     FW_STAMP(2);
     // ---- in-cell NMS on the strength map; survivors are the cell's keypoints ----
-    auto nms = [&](const uint32_t eIn, const bool act, uint32_t* const later) {  // later: the round's register of `outv`, or null
+    auto nms = [&](const uint32_t eIn, const bool act) {
       const uint32_t e = act ? eIn : eIdle;
       const fw_lds_u8* const q = fwLds8(e + kN);  // top-left of the 3 x 3 block in the strength map
       // all nine reads are issued together (short-circuit tests would chain nine LDS round trips)
@@ -1128,24 +1074,18 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
       const int nmax = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
       const bool keep = act && sv > 1 && sv > nmax;
       const unsigned long long mk = __ballot(keep);
-      // tile row = y - oy, tile column = x - ox; o / TS by multiply-shift (exact for o < 2^12)
-      const int o = (int)(e - tileAddr) + 3 * TS + 3;
-      const int row = TS == 64 ? (o >> 6) : (int)(((uint32_t)o * 43691u) >> 21);
-      static_assert(TS == 64 || TS == 48, "row split of a tile offset");
-      const uint32_t cw = packCand(o - row * TS + ox, row + oy, sv - 1);
-      if (later) {
-        *later = keep ? cw : FW_NONE;
-      } else if (keep) {
+      if (keep) {
         const int slot = nOut + fwMbcnt(mk);
-        if (slot < segCap) dstc[slot] = cw;
+        // tile row = y - oy, tile column = x - ox; o / TS by multiply-shift (exact for o < 2^12)
+        const int o = (int)(e - tileAddr) + 3 * TS + 3;
+        const int row = TS == 64 ? (o >> 6) : (int)(((uint32_t)o * 43691u) >> 21);
+        static_assert(TS == 64 || TS == 48, "row split of a tile offset");
+        if (slot < segCap) dstc[slot] = packCand(o - row * TS + ox, row + oy, sv - 1);
       }
       nOut += (int)__popcll(mk);
     };
     if (nCorn <= FW_CORN) {
-      static_assert(FW_CORN == 4 * 64, "the deferred candidates of a cell: one register per NMS round");
-#pragma unroll
-      for (int r = 0; r < 4; r++)
-        if (64 * r < nCorn) nms((uint32_t)fwLds16(cornAddr)[min(64 * r + lane, FW_CORN - 1)], 64 * r + lane < nCorn, &outv[r]);
+      for (int e0 = 0; e0 < nCorn; e0 += 64) nms((uint32_t)fwLds16(cornAddr)[min(e0 + lane, FW_CORN - 1)], e0 + lane < nCorn);
     } else {  // more corners than the list holds (noise at a low threshold): scan the strength map instead
       const uint32_t invw = c_inv20.v[iw];
       const int py0 = (int)(((uint32_t)lane * invw) >> 20), px0 = lane - py0 * iw;
@@ -1157,7 +1097,7 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
         const bool live = idx0 + lane < npix;
         const int sv = live ? (int)fwLds8(e + kS)[0] : 0;
         const unsigned long long any = __ballot(sv > 0);
-        if (any) nms(e, sv > 0, nullptr);
+        if (any) nms(e, sv > 0);
         px += dpx;
         e += (uint32_t)(dpy * TS + dpx);
         if (px >= iw) { px -= iw; e += (uint32_t)(TS - iw); }
@@ -1171,28 +1111,9 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
       if (flat && __ballot((__builtin_bit_cast(uint32_t, looseMin - dth) & 0x80008000u) != 0u) == 0ull) break;
     }
   }
-  outDst = dstc; outCountPtr = myCount; outCount = nOut; outSegCap = segCap; outPending = true;
-  };  // doCell
-  FastCell c = cells[cid0];  // wave-uniform: one s_load_dwordx8
-  loadRows(c);
-#pragma clang loop unroll(disable)
-  for (int cid = cid0; cid < cid1; cid++) {
-    if (lane < (int)(c.nw_ch >> 16)) {  // this cell's rows into the tile ...
-      uint4* const dst = reinterpret_cast<uint4*>(tile + lane * TS);
-#pragma unroll
-      for (int j = 0; j < NQ; j++) dst[j] = make_uint4(q[j].x, q[j].y, q[j].z, q[j].w);
-    }
-    flushOut();  // ... the previous cell's candidates out ...
-    FastCell cn = c;
-    if (cid + 1 < cid1) {  // ... and the next cell's rows on their way
-      cn = cells[cid + 1];
-      loadRows(cn);
-    }
-    doCell(c, cid);
-    __builtin_amdgcn_wave_barrier();  // the next cell's staging stores come after this cell's last LDS reads
-    c = cn;
-  }
-  flushOut();
+  if (lane == 0) *myCount = min(nOut, segCap);  // nOut <= segCap: NMS survivors are never 8-neighbours
+  __builtin_amdgcn_wave_barrier();  // the next cell's staging stores come after this cell's last LDS reads
+  }  // cells of this wave
   FW_STAMP_FLUSH();
 }
 #ifdef ORBX_FAST_STAMPS
