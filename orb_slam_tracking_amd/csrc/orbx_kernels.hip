@@ -882,7 +882,10 @@ __global__ __launch_bounds__(64) void k_fast_wave(const uint8_t* __restrict__ im
   const int grp = ((xi / FW_XK) * 8 + xq) * FW_XK + (xi % FW_XK);
   if (grp >= nGroups) return;
   const int f = blockIdx.y + g.frame0;
-  const int cid0 = grp * FW_CPW, cid1 = min(cid0 + FW_CPW, g.nCellsTotal);
+  // (a frame's groups from the LAST one down: the cells of the small top levels hold about twice the corners of a level-0 cell, and
+  // the workgroups dispatched last are the launch's tail -- with the light level-0 cells there, 0.202 - 0.203 against 0.206 - 0.207 ms
+  // alone per 256 frames, round 6)
+  const int cid0 = (nGroups - 1 - grp) * FW_CPW, cid1 = min(cid0 + FW_CPW, g.nCellsTotal);
   FW_STAMP_INIT();
   for (int cid = cid0; cid < cid1; cid++) {
   const FastCell c = cells[cid];  // wave-uniform: one s_load_dwordx8
